@@ -1,0 +1,347 @@
+"""CPU oracle for the mdir / cirtorch descriptor-extraction-and-ranking hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a plain numpy restatement of the
+reference's arithmetic, written from the reference's behaviour (file:line cited
+per function, paths relative to the upstream repo).  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it -- never the product package ``mdir_amd``: the product path must fail
+loudly when the HIP library is missing, it has no CPU fallback.
+
+Parity pin: the reference ships NO tests or golden vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, generated in the build container by ``tests/golden/make_golden.py``
+(which imports the reference with throw-away stubs for torchvision/cv2/h5py)
+and committed as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks
+every function below against them.
+
+All arithmetic is float32 unless stated (the reference computes in fp32 on the
+device and in float64 only inside compute_map / whitenapply-with-f64-P).
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# a4 / a5: pooling and normalisation
+# --------------------------------------------------------------------------
+
+def gem(x, p=3.0, eps=1e-6):
+    """Generalised-mean pooling of a feature map batch ``[B,C,H,W] -> [B,C]``.
+
+    Reference: ``mdir/external/cirtorch/layers/functional.py:21-22`` --
+    clamp to ``eps`` from below, raise to ``p``, average over the whole H x W
+    window, raise to ``1/p`` (``1/p`` is itself rounded to fp32 because ``p`` is
+    an fp32 Parameter, ``layers/pooling.py:36-44``).
+    """
+    x = np.asarray(x, dtype=F32)
+    p32 = F32(p)
+    powed = np.power(np.maximum(x, F32(eps)), p32, dtype=F32)
+    mean = powed.reshape(x.shape[0], x.shape[1], -1).mean(axis=2, dtype=F32)
+    return np.power(mean, F32(1.0) / p32, dtype=F32)
+
+
+def mac(x):
+    """Global max pooling ``[B,C,H,W] -> [B,C]`` (``layers/functional.py:11-12``)."""
+    x = np.asarray(x, dtype=F32)
+    return x.reshape(x.shape[0], x.shape[1], -1).max(axis=2)
+
+
+def spoc(x):
+    """Global average pooling ``[B,C,H,W] -> [B,C]`` (``layers/functional.py:16-17``)."""
+    x = np.asarray(x, dtype=F32)
+    return x.reshape(x.shape[0], x.shape[1], -1).mean(axis=2, dtype=F32)
+
+
+def l2n(x, eps=1e-6):
+    """L2-normalise over axis 1 with eps ADDED TO THE NORM.
+
+    Reference: ``layers/functional.py:130-131``.  A zero vector maps to zero
+    (never NaN) because the divisor is ``0 + eps``.
+    """
+    x = np.asarray(x, dtype=F32)
+    nrm = np.sqrt(np.sum(x * x, axis=1, keepdims=True, dtype=F32), dtype=F32)
+    return (x / (nrm + F32(eps))).astype(F32)
+
+
+def forward_tail(feat, p=3.0, eps=1e-6, whiten_w=None, whiten_b=None, pooling="gem"):
+    """Everything ``ImageRetrievalNet.forward`` does after ``features``.
+
+    Reference: ``networks/imageretrievalnet.py:107-115``: pool -> L2N ->
+    (optional ``nn.Linear`` whitening -> L2N) -> permute to ``[D,B]``.
+    """
+    pooled = {"gem": lambda t: gem(t, p, eps), "mac": mac, "spoc": spoc}[pooling](feat)
+    o = l2n(pooled)
+    if whiten_w is not None:
+        w = np.asarray(whiten_w, dtype=F32)
+        o = o @ w.T
+        if whiten_b is not None:
+            o = o + np.asarray(whiten_b, dtype=F32)[None, :]
+        o = l2n(o.astype(F32))
+    return np.ascontiguousarray(o.T)
+
+
+# --------------------------------------------------------------------------
+# a7: multi-scale aggregation
+# --------------------------------------------------------------------------
+
+MS_SCALES = (1.0, 1.0 / np.sqrt(2.0), 0.5)  # mdir/components/data/wrapper.py:93
+
+
+def ms_aggregate(vecs, msp=1.0):
+    """Aggregate ``S`` per-scale descriptors ``[S,D] -> [D]``.
+
+    Reference: ``mdir/components/data/wrapper.py:109-119`` (mdir path) and
+    ``networks/imageretrievalnet.py:309-324`` (cirtorch path): power-mean with
+    exponent ``msp`` then divide by the plain L2 norm -- NO eps here.
+    """
+    vecs = np.asarray(vecs, dtype=F32)
+    msp32 = F32(msp)
+    acc = np.zeros(vecs.shape[1], dtype=F32)
+    for v in vecs:  # sequential, in scale order, like the reference's += loop
+        acc = acc + np.power(v, msp32, dtype=F32)
+    v = np.power(acc / F32(vecs.shape[0]), F32(1.0) / msp32, dtype=F32)
+    return (v / np.sqrt(np.sum(v * v, dtype=F32), dtype=F32)).astype(F32)
+
+
+def ms_power(model_meta, nscales, pool_p):
+    """Which exponent the mdir wrapper aggregates with.
+
+    Reference: ``wrapper.py:121-124``: ``pool.p`` iff more than one scale, GeM
+    pooling, not regional, and the MODEL has no in-network whitening; else 1.
+    """
+    if nscales > 1 and model_meta["pooling"] == "gem" and not model_meta["regional"] \
+            and not model_meta["whitening"]:
+        return float(pool_p)
+    return 1.0
+
+
+# --------------------------------------------------------------------------
+# a8: whitening projection
+# --------------------------------------------------------------------------
+
+def whiten_wrapper(v, m, P, dimensions=None):
+    """``CirtorchWhiten.postprocess`` for one descriptor ``[D] -> [d]`` in fp32.
+
+    Reference: ``mdir/components/data/wrapper.py:186-195``: P and m are cast to
+    fp32, ``X = P[:d] @ (v - m)``, then ``X / (||X|| + 1e-6)``.
+    """
+    P = np.asarray(P, dtype=F32)
+    m = np.asarray(m, dtype=F32).reshape(-1)
+    v = np.asarray(v, dtype=F32).reshape(-1)
+    d = dimensions or P.shape[0]
+    X = (P[:d, :] @ (v - m)).astype(F32)
+    return (X / (np.sqrt(np.sum(X * X, dtype=F32), dtype=F32) + F32(1e-6))).astype(F32)
+
+
+def whitenapply(X, m, P, dimensions=None):
+    """Batched whitening ``[D,N] -> [d,N]`` in the dtype numpy promotes to.
+
+    Reference: ``mdir/external/cirtorch/utils/whiten.py:4-12``.
+    """
+    d = dimensions or P.shape[0]
+    Y = np.dot(P[:d, :], X - m)
+    return Y / (np.linalg.norm(Y, ord=2, axis=0, keepdims=True) + 1e-6)
+
+
+# --------------------------------------------------------------------------
+# a11 / a12: similarity and ranking
+# --------------------------------------------------------------------------
+
+def scores(vecs, qvecs):
+    """``[D,N]`` database x ``[D,Q]`` queries -> fp32 ``[N,Q]`` similarity.
+
+    Reference: ``mdir/components/optim/score/cirscore.py:69``
+    (same statement at ``cirtorch/examples/test.py:240``).
+    """
+    return np.dot(np.asarray(vecs, dtype=F32).T, np.asarray(qvecs, dtype=F32))
+
+
+def ranks(sc):
+    """Per-query descending ranking ``[N,Q] -> int64 [N,Q]``.
+
+    Reference: ``cirscore.py:70``.  numpy's default sort is not stable, so tie
+    order is implementation-defined there; the build's rule (and this
+    oracle's) is descending score, ascending database id -- one of the orders
+    the reference may legally produce.
+    """
+    return np.argsort(-np.asarray(sc), axis=0, kind="stable")
+
+
+def rank_of(sc, ids):
+    """Zero-based rank position of each database id in ``ids`` for ONE query.
+
+    ``sc`` is that query's score column ``[N]``.  Position = number of items
+    strictly better, plus equal-scored items with a smaller id (the tie rule of
+    :func:`ranks`).  Equals ``np.nonzero(ranks(sc)[:, None] == ids)`` without
+    materialising the ranking; feeds :func:`compute_ap` exactly like
+    ``evaluate.py:80-81`` does through ``np.in1d``.
+    """
+    sc = np.asarray(sc)
+    ids = np.asarray(ids, dtype=np.int64)
+    key = -sc
+    out = np.empty(len(ids), dtype=np.int64)
+    for t, i in enumerate(ids):
+        better = np.count_nonzero(key < key[i])
+        tied_before = np.count_nonzero(key[:i] == key[i])
+        out[t] = better + tied_before
+    return out
+
+
+def topk(sc, k):
+    """First ``k`` rows of :func:`ranks` plus their scores (``[k,Q]`` each)."""
+    r = ranks(sc)[:k]
+    return r, np.take_along_axis(np.asarray(sc), r, axis=0)
+
+
+# --------------------------------------------------------------------------
+# a13: mean average precision
+# --------------------------------------------------------------------------
+
+def compute_ap(pos, nres):
+    """Average precision from zero-based ranks of the positives.
+
+    Reference: ``mdir/external/cirtorch/utils/evaluate.py:3-37``: area under
+    the precision/recall polyline, one trapezoid per positive, accumulated in
+    order in float64.
+    """
+    ap = 0.0
+    step = 1.0 / nres
+    for j, rank in enumerate(pos):
+        rank = int(rank)
+        before = 1.0 if rank == 0 else float(j) / rank
+        after = float(j + 1) / (rank + 1)
+        ap += (before + after) * step / 2.0
+    return ap
+
+
+def _junk_shift(pos, junk):
+    """Move each positive up by the number of junk items ranked before it
+    (``evaluate.py:85-94``).  Both inputs ascending."""
+    return pos - np.searchsorted(junk, pos, side="left")
+
+
+def ap_from_positions(pos, junk, nok, kappas=()):
+    """AP and precision@kappas for one query from rank POSITIONS.
+
+    ``pos`` / ``junk``: ascending zero-based positions in the ranking of the
+    positive / junk database ids; ``nok`` = number of positives.  This is the
+    body of the per-query loop of ``evaluate.py:79-106``.
+    """
+    pos = _junk_shift(np.asarray(pos, dtype=np.int64), np.asarray(junk, dtype=np.int64))
+    ap = compute_ap(pos, nok)
+    pos1 = pos + 1
+    prs = np.zeros(len(kappas))
+    for j, kappa in enumerate(kappas):
+        kq = min(int(pos1.max()), kappa)
+        prs[j] = np.count_nonzero(pos1 <= kq) / kq
+    return ap, prs
+
+
+def compute_map(rk, gnd, kappas=()):
+    """mAP over queries: ``(map, aps[Q], pr[K], prs[Q,K])``.
+
+    Reference: ``evaluate.py:39-111``.  ``rk`` is ``[N,Q]`` (column q = database
+    ids best to worst), ``gnd[q]`` has ``ok`` and optionally ``junk`` id lists.
+    Queries without positives get NaN and are left out of the mean (:68-72,108).
+    """
+    nq = len(gnd)
+    aps = np.zeros(nq)
+    prs = np.zeros((nq, len(kappas)))
+    pr = np.zeros(len(kappas))
+    total = 0.0
+    nempty = 0
+    where = np.arange(rk.shape[0])
+    for q in range(nq):
+        ok = np.array(gnd[q]["ok"])
+        if ok.shape[0] == 0:
+            aps[q] = np.nan
+            prs[q, :] = np.nan
+            nempty += 1
+            continue
+        junk_ids = np.array(gnd[q]["junk"]) if "junk" in gnd[q] else np.empty(0)
+        column = rk[:, q]
+        pos = where[np.isin(column, ok)]
+        junk = where[np.isin(column, junk_ids)]
+        ap, prs[q, :] = ap_from_positions(pos, junk, len(ok), kappas)
+        aps[q] = ap
+        total += ap
+        pr = pr + prs[q, :]
+    return total / (nq - nempty), aps, pr / (nq - nempty), prs
+
+
+def protocol_gnd(gnd, level):
+    """Revisited-Oxford/Paris regrouping into ok/junk for easy|medium|hard
+    (``evaluate.py:125-147``)."""
+    ok_keys, junk_keys = {"easy": (("easy",), ("junk", "hard")),
+                          "medium": (("easy", "hard"), ("junk",)),
+                          "hard": (("hard",), ("junk", "easy"))}[level]
+    out = []
+    for g in gnd:
+        out.append({"ok": np.concatenate([g[k] for k in ok_keys]),
+                    "junk": np.concatenate([g[k] for k in junk_keys])})
+    return out
+
+
+def compute_map_and_print(dataset, rk, gnd, kappas=(1, 5, 10)):
+    """``(averages, per_query)`` dictionaries, reference key names.
+
+    Reference: ``evaluate.py:114-152`` (the mdir-patched variant that RETURNS
+    dictionaries): old protocol when the first gnd entry has ``ok``; revisited
+    protocol for ``roxford5k*`` / ``rparis6k*``; anything else returns None.
+    """
+    if "ok" in gnd[0]:
+        m, aps, _, _ = compute_map(rk, gnd)
+        return {"map": m}, {"ap": aps}
+    if dataset.startswith("roxford5k") or dataset.startswith("rparis6k"):
+        avg, per = {}, {}
+        for level in ("easy", "medium", "hard"):
+            m, aps, _, _ = compute_map(rk, protocol_gnd(gnd, level), list(kappas))
+            avg["map_" + level] = m
+            per["ap_" + level] = aps
+        return avg, per
+    return None
+
+
+def nanmean_metric(per_query):
+    """The number eval.py prints: nan-filtered mean of the per-query rows
+    (``mdir/tools/eventprocessor.py:101-115``)."""
+    v = np.asarray(per_query, dtype=np.float64)
+    return float(np.mean(v[~np.isnan(v)]))
+
+
+# --------------------------------------------------------------------------
+# synthetic workloads shared by tests and bench
+# --------------------------------------------------------------------------
+
+def synth_ranking_problem(n, q=70, d=2048, seed=0, noise=0.05, dtype=F32):
+    """Database ``[D,N]`` + queries ``[D,Q]`` in the REFERENCE layout.
+
+    Rows i.i.d. N(0,1), L2-normalised; queries = ``q`` distinct database rows
+    plus ``noise`` * N(0,1), re-normalised.  Generated in row blocks so the 1 M
+    case never holds more than one float64 block at a time.
+    """
+    rng = np.random.default_rng(seed)
+    vecs = np.empty((d, n), dtype=dtype)
+    block = 65536
+    for s in range(0, n, block):
+        e = min(n, s + block)
+        blk = rng.standard_normal((e - s, d), dtype=np.float32)
+        blk /= np.linalg.norm(blk, axis=1, keepdims=True)
+        vecs[:, s:e] = blk.T
+    qid = rng.choice(n, size=q, replace=False)
+    qv = vecs[:, qid].T.astype(np.float32) + noise * rng.standard_normal((q, d), dtype=np.float32)
+    qv /= np.linalg.norm(qv, axis=1, keepdims=True)
+    return vecs, np.ascontiguousarray(qv.T.astype(dtype)), qid
+
+
+def synth_gnd(nq, n_labelled, seed=1, easy=5, hard=10, junk=5):
+    """rOxford-shaped ground truth: disjoint random ids from the first
+    ``n_labelled`` database rows per query."""
+    rng = np.random.default_rng(seed)
+    gnd = []
+    for _ in range(nq):
+        ids = rng.choice(n_labelled, size=easy + hard + junk, replace=False)
+        gnd.append({"easy": np.sort(ids[:easy]), "hard": np.sort(ids[easy:easy + hard]),
+                    "junk": np.sort(ids[easy + hard:]), "bbx": None})
+    return gnd

@@ -1,0 +1,179 @@
+"""The CPU oracle against outputs of the reference itself (tests/golden, made by
+make_golden.py).  This is what pins the oracle; the GPU tests then compare the
+HIP path with the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, sparse_map
+from oracle import chain as OC
+from oracle import oracle as O
+
+
+def test_g1_pooling(golden):
+    g = golden("g1_pool.npz")
+    for c, h, w in [(2048, 24, 32), (2048, 17, 23), (512, 48, 64), (256, 7, 5)]:
+        x = sparse_map(int(g[f"seed_c{c}_h{h}_w{w}"]), (1, c, h, w))
+        for p in (3.0, 2.2, 1.0):
+            np.testing.assert_allclose(O.gem(x, p)[0], g[f"gem_c{c}_h{h}_w{w}_p{p}"], rtol=5e-6, atol=1e-7)
+        np.testing.assert_array_equal(O.mac(x)[0], g[f"mac_c{c}_h{h}_w{w}"])
+        np.testing.assert_allclose(O.spoc(x)[0], g[f"spoc_c{c}_h{h}_w{w}"], rtol=5e-6)
+    np.testing.assert_array_equal(sparse_map(103, (1, 256, 7, 5)), g["x_c256_h7_w5"])
+
+
+def test_g2_l2n(golden):
+    g = golden("g2_l2n.npz")
+    y = O.l2n(g["x"])
+    np.testing.assert_allclose(y, g["y"], rtol=1e-6, atol=1e-9)
+    assert np.all(y[2] == 0) and not np.isnan(y).any()
+
+
+def test_g3_forward_tail(golden):
+    g = golden("g3_tail.npz")
+    for p in (3.0, 2.92):
+        np.testing.assert_allclose(O.forward_tail(g["feat"], p), g[f"out_plain_p{p}"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(O.forward_tail(g["feat"], p, whiten_w=g["w"], whiten_b=g["b"]),
+                                   g[f"out_whiten_p{p}"], rtol=1e-5, atol=2e-7)
+
+
+def test_g4_aggregate(golden):
+    g = golden("g4_aggregate.npz")
+    for msp in (1.0, 3.0, 2.92):
+        np.testing.assert_allclose(O.ms_aggregate(g["vecs"], msp), g[f"agg_msp{msp}"], rtol=2e-6, atol=1e-8)
+
+
+def test_g5_whiten(golden):
+    g = golden("g5_whiten.npz")
+    for dims in (None, 48):
+        got = np.stack([O.whiten_wrapper(g["X"][:, i], g["m"], g["P"], dims) for i in range(g["X"].shape[1])], 1)
+        np.testing.assert_allclose(got, g[f"wrapper_dims{dims}"], rtol=1e-5, atol=2e-7)
+        np.testing.assert_allclose(O.whitenapply(g["X"].astype(np.float64), g["m"], g["P"], dims),
+                                   g[f"whitenapply_f64_dims{dims}"], rtol=1e-12)
+        f32 = O.whitenapply(g["X"], g["m"].astype(np.float32), g["P"].astype(np.float32), dims)
+        assert f32.dtype == np.float32
+        np.testing.assert_allclose(f32, g[f"whitenapply_f32_dims{dims}"], rtol=1e-5, atol=2e-7)
+
+
+def test_g7_small_rankings(golden):
+    g = golden("g7_ranking.npz")
+    for name in "abc":
+        sc = O.scores(g[f"{name}_vecs"], g[f"{name}_qvecs"])
+        np.testing.assert_allclose(sc, g[f"{name}_scores"], rtol=0, atol=1e-6)
+        assert float(g[f"{name}_mingap"]) > 1e-6
+        np.testing.assert_array_equal(O.ranks(sc), g[f"{name}_ranks"])
+        # the chain order the GPU commits to gives the same ranking on tie-free data
+        ch = OC.scores_chain(g[f"{name}_vecs"], g[f"{name}_qvecs"])
+        np.testing.assert_allclose(ch.T, g[f"{name}_scores"], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(OC.rank_full(ch).T, g[f"{name}_ranks"])
+
+
+def test_g7_ties(golden):
+    g = golden("g7_ranking.npz")
+    sc = O.scores(g["tie_vecs"], g["tie_qvecs"])
+    np.testing.assert_array_equal(sc, g["tie_scores"])  # exactly representable sums
+    mine, ref = O.ranks(sc), g["tie_ranks_numpy_default"]
+    # same ids inside every run of equal scores; the build orders a run by ascending id
+    for q in range(sc.shape[1]):
+        col = sc[:, q]
+        np.testing.assert_array_equal(col[mine[:, q]], col[ref[:, q]])
+        srt = col[mine[:, q]]
+        for v in np.unique(srt):
+            run = np.nonzero(srt == v)[0]
+            assert set(mine[run, q]) == set(ref[run, q])
+            assert np.all(np.diff(mine[run, q]) > 0)
+    np.testing.assert_array_equal(OC.rank_full(np.ascontiguousarray(sc.T)).T, mine)
+
+
+def test_g7_roxford_shape(golden):
+    g = golden("g7_roxford_shape.npz")
+    vecs, qvecs, qid = O.synth_ranking_problem(4993, 70, 2048, seed=0)
+    assert float(g["vecs_checksum"]) == float(vecs.astype(np.float64).sum())
+    np.testing.assert_array_equal(qid, g["qid"])
+    sc = O.scores(vecs, qvecs)
+    np.testing.assert_allclose(sc[::97], g["scores_rows_0_4992_step_97"], rtol=0, atol=1e-6)
+    rk = O.ranks(sc)
+    # the top-100 are separated by more than fp32 summation noise -> identical ids
+    assert float(g["top100_mingap"]) > 1e-8
+    same = rk[:100] == g["top100"]
+    assert same.mean() > 0.999
+    np.testing.assert_array_equal(rk[0], qid)  # every query finds its source row first
+    avg, per = O.compute_map_and_print("roxford5k", rk, O.synth_gnd(70, 4993, seed=1))
+    for lvl in ("easy", "medium", "hard"):
+        np.testing.assert_allclose(avg["map_" + lvl], float(g["map_" + lvl]), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(per["ap_" + lvl], g["ap_" + lvl], rtol=0, atol=1e-5)
+
+
+def test_g8_compute_map(golden):
+    g = golden("g8_map.npz")
+    rk = g["ranks"].astype(np.int64)
+    gnd = json.loads(bytes(g["gnd_json"]).decode())
+    avg, per = O.compute_map_and_print("roxford5k", rk, gnd)
+    for lvl in ("easy", "medium", "hard"):
+        assert avg["map_" + lvl] == float(g["rox_map_" + lvl])
+        np.testing.assert_array_equal(per["ap_" + lvl], g["rox_ap_" + lvl])
+    gnd_m = O.protocol_gnd(gnd, "medium")
+    m, aps, pr, prs = O.compute_map(rk, gnd_m, [1, 5, 10])
+    assert m == float(g["medium_map"])
+    np.testing.assert_array_equal(aps, g["medium_aps"])
+    np.testing.assert_array_equal(pr, g["medium_pr"])
+    np.testing.assert_array_equal(prs, g["medium_prs"])
+    assert np.isnan(aps[4]) and np.isnan(prs[4]).all()
+    old = [{"ok": x["easy"] + x["hard"], "junk": x["junk"]} for x in gnd]
+    avg, per = O.compute_map_and_print("247tokyo1k", rk, old)
+    assert avg["map"] == float(g["old_map"])
+    np.testing.assert_array_equal(per["ap"], g["old_ap"])
+    m, aps, _, _ = O.compute_map(rk, [{"ok": x["ok"]} for x in old])
+    assert m == float(g["nojunkkey_map"])
+    np.testing.assert_array_equal(aps, g["nojunkkey_aps"])
+    assert bool(g["other_dataset_returns_none"]) and O.compute_map_and_print("oxford5k", rk, gnd) is None
+    assert O.compute_ap([0], 1) == float(g["ap_r0_n1"]) == 1.0
+    assert O.compute_ap([1], 1) == float(g["ap_r1_n1"]) == 0.25
+    assert O.compute_ap([0, 2], 2) == float(g["ap_r02_n2"])
+    assert O.compute_ap([], 3) == float(g["ap_empty_n3"]) == 0
+    assert O.compute_ap([0, 4, 9], 5) == float(g["ap_r0_4_9_n5"])
+
+
+def test_rank_of_matches_full_ranking():
+    rng = np.random.default_rng(5)
+    sc = rng.standard_normal((400, 3)).astype(np.float32)
+    sc[10:20, 1] = sc[5, 1]          # a run of ties
+    sc[30, 2] = np.nan
+    rk = O.ranks(sc[:, :2])
+    ids = np.array([5, 10, 19, 0, 399, 77])
+    for q in range(2):
+        inv = np.empty(400, dtype=np.int64)
+        inv[rk[:, q]] = np.arange(400)
+        np.testing.assert_array_equal(O.rank_of(sc[:, q], ids), inv[ids])
+        np.testing.assert_array_equal(OC.rank_of(sc[:, q], ids), inv[ids])
+    # C ranking: NaN goes last, -0 == +0
+    crk = OC.rank_full(np.ascontiguousarray(sc.T))
+    assert crk[2, -1] == 30
+    assert OC.desc_key(-0.0) == OC.desc_key(0.0)
+    for q in range(2):
+        np.testing.assert_array_equal(crk[q], rk[:, q])
+
+
+def test_chain_is_sequential_fma():
+    """oracle/chain.c really is the k-ascending fused chain (checked in float64 emulation)."""
+    rng = np.random.default_rng(6)
+    d, n, q = 37, 9, 3
+    vecs = rng.standard_normal((d, n)).astype(np.float32)
+    qv = rng.standard_normal((d, q)).astype(np.float32)
+    got = OC.scores_chain(vecs, qv)
+    for j in range(q):
+        for i in range(n):
+            acc = np.float32(0)
+            for k in range(d):  # fma: exact product + acc in float64 (53 bits hold 24x24+align), one rounding
+                acc = np.float32(np.float64(qv[k, j]) * np.float64(vecs[k, i]) + np.float64(acc))
+            assert got[j, i] == acc
+    a = rng.standard_normal((5, d)).astype(np.float32)
+    b = rng.standard_normal((4, d)).astype(np.float32)
+    np.testing.assert_array_equal(OC.gemm_nt_chain(a, b), OC.scores_chain(b.T.copy(), a.T.copy()))
+
+
+def test_g11_nanmean_metric():
+    meta = json.load(open(os.path.join(GOLDEN, "g11_scenario.json")))["metadata"]
+    aps = [0.5, float("nan"), 0.25, 1.0]
+    assert O.nanmean_metric(aps) == meta["roxford5k/validation/score:ap_medium_avg.4"][0]
