@@ -1,0 +1,165 @@
+/* mdx.h -- C ABI of libmdx.so: the MI355X (gfx950) implementation of the
+ * descriptor-extraction-and-ranking hot path of jenicek/mdir + cirtorch.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one statement (or a
+ * short run of statements) of the reference; the reference location is cited
+ * per function (paths relative to the upstream repository).  The reference is
+ * pure Python, so "what its FFI would bind" is a ctypes stub -- INTEGRATION.md
+ * shows it for each call site.
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers (hipMalloc / torch CUDA tensors) unless
+ *    a parameter says "host".  The caller owns every buffer; the library allocates
+ *    nothing persistent except inside an mdx_index (explicit create/destroy).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *    only enqueue work; nothing synchronises the device.  Safe under graph capture
+ *    except mdx_index_create / mdx_index_destroy (they allocate / free).
+ *  - Every function returns MDX_OK (0) or a negative mdx_status; the message of
+ *    the last failure on the calling thread is mdx_last_error().  Nothing aborts.
+ *  - One host thread per device at a time; handles are not internally locked.
+ *  - Matrices are dense fp32.  "row-major [a,b]" means element (i,j) at i*b+j.
+ */
+#ifndef MDX_H
+#define MDX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_ABI_VERSION 1
+
+typedef enum mdx_status {
+    MDX_OK = 0,
+    MDX_ERR_INVALID = -1,   /* bad argument (NULL, negative size, unsupported value) */
+    MDX_ERR_RUNTIME = -2,   /* a HIP runtime call failed (message has hipGetErrorString) */
+    MDX_ERR_NOMEM = -3,     /* device allocation failed */
+    MDX_ERR_WORKSPACE = -4  /* caller-provided workspace too small */
+} mdx_status;
+
+/* Layout of a descriptor matrix handed to the library. */
+typedef enum mdx_layout {
+    MDX_DIM_MAJOR = 0,  /* [D,N]: the reference's `vecs` (imageretrievalnet.py:291) */
+    MDX_ROW_MAJOR = 1   /* [N,D]: one descriptor per row */
+} mdx_layout;
+
+/* Global pooling kinds (cirtorch/networks/imageretrievalnet.py:32-37; rmac is out
+ * of scope). */
+typedef enum mdx_pool_kind { MDX_POOL_GEM = 0, MDX_POOL_MAC = 1, MDX_POOL_SPOC = 2 } mdx_pool_kind;
+
+int mdx_abi_version(void);
+const char *mdx_last_error(void);
+
+/* ---------------------------------------------------------------- extraction */
+
+/* Global pooling of a feature-map batch followed by L2 normalisation over channels.
+ *   feat [B,C,H,W] row-major  ->  out [B,C]
+ * Replaces `self.norm(self.pool(o))` of ImageRetrievalNet.forward
+ * (cirtorch/networks/imageretrievalnet.py:108) = LF.gem / LF.mac / LF.spoc
+ * (cirtorch/layers/functional.py:11-22) then LF.l2n (functional.py:130-131).
+ *   p, pool_eps: GeM exponent and clamp (ignored for mac/spoc).
+ *   l2n_eps    : added to the norm; pass a NEGATIVE value to skip normalisation. */
+int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float p,
+                 float pool_eps, float l2n_eps, float *out, void *stream);
+
+/* In place: x[r,:] = (x[r,:] + bias) / (||x[r,:] + bias||_2 + eps) for R rows of
+ * length D; bias may be NULL.  LF.l2n (functional.py:130-131); with bias it is the
+ * tail of the in-network whitening `self.norm(self.whiten(o))`
+ * (imageretrievalnet.py:111-112). */
+int mdx_l2n_rows(float *x, int64_t R, int64_t D, const float *bias, float eps, void *stream);
+
+/* Multi-scale aggregation of S per-scale descriptors of one image:
+ *   out[k] = v[k] / ||v||,  v[k] = (sum_s vecs[s][k]^msp / S)^(1/msp)     (no eps)
+ * Replaces CirMultiscaleAggregation.aggregate_tensor
+ * (mdir/components/data/wrapper.py:109-119) and the tail of extract_ms
+ * (cirtorch/networks/imageretrievalnet.py:319-322).
+ *   scale_vecs: HOST array of S device pointers, each D floats (1 <= S <= 8). */
+int mdx_ms_aggregate(const float *const *scale_vecs, int S, int64_t D, float msp, float *out,
+                     void *stream);
+
+/* ------------------------------------------------------------------- index  */
+
+/* A resident shard of database descriptors, re-laid out once into MFMA-fragment
+ * order (DESIGN.md "Data layout").  Also used for a whitening matrix P, whose rows
+ * then play the part of database rows. */
+typedef struct mdx_index mdx_index;
+
+/* Build a shard from n descriptors of dimension d.  `src` is a DEVICE pointer in
+ * the given layout.  `row_offset` is the global id of the shard's first row
+ * (added to ids by nothing here -- kept for the caller, see mdx_index_info).
+ * Allocates n_pad*d_pad*4 bytes of device memory.  Synchronises `stream` only
+ * if the build fails. */
+int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
+                     int64_t row_offset, void *stream);
+int mdx_index_destroy(mdx_index *index);
+/* n, d, row_offset and device bytes held. */
+int mdx_index_info(const mdx_index *index, int64_t *n, int64_t *d, int64_t *row_offset,
+                   int64_t *device_bytes);
+
+/* Bytes of scratch mdx_scores needs for nq queries of dimension d. */
+int64_t mdx_scores_workspace(int64_t nq, int64_t d);
+
+/* Similarity of nq queries against every row of the shard:
+ *   scores[q, i] = sum_k queries(q,k) * db(i,k)      scores row-major [nq, n]
+ * i.e. the TRANSPOSE of `np.dot(vecs.T, qvecs)` (mdir/components/optim/score/
+ * cirscore.py:69; cirtorch/examples/test.py:240,250), one row per query.
+ * Accumulation order is fixed: k ascending, one fused multiply-add per k from +0
+ * (oracle/chain.c states it; fp32 MFMA executes exactly that chain).
+ *   queries : device, layout `qlayout` ([d,nq] dim-major as the reference's qvecs,
+ *             or [nq,d] row-major)
+ *   center  : optional device vector [d] subtracted from every query first
+ *             (the `v - m` of CirtorchWhiten.postprocess, wrapper.py:194); NULL = none
+ *   workspace: device scratch of at least mdx_scores_workspace(nq, d) bytes */
+int mdx_scores(const mdx_index *index, const float *queries, int64_t nq, int qlayout,
+               const float *center, float *scores, void *workspace, int64_t workspace_bytes,
+               void *stream);
+
+/* ------------------------------------------------------------------ ranking */
+
+int64_t mdx_rank_workspace(int64_t n, int64_t nq);
+
+/* Full descending ranking of every query row:
+ *   ranks[q, r] = id of the r-th best database row for query q    int64 [nq, n]
+ * the transpose of `np.argsort(-scores, axis=0)` (cirscore.py:70).  Order: larger
+ * score first, equal scores by ascending id, -0 == +0, NaN last (numpy puts NaN
+ * last too; its order inside a run of equal scores is unspecified).
+ * `id_offset` is added to every id (shard offset / global ids). */
+int mdx_rank_full(const float *scores, int64_t n, int64_t nq, int64_t id_offset, int64_t *ranks,
+                  void *workspace, int64_t workspace_bytes, void *stream);
+
+/* First k entries of mdx_rank_full per query, with their scores:
+ *   top_ids [nq,k] int64, top_scores [nq,k] fp32 (either may be NULL).
+ * Same workspace size as mdx_rank_full. */
+int mdx_topk(const float *scores, int64_t n, int64_t nq, int64_t k, int64_t id_offset,
+             int64_t *top_ids, float *top_scores, void *workspace, int64_t workspace_bytes,
+             void *stream);
+
+/* Rank position of labelled database ids without materialising the ranking:
+ *   pos[t] = #{i : score[q,i] ranks strictly before id t's score under the order above}
+ * for t in [offsets[q], offsets[q+1]).  Gives compute_map (cirtorch/utils/
+ * evaluate.py:80-81) exactly what `np.arange(N)[np.in1d(ranks[:,q], ids)]` yields,
+ * unsorted.  ids int64 [total], offsets int64 [nq+1] (CSR), pos int64 [total];
+ * ids are LOCAL to this score matrix (0 <= id < n).  id_scores fp32 [total]
+ * receives scores[q, ids[t]] (it is also the kernel's scratch, so it is required). */
+int mdx_rank_of(const float *scores, int64_t n, int64_t nq, const int64_t *ids,
+                const int64_t *offsets, int64_t total, float *id_scores, int64_t *pos,
+                void *stream);
+
+/* Scores of given ids: out[t] = scores[q, ids[t]] for t in the CSR range of q. */
+int mdx_gather_scores(const float *scores, int64_t n, int64_t nq, const int64_t *ids,
+                      const int64_t *offsets, int64_t total, float *out, void *stream);
+
+/* Count, per labelled id given by its SCORE (possibly living on another shard),
+ * how many rows of THIS score matrix rank strictly before it:
+ *   cnt[t] += #{i : (score[q,i], i + id_offset) precedes (ref_scores[t], ref_ids[t])}
+ * The multi-GPU form of mdx_rank_of: every shard adds its partial count, the sum
+ * over shards is the global position.  cnt int64 [total] is ACCUMULATED into. */
+int mdx_rank_count(const float *scores, int64_t n, int64_t nq, int64_t id_offset,
+                   const float *ref_scores, const int64_t *ref_ids, const int64_t *offsets,
+                   int64_t total, int64_t *cnt, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libmdx.so (the C ABI declared in include/mdx.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an
+exception is raised.  `build()` compiles it in-tree with hipcc for gfx950
+(cross-compiles without a GPU); the built file travels with the source tree.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdx.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MDX_DIM_MAJOR, MDX_ROW_MAJOR = 0, 1
+MDX_POOL_GEM, MDX_POOL_MAC, MDX_POOL_SPOC = 0, 1, 2
+POOL_KINDS = {"gem": MDX_POOL_GEM, "mac": MDX_POOL_MAC, "spoc": MDX_POOL_SPOC}
+
+
+class MdxError(RuntimeError):
+    """A libmdx call returned a negative status."""
+
+
+_STATUS_EXC = {-1: ValueError, -2: MdxError, -3: MemoryError, -4: ValueError}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libmdx.so with hipcc --offload-arch=gfx950 (see csrc/Makefile)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "mdx.h"))
+    stale = not os.path.exists(LIB_PATH) or \
+        any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def _declare(lib):
+    i32, i64, f32, p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    pi64 = ctypes.POINTER(ctypes.c_int64)
+    sig = {
+        "mdx_abi_version": (i32, []),
+        "mdx_last_error": (ctypes.c_char_p, []),
+        "mdx_pool_l2n": (i32, [p, i32, i32, i32, i32, i32, f32, f32, f32, p, p]),
+        "mdx_l2n_rows": (i32, [p, i64, i64, p, f32, p]),
+        "mdx_ms_aggregate": (i32, [pp, i32, i64, f32, p, p]),
+        "mdx_index_create": (i32, [pp, p, i64, i64, i32, i64, p]),
+        "mdx_index_destroy": (i32, [p]),
+        "mdx_index_info": (i32, [p, pi64, pi64, pi64, pi64]),
+        "mdx_scores_workspace": (i64, [i64, i64]),
+        "mdx_scores": (i32, [p, p, i64, i32, p, p, p, i64, p]),
+        "mdx_rank_workspace": (i64, [i64, i64]),
+        "mdx_rank_full": (i32, [p, i64, i64, i64, p, p, i64, p]),
+        "mdx_topk": (i32, [p, i64, i64, i64, i64, p, p, p, i64, p]),
+        "mdx_rank_of": (i32, [p, i64, i64, p, p, i64, p, p, p]),
+        "mdx_gather_scores": (i32, [p, i64, i64, p, p, i64, p, p]),
+        "mdx_rank_count": (i32, [p, i64, i64, i64, p, p, p, i64, p, p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    return sig
+
+
+EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
+           "mdx_index_create", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
+           "mdx_scores", "mdx_rank_workspace", "mdx_rank_full", "mdx_topk", "mdx_rank_of",
+           "mdx_gather_scores", "mdx_rank_count")
+
+
+def lib():
+    """The loaded library; raises if it was never built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MdxError("libmdx.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` or `make -C mdir_amd/csrc`" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        _declare(handle)
+        if handle.mdx_abi_version() != 1:
+            raise MdxError("libmdx.so ABI version %d, expected 1" % handle.mdx_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().mdx_last_error().decode(errors="replace")
+        raise _STATUS_EXC.get(status, MdxError)("%s failed (status %d): %s" % (what or "libmdx", status, msg))

@@ -1,0 +1,338 @@
+// Database shard ("index") in MFMA-fragment order + the similarity kernel.
+//
+// Replaces `scores = np.dot(vecs.T, qvecs)` (mdir/components/optim/score/
+// cirscore.py:69) and, with the whitening matrix as the "database", the projection
+// of CirtorchWhiten.postprocess (mdir/components/data/wrapper.py:193-195).
+//
+// Data layout: rows are grouped in tiles of 16, the dimension in blocks
+// of 16; tile (rt, kb) is 1 KiB = 64 lanes x float4, stored at ((rt*KB)+kb)*1024 B.
+// Lane l = 16*g + j holds, in element t (0..3), value (row 16*rt+j, k 16*kb+4*t+g).
+// One wave-wide 16-B load therefore fetches one fully coalesced KiB and element t
+// of every lane is exactly the B (or A) operand of v_mfma_f32_16x16x4_f32 number t
+// of that k-block, with k ascending inside each MFMA and across MFMAs -- so every
+// score is the k = 0..D-1 fused-multiply-add chain stated in oracle/chain.c.
+#include <stdarg.h>
+
+#include "mdx_common.h"
+
+namespace mdx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE_ROWS = 16;   // rows per tile  (MFMA N / M)
+constexpr int TILE_K = 16;      // k per tile     (4 MFMA k-steps of 4)
+constexpr int KBC = 4;          // k-blocks per LDS chunk  (64 k)
+constexpr int WAVES = 4;        // waves per workgroup
+constexpr int MAX_QT = 8;       // query tiles (of 16) per launch
+
+// ---------------------------------------------------------------------------
+// re-tiling: any strided [rows, k] fp32 matrix -> fragment-order tiles
+//   element (row, k) is read from src[row*rs + k*ks]; rows >= n and k >= d read 0.
+//   kb_fast != 0 : consecutive waves take consecutive kb of one row tile
+//                  (row-major sources: 256 contiguous bytes per row and workgroup)
+//   kb_fast == 0 : consecutive waves take consecutive row tiles of one kb
+//                  (dimension-major sources: 256 contiguous bytes per k)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ src, int64_t rs,
+                                                     int64_t ks, int64_t n, int64_t d,
+                                                     const float *__restrict__ center,
+                                                     f32x4 *__restrict__ tiles, int64_t RT,
+                                                     int64_t KB, int kb_fast)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (tile >= RT * KB) return;
+    int64_t rt, kb;
+    if (kb_fast) { rt = tile / KB; kb = tile % KB; }
+    else         { kb = tile / RT; rt = tile % RT; }
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t row = rt * TILE_ROWS + j;
+    f32x4 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int64_t k = kb * TILE_K + 4 * t + g;
+        float x = 0.0f;
+        if (row < n && k < d) {
+            x = src[row * rs + k * ks];
+            if (center) x -= center[k];
+        }
+        v[t] = x;
+    }
+    tiles[(rt * KB + kb) * 64 + lane] = v;
+}
+
+// ---------------------------------------------------------------------------
+// similarity: one workgroup = 4 waves, each wave owns R row tiles (16*R database
+// rows) and ALL QT query tiles; the dimension is walked in chunks of 64.
+//   - database: streamed once from HBM, register double-buffered one chunk ahead
+//   - queries : chunk staged through LDS (double-buffered, one barrier per chunk),
+//               read back as ds_read_b128 = 4 A operands
+//   - fp32 MFMA 16x16x4: A = queries (M), B = database rows (N)
+// ---------------------------------------------------------------------------
+template <int QT, int R>
+__global__ __launch_bounds__(256) void scores_kernel(const f32x4 *__restrict__ db,
+                                                     const f32x4 *__restrict__ qtiles,
+                                                     float *__restrict__ out, int64_t n, int KB,
+                                                     int nq_valid)
+{
+    constexpr int CHUNK4 = QT * KBC * 64;          // float4 per LDS buffer
+    constexpr int COPIES = QT * KBC / WAVES;       // float4 per thread per chunk
+    __shared__ f32x4 lds[2][CHUNK4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t rt0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
+    const int nchunks = KB / KBC;
+
+    const f32x4 *bp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) bp[r] = db + ((rt0 + r) * KB) * 64 + lane;
+
+    // per-thread source offsets of the query-chunk copy (chunk 0), in float4
+    int qsrc[COPIES];
+#pragma unroll
+    for (int i = 0; i < COPIES; ++i) {
+        const int e = tid + i * 256;
+        const int tl = e >> 6, ln = e & 63;
+        const int qt = tl / KBC, kbc = tl % KBC;
+        qsrc[i] = (qt * KB + kbc) * 64 + ln;
+    }
+
+    f32x4 acc[R][QT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < QT; ++q) acc[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 bcur[R][KBC], bnxt[R][KBC], qreg[COPIES];
+
+    // prologue: chunk 0
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int kb = 0; kb < KBC; ++kb) bcur[r][kb] = bp[r][kb * 64];
+#pragma unroll
+    for (int i = 0; i < COPIES; ++i) qreg[i] = qtiles[qsrc[i]];
+#pragma unroll
+    for (int i = 0; i < COPIES; ++i) lds[0][tid + i * 256] = qreg[i];
+
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1 < nchunks);
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int kb = 0; kb < KBC; ++kb) bnxt[r][kb] = bp[r][((c + 1) * KBC + kb) * 64];
+#pragma unroll
+            for (int i = 0; i < COPIES; ++i) qreg[i] = qtiles[qsrc[i] + (c + 1) * KBC * 64];
+        }
+        __syncthreads();  // lds[c&1] written (prologue or previous iteration) and visible
+        const f32x4 *lq = lds[c & 1];
+#pragma unroll
+        for (int kb = 0; kb < KBC; ++kb) {
+            f32x4 a[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) a[q] = lq[(q * KBC + kb) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int q = 0; q < QT; ++q)
+                        acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][t], bcur[r][kb][t],
+                                                                         acc[r][q], 0, 0, 0);
+        }
+        if (more) {
+            // lds[(c+1)&1] was last read in iteration c-1; every wave is past this
+            // iteration's barrier, hence done with it.
+#pragma unroll
+            for (int i = 0; i < COPIES; ++i) lds[(c + 1) & 1][tid + i * 256] = qreg[i];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int kb = 0; kb < KBC; ++kb) bcur[r][kb] = bnxt[r][kb];
+        }
+    }
+
+    // C/D map of 16x16x4: reg i of lane l is (M = 4*(l>>4)+i, N = l&15)
+    const int qrow = 4 * (lane >> 4);
+    const int64_t col = lane & 15;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (rt0 + r) * TILE_ROWS + col;
+        if (row >= n) continue;
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qi = q * 16 + qrow + i;
+                if (qi < nq_valid) out[(int64_t)qi * n + row] = acc[r][q][i];
+            }
+    }
+}
+
+template <int QT, int R>
+static void launch_scores(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
+                          int KB, int nq_valid, hipStream_t s)
+{
+    const int64_t blocks = ceil_div(RT, (int64_t)WAVES * R);
+    hipLaunchKernelGGL((scores_kernel<QT, R>), dim3((unsigned)blocks), dim3(256), 0, s, db, qt, out,
+                       n, KB, nq_valid);
+}
+
+template <int R>
+static void dispatch_qt(int qt, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
+                        int KB, int nq_valid, hipStream_t s)
+{
+    switch (qt) {
+        case 1: launch_scores<1, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 2: launch_scores<2, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 3: launch_scores<3, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 4: launch_scores<4, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 5: launch_scores<5, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 6: launch_scores<6, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 7: launch_scores<7, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+        default: launch_scores<8, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+    }
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+struct mdx_index {
+    f32x4 *tiles;
+    int64_t n, d, d_pad, RT, RT_pad, KB, row_offset;
+    int64_t bytes;
+};
+
+extern "C" {
+
+int mdx_abi_version(void) { return MDX_ABI_VERSION; }
+const char *mdx_last_error(void) { return mdx::g_err; }
+
+static int retile(const float *src, int64_t n, int64_t d, int layout, const float *center,
+                  f32x4 *tiles, int64_t RT, int64_t KB, hipStream_t s)
+{
+    const int64_t rs = layout == MDX_DIM_MAJOR ? 1 : d;
+    const int64_t ks = layout == MDX_DIM_MAJOR ? n : 1;
+    const int64_t blocks = ceil_div(RT * KB, (int64_t)WAVES);
+    MDX_CHECK_ARG(blocks < (1ll << 31), "matrix too large to re-tile in one launch");
+    hipLaunchKernelGGL(retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, rs, ks, n, d,
+                       center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
+                     int64_t row_offset, void *stream)
+{
+    MDX_CHECK_ARG(out && src, "mdx_index_create: NULL pointer");
+    MDX_CHECK_ARG(n > 0 && d > 0, "mdx_index_create: n=%lld d=%lld must be positive",
+                  (long long)n, (long long)d);
+    MDX_CHECK_ARG(layout == MDX_DIM_MAJOR || layout == MDX_ROW_MAJOR, "mdx_index_create: layout %d",
+                  layout);
+    mdx_index *ix = new mdx_index();
+    ix->n = n;
+    ix->d = d;
+    ix->d_pad = round_up(d, TILE_K * KBC);
+    ix->KB = ix->d_pad / TILE_K;
+    ix->RT = ceil_div(n, TILE_ROWS);
+    ix->RT_pad = round_up(ix->RT, WAVES * 2);  // every wave of every workgroup has tiles to read
+    ix->row_offset = row_offset;
+    ix->bytes = ix->RT_pad * ix->KB * 1024;
+    hipError_t e = hipMalloc((void **)&ix->tiles, (size_t)ix->bytes);
+    if (e != hipSuccess) {
+        set_error("mdx_index_create: hipMalloc(%lld bytes) failed: %s", (long long)ix->bytes,
+                  hipGetErrorString(e));
+        delete ix;
+        return MDX_ERR_NOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int rc = retile(src, n, d, layout, nullptr, ix->tiles, ix->RT_pad, ix->KB, s);
+    if (rc != MDX_OK) {
+        hipStreamSynchronize(s);
+        hipFree(ix->tiles);
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return MDX_OK;
+}
+
+int mdx_index_destroy(mdx_index *ix)
+{
+    if (!ix) return MDX_OK;
+    hipError_t e = hipFree(ix->tiles);
+    delete ix;
+    if (e != hipSuccess) {
+        set_error("mdx_index_destroy: hipFree failed: %s", hipGetErrorString(e));
+        return MDX_ERR_RUNTIME;
+    }
+    return MDX_OK;
+}
+
+int mdx_index_info(const mdx_index *ix, int64_t *n, int64_t *d, int64_t *row_offset,
+                   int64_t *device_bytes)
+{
+    MDX_CHECK_ARG(ix, "mdx_index_info: NULL index");
+    if (n) *n = ix->n;
+    if (d) *d = ix->d;
+    if (row_offset) *row_offset = ix->row_offset;
+    if (device_bytes) *device_bytes = ix->bytes;
+    return MDX_OK;
+}
+
+int64_t mdx_scores_workspace(int64_t nq, int64_t d)
+{
+    if (nq <= 0 || d <= 0) return 0;
+    return round_up(nq, TILE_ROWS) * round_up(d, TILE_K * KBC) * 4;
+}
+
+int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayout,
+               const float *center, float *scores, void *workspace, int64_t workspace_bytes,
+               void *stream)
+{
+    MDX_CHECK_ARG(ix && queries && scores, "mdx_scores: NULL pointer");
+    MDX_CHECK_ARG(nq > 0, "mdx_scores: nq=%lld must be positive", (long long)nq);
+    MDX_CHECK_ARG(qlayout == MDX_DIM_MAJOR || qlayout == MDX_ROW_MAJOR, "mdx_scores: qlayout %d",
+                  qlayout);
+    const int64_t need = mdx_scores_workspace(nq, ix->d);
+    if (!workspace || workspace_bytes < need) {
+        set_error("mdx_scores: workspace %lld B < required %lld B", (long long)workspace_bytes,
+                  (long long)need);
+        return MDX_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    f32x4 *qtiles = (f32x4 *)workspace;
+    const int64_t QT_total = ceil_div(nq, TILE_ROWS);
+    int rc = retile(queries, nq, ix->d, qlayout, center, qtiles, QT_total, ix->KB, s);
+    if (rc != MDX_OK) return rc;
+
+    // Small shards: one row tile per wave so that more CUs get work.
+    const bool small = ix->RT < 256 * WAVES * 2 * 2;
+    for (int64_t qt0 = 0; qt0 < QT_total; qt0 += MAX_QT) {
+        const int qt = (int)((QT_total - qt0) < MAX_QT ? (QT_total - qt0) : MAX_QT);
+        const int64_t q0 = qt0 * TILE_ROWS;
+        const int nq_valid = (int)((nq - q0) < qt * TILE_ROWS ? (nq - q0) : qt * TILE_ROWS);
+        const f32x4 *qp = qtiles + qt0 * ix->KB * 64;
+        float *op = scores + q0 * ix->n;
+        if (small) dispatch_qt<1>(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        else       dispatch_qt<2>(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        MDX_LAUNCH_CHECK();
+    }
+    return MDX_OK;
+}
+
+}  // extern "C"

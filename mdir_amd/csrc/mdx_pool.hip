@@ -1,0 +1,194 @@
+// Descriptor tail: global pooling (GeM / MAC / SPoC), L2 normalisation, multi-scale
+// aggregation.  All HBM- (really launch-) bound streaming reductions: one wave per
+// (image, channel) plane with 16-B loads, wavefront shuffles for the reduction.
+//
+// Replaces LF.gem / LF.mac / LF.spoc / LF.l2n (mdir/external/cirtorch/layers/
+// functional.py:11-22,130-131) as used by ImageRetrievalNet.forward
+// (cirtorch/networks/imageretrievalnet.py:108-112) and
+// CirMultiscaleAggregation.aggregate_tensor (mdir/components/data/wrapper.py:109-119).
+#include <math.h>
+
+#include "mdx_common.h"
+
+namespace mdx {
+
+// x^p for x >= eps > 0.  Exact products for the exponents that occur untrained
+// (p = 1, 2, 3, layers/pooling.py:38); exp2(p*log2 x) through the hardware
+// transcendental units otherwise (relative error ~1e-6, tests/test_gpu_pool.py).
+template <int MODE>
+__device__ __forceinline__ float pow_pos(float x, float p)
+{
+    if (MODE == 1) return x;
+    if (MODE == 2) return x * x;
+    if (MODE == 3) return x * x * x;
+    return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x));
+}
+
+template <int KIND, int MODE>
+__device__ __forceinline__ float pool_elem(float x, float p, float eps)
+{
+    if (KIND == MDX_POOL_GEM) return pow_pos<MODE>(fmaxf(x, eps), p);
+    return x;
+}
+
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ feat, int64_t planes,
+                                                   int HW, float p, float inv_p, float eps,
+                                                   float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const float *src = feat + plane * HW;
+    float acc = KIND == MDX_POOL_MAC ? -INFINITY : 0.0f;
+    if ((HW & 3) == 0 && ((uintptr_t)feat & 15) == 0) {
+        const float4 *s4 = (const float4 *)src;
+        const int n4 = HW >> 2;
+        for (int i = lane; i < n4; i += 64) {
+            const float4 v = s4[i];
+            const float a = pool_elem<KIND, MODE>(v.x, p, eps), b = pool_elem<KIND, MODE>(v.y, p, eps);
+            const float c = pool_elem<KIND, MODE>(v.z, p, eps), d = pool_elem<KIND, MODE>(v.w, p, eps);
+            if (KIND == MDX_POOL_MAC) acc = fmaxf(acc, fmaxf(fmaxf(a, b), fmaxf(c, d)));
+            else acc += (a + b) + (c + d);
+        }
+    } else {
+        for (int i = lane; i < HW; i += 64) {
+            const float a = pool_elem<KIND, MODE>(src[i], p, eps);
+            if (KIND == MDX_POOL_MAC) acc = fmaxf(acc, a);
+            else acc += a;
+        }
+    }
+    acc = KIND == MDX_POOL_MAC ? wave_max(acc) : wave_sum(acc);
+    if (lane == 0) {
+        float r = acc;
+        if (KIND != MDX_POOL_MAC) r = acc / (float)HW;
+        if (KIND == MDX_POOL_GEM && MODE != 1) r = powf(r, inv_p);
+        out[plane] = r;
+    }
+}
+
+// one workgroup per row: x = (x + bias) / (||x + bias|| + eps)
+__global__ __launch_bounds__(256) void l2n_rows_kernel(float *__restrict__ x, int64_t D,
+                                                       const float *__restrict__ bias, float eps)
+{
+    __shared__ float part[4];
+    float *row = x + (int64_t)blockIdx.x * D;
+    const int tid = threadIdx.x;
+    float ss = 0.0f;
+    for (int64_t k = tid; k < D; k += 256) {
+        float v = row[k];
+        if (bias) v += bias[k];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    const float den = sqrtf((part[0] + part[1]) + (part[2] + part[3])) + eps;
+    for (int64_t k = tid; k < D; k += 256) {
+        float v = row[k];
+        if (bias) v += bias[k];
+        row[k] = v / den;
+    }
+}
+
+struct ScalePtrs { const float *p[8]; };
+
+// single workgroup: power mean over scales, then plain L2 normalisation (no eps)
+__global__ __launch_bounds__(1024) void ms_aggregate_kernel(ScalePtrs sp, int S, int64_t D, float msp,
+                                                            float inv_msp, float *__restrict__ out)
+{
+    __shared__ float part[16];
+    const int tid = threadIdx.x;
+    float ss = 0.0f;
+    for (int64_t k = tid; k < D; k += 1024) {
+        float a = 0.0f;
+        for (int s = 0; s < S; ++s) a += (msp == 1.0f) ? sp.p[s][k] : powf(sp.p[s][k], msp);
+        a = a / (float)S;
+        if (msp != 1.0f) a = powf(a, inv_msp);
+        out[k] = a;
+        ss += a * a;
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += part[w];
+    const float nrm = sqrtf(tot);
+    for (int64_t k = tid; k < D; k += 1024) out[k] = out[k] / nrm;
+}
+
+template <int KIND>
+static void launch_pool(int mode, const float *feat, int64_t planes, int HW, float p, float eps,
+                        float *out, hipStream_t s)
+{
+    const dim3 grid((unsigned)ceil_div(planes, 4)), blk(256);
+    const float inv_p = 1.0f / p;
+    switch (mode) {
+        case 1: hipLaunchKernelGGL((pool_kernel<KIND, 1>), grid, blk, 0, s, feat, planes, HW, p, inv_p, eps, out); break;
+        case 2: hipLaunchKernelGGL((pool_kernel<KIND, 2>), grid, blk, 0, s, feat, planes, HW, p, inv_p, eps, out); break;
+        case 3: hipLaunchKernelGGL((pool_kernel<KIND, 3>), grid, blk, 0, s, feat, planes, HW, p, inv_p, eps, out); break;
+        default: hipLaunchKernelGGL((pool_kernel<KIND, 0>), grid, blk, 0, s, feat, planes, HW, p, inv_p, eps, out); break;
+    }
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+extern "C" {
+
+int mdx_l2n_rows(float *x, int64_t R, int64_t D, const float *bias, float eps, void *stream)
+{
+    MDX_CHECK_ARG(x, "mdx_l2n_rows: NULL pointer");
+    MDX_CHECK_ARG(R > 0 && D > 0 && R < (1ll << 31), "mdx_l2n_rows: R=%lld D=%lld", (long long)R,
+                  (long long)D);
+    hipLaunchKernelGGL(l2n_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, D,
+                       bias, eps);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float p, float pool_eps,
+                 float l2n_eps, float *out, void *stream)
+{
+    MDX_CHECK_ARG(feat && out, "mdx_pool_l2n: NULL pointer");
+    MDX_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0, "mdx_pool_l2n: bad shape [%d,%d,%d,%d]", B, C, H, W);
+    MDX_CHECK_ARG((int64_t)H * W < (1ll << 31), "mdx_pool_l2n: H*W too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t planes = (int64_t)B * C;
+    const int HW = H * W;
+    switch (kind) {
+        case MDX_POOL_GEM: {
+            MDX_CHECK_ARG(p > 0.0f && pool_eps > 0.0f, "mdx_pool_l2n: gem needs p > 0 and eps > 0");
+            const int mode = p == 1.0f ? 1 : p == 2.0f ? 2 : p == 3.0f ? 3 : 0;
+            launch_pool<MDX_POOL_GEM>(mode, feat, planes, HW, p, pool_eps, out, s);
+            break;
+        }
+        case MDX_POOL_MAC: launch_pool<MDX_POOL_MAC>(1, feat, planes, HW, 1.0f, 0.0f, out, s); break;
+        case MDX_POOL_SPOC: launch_pool<MDX_POOL_SPOC>(1, feat, planes, HW, 1.0f, 0.0f, out, s); break;
+        default: MDX_CHECK_ARG(false, "mdx_pool_l2n: unknown pooling kind %d", kind);
+    }
+    MDX_LAUNCH_CHECK();
+    if (l2n_eps >= 0.0f) return mdx_l2n_rows(out, B, C, nullptr, l2n_eps, stream);
+    return MDX_OK;
+}
+
+int mdx_ms_aggregate(const float *const *scale_vecs, int S, int64_t D, float msp, float *out,
+                     void *stream)
+{
+    MDX_CHECK_ARG(scale_vecs && out, "mdx_ms_aggregate: NULL pointer");
+    MDX_CHECK_ARG(S >= 1 && S <= 8, "mdx_ms_aggregate: S=%d not in 1..8", S);
+    MDX_CHECK_ARG(D > 0, "mdx_ms_aggregate: D=%lld", (long long)D);
+    ScalePtrs sp;
+    for (int s = 0; s < 8; ++s) {
+        sp.p[s] = s < S ? scale_vecs[s] : nullptr;
+        MDX_CHECK_ARG(s >= S || sp.p[s], "mdx_ms_aggregate: scale %d is NULL", s);
+    }
+    hipLaunchKernelGGL(ms_aggregate_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sp, S, D, msp,
+                       1.0f / msp, out);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// Ranking: segmented (one segment per query) stable LSD radix sort of
+// (desc_key(score), id), plus rank-of-labelled-ids counting.
+//
+// Replaces `ranks = np.argsort(-scores, axis=0)` (mdir/components/optim/score/
+// cirscore.py:70) and the `np.in1d` position lookups of compute_map
+// (mdir/external/cirtorch/utils/evaluate.py:80-81).
+//
+// All of it is HBM-bound integer work: 4 passes of 8 bits; per pass a per-tile
+// histogram, a per-query scan, and a stable scatter.  Stability (equal keys keep
+// ascending id) is what fixes the tie order documented in include/mdx.h.
+#include "mdx_common.h"
+
+namespace mdx {
+
+constexpr int SORT_ITEMS = 16;                 // elements per lane
+constexpr int SORT_TILE = 256 * SORT_ITEMS;    // elements per workgroup
+constexpr int SUB_TILE = 64 * SORT_ITEMS;      // elements per wave
+constexpr int RADIX = 256;
+
+__device__ __forceinline__ uint32_t load_key(const float *scores, const uint32_t *keys, int64_t i,
+                                             bool first)
+{
+    return first ? desc_key(scores[i]) : keys[i];
+}
+
+// per-tile digit histogram -> block_hist[q][b][digit]
+template <bool FIRST>
+__global__ __launch_bounds__(256) void sort_hist_kernel(const float *__restrict__ scores,
+                                                        const uint32_t *__restrict__ keys,
+                                                        int64_t n, int nblk, int shift,
+                                                        uint32_t *__restrict__ block_hist)
+{
+    __shared__ uint32_t h[4][RADIX];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t q = blockIdx.y, b = blockIdx.x;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) h[w][tid] = 0;
+    __syncthreads();
+    const int64_t base = q * n;
+    const int64_t t0 = b * SORT_TILE;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t i = t0 + r * 256 + tid;
+        if (i < n) {
+            const uint32_t k = load_key(scores, keys, base + i, FIRST);
+            atomicAdd(&h[wave][(k >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    block_hist[(q * nblk + b) * RADIX + tid] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+}
+
+// per query: exclusive prefix over tiles for each digit (in place) + digit bases
+__global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ block_hist, int nblk,
+                                                        uint32_t *__restrict__ digit_base)
+{
+    __shared__ uint32_t s[RADIX];
+    const int d = threadIdx.x;
+    uint32_t *p = block_hist + (int64_t)blockIdx.x * nblk * RADIX + d;
+    uint32_t run = 0;
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = p[(int64_t)(b + u) * RADIX];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            p[(int64_t)(b + u) * RADIX] = run;
+            run += c[u];
+        }
+    }
+    for (; b < nblk; ++b) {
+        const uint32_t c = p[(int64_t)b * RADIX];
+        p[(int64_t)b * RADIX] = run;
+        run += c;
+    }
+    s[d] = run;
+    __syncthreads();
+    for (int off = 1; off < RADIX; off <<= 1) {
+        const uint32_t v = d >= off ? s[d - off] : 0u;
+        __syncthreads();
+        s[d] += v;
+        __syncthreads();
+    }
+    digit_base[(int64_t)blockIdx.x * RADIX + d] = s[d] - run;
+}
+
+// stable scatter of one tile.  Element order inside a query = (tile, wave, round,
+// lane); each wave ranks its 64 elements of a round with ballots (lanes with the
+// same digit, lower lane first) and keeps a running per-digit count in LDS.
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(
+    const float *__restrict__ scores, const uint32_t *__restrict__ keys_in,
+    const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, int64_t *__restrict__ ranks, float *__restrict__ top_scores,
+    int64_t n, int nblk, int shift, const uint32_t *__restrict__ block_hist,
+    const uint32_t *__restrict__ digit_base, int64_t id_offset, int64_t klimit)
+{
+    __shared__ uint32_t wcnt[4][RADIX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.y, b = blockIdx.x;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+    __syncthreads();
+
+    const int64_t base = q * n;
+    const int64_t sub0 = b * SORT_TILE + wave * SUB_TILE;
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], pos[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t i = sub0 + r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? load_key(scores, keys_in, base + i, FIRST) : 0xFFFFFFFFu;
+        val[r] = FIRST ? (uint32_t)i : (valid ? vals_in[base + i] : 0u);
+    }
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const bool valid = (sub0 + r * 64 + lane) < n;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const uint64_t m = __ballot(valid && one);
+            peers &= one ? m : ~m;
+        }
+        const uint32_t rank = __popcll(peers & lt_mask);
+        const uint32_t cnt = __popcll(peers);
+        const uint32_t old = wcnt[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wcnt[wave][d] = old + cnt;
+        __builtin_amdgcn_wave_barrier();
+        pos[r] = old + rank;
+    }
+    __syncthreads();
+    {   // thread = digit: global base + prefix over the 4 waves, written back over wcnt
+        uint32_t run = digit_base[q * RADIX + tid] + block_hist[(q * nblk + b) * RADIX + tid];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = wcnt[w][tid];
+            wcnt[w][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const bool valid = (sub0 + r * 64 + lane) < n;
+        if (!valid) continue;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        const int64_t dst = (int64_t)wcnt[wave][d] + pos[r];
+        if (LAST) {
+            if (dst < klimit) {
+                if (ranks) ranks[q * klimit + dst] = (int64_t)val[r] + id_offset;
+                if (top_scores) top_scores[q * klimit + dst] = scores[base + val[r]];
+            }
+        } else {
+            keys_out[base + dst] = key[r];
+            vals_out[base + dst] = val[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// counting ranks of labelled items
+// ---------------------------------------------------------------------------
+constexpr int CNT_TILE = 4096;
+constexpr int CNT_REFS = 256;
+
+__global__ __launch_bounds__(256) void rank_count_kernel(
+    const float *__restrict__ scores, int64_t n, int64_t id_offset,
+    const float *__restrict__ ref_scores, const int64_t *__restrict__ ref_ids,
+    const int64_t *__restrict__ offsets, unsigned long long *__restrict__ cnt)
+{
+    __shared__ uint32_t skey[CNT_TILE];
+    __shared__ uint32_t rkey[CNT_REFS];
+    __shared__ int64_t rid[CNT_REFS];
+    __shared__ uint32_t rcnt[CNT_REFS];
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.y;
+    const int64_t t0 = (int64_t)blockIdx.x * CNT_TILE;
+    const int64_t lo = offsets[q], hi = offsets[q + 1];
+    if (lo >= hi) return;
+    const int tile_n = (int)((n - t0) < CNT_TILE ? (n - t0) : CNT_TILE);
+    for (int e = tid; e < CNT_TILE; e += 256)
+        skey[e] = e < tile_n ? desc_key(scores[q * n + t0 + e]) : 0xFFFFFFFFu;
+    for (int64_t r0 = lo; r0 < hi; r0 += CNT_REFS) {
+        const int nref = (int)((hi - r0) < CNT_REFS ? (hi - r0) : CNT_REFS);
+        __syncthreads();
+        if (tid < nref) {
+            rkey[tid] = desc_key(ref_scores[r0 + tid]);
+            rid[tid] = ref_ids[r0 + tid];
+        }
+        rcnt[tid] = 0;
+        __syncthreads();
+        // slots = power of two >= nref; the 256 threads split into 256/slots element slices
+        int slots = 1;
+        while (slots < nref) slots <<= 1;
+        const int slices = 256 / slots;
+        const int slot = tid & (slots - 1), slice = tid / slots;
+        if (slot < nref) {
+            const uint32_t rk = rkey[slot];
+            const int64_t ri = rid[slot];
+            const int per = (tile_n + slices - 1) / slices;
+            const int e0 = slice * per, e1 = (e0 + per) < tile_n ? (e0 + per) : tile_n;
+            uint32_t c = 0;
+            for (int e = e0; e < e1; ++e) {
+                const uint32_t k = skey[e];
+                c += (k < rk) || (k == rk && (t0 + e + id_offset) < ri);
+            }
+            if (c) atomicAdd(&rcnt[slot], c);
+        }
+        __syncthreads();
+        if (tid < nref && rcnt[tid]) atomicAdd(&cnt[r0 + tid], (unsigned long long)rcnt[tid]);
+    }
+}
+
+__global__ void gather_scores_kernel(const float *__restrict__ scores, int64_t n, int64_t nq,
+                                     const int64_t *__restrict__ ids,
+                                     const int64_t *__restrict__ offsets, int64_t total,
+                                     float *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    // binary search the query this entry belongs to
+    int64_t a = 0, b = nq;
+    while (b - a > 1) {
+        const int64_t m = (a + b) >> 1;
+        if (offsets[m] <= t) a = m; else b = m;
+    }
+    const int64_t id = ids[t];
+    out[t] = (id >= 0 && id < n) ? scores[a * n + id] : __uint_as_float(0x7FC00000u);
+}
+
+struct RankWs {
+    uint32_t *keys[2];
+    uint32_t *vals[2];
+    uint32_t *block_hist;
+    uint32_t *digit_base;
+    int nblk;
+};
+
+static int64_t carve(RankWs *ws, char *base, int64_t n, int64_t nq)
+{
+    const int64_t nblk = ceil_div(n, SORT_TILE);
+    const int64_t elems = round_up(n * nq * 4, 256);
+    int64_t off = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (ws) ws->keys[i] = (uint32_t *)(base + off);
+        off += elems;
+        if (ws) ws->vals[i] = (uint32_t *)(base + off);
+        off += elems;
+    }
+    if (ws) ws->block_hist = (uint32_t *)(base + off);
+    off += round_up(nq * nblk * RADIX * 4, 256);
+    if (ws) ws->digit_base = (uint32_t *)(base + off);
+    off += round_up(nq * RADIX * 4, 256);
+    if (ws) ws->nblk = (int)nblk;
+    return off;
+}
+
+static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offset, int64_t *ranks,
+                     float *top_scores, int64_t klimit, void *workspace, int64_t workspace_bytes,
+                     hipStream_t s, const char *who)
+{
+    MDX_CHECK_ARG(scores, "%s: NULL scores", who);
+    MDX_CHECK_ARG(n > 0 && nq > 0, "%s: n=%lld nq=%lld must be positive", who, (long long)n,
+                  (long long)nq);
+    MDX_CHECK_ARG(n < (1ll << 32) && nq < 65536, "%s: n or nq too large", who);
+    const int64_t need = carve(nullptr, nullptr, n, nq);
+    if (!workspace || workspace_bytes < need) {
+        set_error("%s: workspace %lld B < required %lld B", who, (long long)workspace_bytes,
+                  (long long)need);
+        return MDX_ERR_WORKSPACE;
+    }
+    RankWs ws;
+    carve(&ws, (char *)workspace, n, nq);
+    const dim3 grid((unsigned)ws.nblk, (unsigned)nq), blk(256);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 8 * pass;
+        const uint32_t *kin = pass == 0 ? nullptr : ws.keys[(pass - 1) & 1];
+        const uint32_t *vin = pass == 0 ? nullptr : ws.vals[(pass - 1) & 1];
+        uint32_t *kout = ws.keys[pass & 1], *vout = ws.vals[pass & 1];
+        if (pass == 0)
+            hipLaunchKernelGGL(sort_hist_kernel<true>, grid, blk, 0, s, scores, kin, n, ws.nblk, shift,
+                               ws.block_hist);
+        else
+            hipLaunchKernelGGL(sort_hist_kernel<false>, grid, blk, 0, s, scores, kin, n, ws.nblk,
+                               shift, ws.block_hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)nq), blk, 0, s, ws.block_hist, ws.nblk,
+                           ws.digit_base);
+        if (pass == 0)
+            hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, blk, 0, s, scores, kin, vin,
+                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
+                               ws.digit_base, id_offset, klimit);
+        else if (pass < 3)
+            hipLaunchKernelGGL((sort_scatter_kernel<false, false>), grid, blk, 0, s, scores, kin, vin,
+                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
+                               ws.digit_base, id_offset, klimit);
+        else
+            hipLaunchKernelGGL((sort_scatter_kernel<false, true>), grid, blk, 0, s, scores, kin, vin,
+                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
+                               ws.digit_base, id_offset, klimit);
+        MDX_LAUNCH_CHECK();
+    }
+    return MDX_OK;
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+extern "C" {
+
+int64_t mdx_rank_workspace(int64_t n, int64_t nq)
+{
+    if (n <= 0 || nq <= 0) return 0;
+    return carve(nullptr, nullptr, n, nq);
+}
+
+int mdx_rank_full(const float *scores, int64_t n, int64_t nq, int64_t id_offset, int64_t *ranks,
+                  void *workspace, int64_t workspace_bytes, void *stream)
+{
+    MDX_CHECK_ARG(ranks, "mdx_rank_full: NULL ranks");
+    return rank_impl(scores, n, nq, id_offset, ranks, nullptr, n, workspace, workspace_bytes,
+                     (hipStream_t)stream, "mdx_rank_full");
+}
+
+int mdx_topk(const float *scores, int64_t n, int64_t nq, int64_t k, int64_t id_offset,
+             int64_t *top_ids, float *top_scores, void *workspace, int64_t workspace_bytes,
+             void *stream)
+{
+    MDX_CHECK_ARG(k > 0 && k <= n, "mdx_topk: k=%lld out of range (n=%lld)", (long long)k,
+                  (long long)n);
+    MDX_CHECK_ARG(top_ids || top_scores, "mdx_topk: both outputs NULL");
+    return rank_impl(scores, n, nq, id_offset, top_ids, top_scores, k, workspace, workspace_bytes,
+                     (hipStream_t)stream, "mdx_topk");
+}
+
+int mdx_gather_scores(const float *scores, int64_t n, int64_t nq, const int64_t *ids,
+                      const int64_t *offsets, int64_t total, float *out, void *stream)
+{
+    MDX_CHECK_ARG(scores && ids && offsets && out, "mdx_gather_scores: NULL pointer");
+    MDX_CHECK_ARG(n > 0 && nq > 0 && total >= 0, "mdx_gather_scores: bad sizes");
+    if (total == 0) return MDX_OK;
+    hipLaunchKernelGGL(gather_scores_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, scores, n, nq, ids, offsets, total, out);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+int mdx_rank_count(const float *scores, int64_t n, int64_t nq, int64_t id_offset,
+                   const float *ref_scores, const int64_t *ref_ids, const int64_t *offsets,
+                   int64_t total, int64_t *cnt, void *stream)
+{
+    MDX_CHECK_ARG(scores && ref_scores && ref_ids && offsets && cnt, "mdx_rank_count: NULL pointer");
+    MDX_CHECK_ARG(n > 0 && nq > 0 && total >= 0 && nq < 65536, "mdx_rank_count: bad sizes");
+    if (total == 0) return MDX_OK;
+    const dim3 grid((unsigned)ceil_div(n, CNT_TILE), (unsigned)nq);
+    hipLaunchKernelGGL(rank_count_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, n,
+                       id_offset, ref_scores, ref_ids, offsets, (unsigned long long *)cnt);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+int mdx_rank_of(const float *scores, int64_t n, int64_t nq, const int64_t *ids,
+                const int64_t *offsets, int64_t total, float *id_scores, int64_t *pos, void *stream)
+{
+    MDX_CHECK_ARG(scores && ids && offsets && pos && id_scores, "mdx_rank_of: NULL pointer");
+    if (total == 0) return MDX_OK;
+    int rc = mdx_gather_scores(scores, n, nq, ids, offsets, total, id_scores, stream);
+    if (rc != MDX_OK) return rc;
+    MDX_HIP(hipMemsetAsync(pos, 0, (size_t)total * sizeof(int64_t), (hipStream_t)stream));
+    return mdx_rank_count(scores, n, nq, 0, id_scores, ids, offsets, total, pos, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+"""Operators of the hot path as calls into libmdx.so on torch CUDA (ROCm) tensors.
+
+torch is plumbing only: device memory, the current HIP stream, and (elsewhere)
+torch.distributed.  Every function here hands raw device pointers to the C ABI
+(include/mdx.h); nothing computes with torch ops and nothing falls back to the CPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MDX_DIM_MAJOR, MDX_ROW_MAJOR, POOL_KINDS, check
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA/ROCm tensor: the MI355X path has no CPU fallback" % what)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (what, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % what)
+    return _vp(t.data_ptr())
+
+
+def _layout(t, layout, what):
+    """(n, d) of a 2-D descriptor matrix under the given layout name."""
+    if t.dim() != 2:
+        raise ValueError("%s must be 2-D" % what)
+    if layout in ("DN", "dim_major", MDX_DIM_MAJOR):
+        return t.shape[1], t.shape[0], MDX_DIM_MAJOR
+    if layout in ("ND", "row_major", MDX_ROW_MAJOR):
+        return t.shape[0], t.shape[1], MDX_ROW_MAJOR
+    raise ValueError("unknown layout %r" % (layout,))
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------ extraction
+
+def pool_l2n(feat, kind="gem", p=3.0, pool_eps=1e-6, l2n_eps=1e-6):
+    """[B,C,H,W] feature maps -> [B,C] pooled (+ L2-normalised unless l2n_eps is None).
+
+    ``self.norm(self.pool(o))`` of cirtorch/networks/imageretrievalnet.py:108."""
+    if feat.dim() != 4:
+        raise ValueError("feature map must be [B,C,H,W]")
+    fp = _dev(feat, torch.float32, "feature map")
+    B, C, H, W = feat.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=feat.device)
+    check(_lib.lib().mdx_pool_l2n(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps),
+                                  -1.0 if l2n_eps is None else float(l2n_eps), _vp(out.data_ptr()),
+                                  _stream()), "mdx_pool_l2n")
+    return out
+
+
+def l2n_rows_(x, bias=None, eps=1e-6):
+    """In place ``(x + bias) / (||x + bias|| + eps)`` per row of a [R,D] matrix."""
+    xp = _dev(x, torch.float32, "x")
+    if x.dim() != 2:
+        raise ValueError("x must be [R,D]")
+    bp = _dev(bias, torch.float32, "bias") if bias is not None else None
+    if bias is not None and bias.numel() != x.shape[1]:
+        raise ValueError("bias length %d != D %d" % (bias.numel(), x.shape[1]))
+    check(_lib.lib().mdx_l2n_rows(xp, x.shape[0], x.shape[1], bp, float(eps), _stream()), "mdx_l2n_rows")
+    return x
+
+
+def ms_aggregate(vecs, msp=1.0):
+    """Per-scale descriptors (list of [D] or [D,1] tensors) -> aggregated [D].
+
+    mdir/components/data/wrapper.py:109-119."""
+    if not 1 <= len(vecs) <= 8:
+        raise ValueError("1..8 scales supported, got %d" % len(vecs))
+    flat = [v.reshape(-1) for v in vecs]
+    D = flat[0].numel()
+    ptrs = (ctypes.c_void_p * len(flat))()
+    for i, v in enumerate(flat):
+        if v.numel() != D:
+            raise ValueError("scale %d has %d elements, expected %d" % (i, v.numel(), D))
+        ptrs[i] = _dev(v, torch.float32, "scale descriptor").value
+    out = torch.empty(D, dtype=torch.float32, device=flat[0].device)
+    check(_lib.lib().mdx_ms_aggregate(ptrs, len(flat), D, float(msp), _vp(out.data_ptr()), _stream()),
+          "mdx_ms_aggregate")
+    return out
+
+
+# ----------------------------------------------------------------------- index
+
+class DescriptorIndex:
+    """A resident, re-tiled shard of descriptors (``mdx_index``).
+
+    ``vecs`` is a device tensor, ``[D,N]`` (layout "DN", the reference's
+    ``extract_vectors`` output) or ``[N,D]`` (layout "ND")."""
+
+    def __init__(self, vecs, layout="DN", row_offset=0):
+        n, d, lay = _layout(vecs, layout, "vecs")
+        self._h = ctypes.c_void_p()
+        self.device = vecs.device
+        self.n, self.d, self.row_offset = n, d, int(row_offset)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mdx_index_create(ctypes.byref(self._h), _dev(vecs, torch.float32, "vecs"), n, d,
+                                              lay, self.row_offset, _stream()), "mdx_index_create")
+            # the source tensor may be freed by the caller right after: finish the re-tiling first
+            torch.cuda.current_stream().synchronize()
+
+    @property
+    def device_bytes(self):
+        b = ctypes.c_int64()
+        check(_lib.lib().mdx_index_info(self._h, None, None, None, ctypes.byref(b)), "mdx_index_info")
+        return b.value
+
+    def scores(self, queries, qlayout="DN", center=None, out=None):
+        """fp32 ``[nq, n]``: row q = similarities of query q to every shard row.
+
+        The transpose of ``np.dot(vecs.T, qvecs)`` (cirscore.py:69)."""
+        if self._h is None:
+            raise RuntimeError("index is closed")
+        nq, d, lay = _layout(queries, qlayout, "queries")
+        if d != self.d:
+            raise ValueError("query dimension %d != index dimension %d" % (d, self.d))
+        qp = _dev(queries, torch.float32, "queries")
+        cp = _dev(center, torch.float32, "center") if center is not None else None
+        if center is not None and center.numel() != d:
+            raise ValueError("center has %d elements, expected %d" % (center.numel(), d))
+        if out is None:
+            out = torch.empty((nq, self.n), dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (nq, self.n):
+            raise ValueError("out must be [%d,%d]" % (nq, self.n))
+        need = _lib.lib().mdx_scores_workspace(nq, d)
+        ws = _workspace(need, self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mdx_scores(self._h, qp, nq, lay, cp, _dev(out, torch.float32, "out"),
+                                        _vp(ws.data_ptr()), need, _stream()), "mdx_scores")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            h, self._h = self._h, None
+            check(_lib.lib().mdx_index_destroy(h), "mdx_index_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------- ranking
+
+def rank_workspace_bytes(n, nq):
+    return _lib.lib().mdx_rank_workspace(n, nq)
+
+
+def rank_full(scores, id_offset=0, out=None, workspace=None):
+    """int64 ``[nq, n]``: row q = ids best to worst (transpose of cirscore.py:70)."""
+    sp = _dev(scores, torch.float32, "scores")
+    nq, n = scores.shape
+    need = rank_workspace_bytes(n, nq)
+    ws = workspace if workspace is not None else _workspace(need, scores.device)
+    if out is None:
+        out = torch.empty((nq, n), dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        check(_lib.lib().mdx_rank_full(sp, n, nq, int(id_offset), _dev(out, torch.int64, "ranks"),
+                                       _vp(ws.data_ptr()), ws.numel(), _stream()), "mdx_rank_full")
+    return out
+
+
+def topk(scores, k, id_offset=0, workspace=None):
+    """(ids int64 [nq,k], scores fp32 [nq,k]) of the k best rows per query."""
+    sp = _dev(scores, torch.float32, "scores")
+    nq, n = scores.shape
+    need = rank_workspace_bytes(n, nq)
+    ws = workspace if workspace is not None else _workspace(need, scores.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    vals = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    with torch.cuda.device(scores.device):
+        check(_lib.lib().mdx_topk(sp, n, nq, int(k), int(id_offset), _vp(ids.data_ptr()), _vp(vals.data_ptr()),
+                                  _vp(ws.data_ptr()), ws.numel(), _stream()), "mdx_topk")
+    return ids, vals
+
+
+def _csr(id_lists, device):
+    offsets = [0]
+    flat = []
+    for ids in id_lists:
+        flat.extend(int(i) for i in ids)
+        offsets.append(len(flat))
+    ids_t = torch.tensor(flat, dtype=torch.int64, device=device)
+    off_t = torch.tensor(offsets, dtype=torch.int64, device=device)
+    return ids_t, off_t, offsets
+
+
+def rank_of(scores, id_lists):
+    """Zero-based rank positions of the given ids, per query, without sorting.
+
+    ``id_lists[q]`` = database ids of query q.  Returns (positions, id_scores) as
+    flat device tensors plus the CSR offsets (python list)."""
+    sp = _dev(scores, torch.float32, "scores")
+    nq, n = scores.shape
+    if len(id_lists) != nq:
+        raise ValueError("need one id list per query")
+    ids_t, off_t, offsets = _csr(id_lists, scores.device)
+    total = ids_t.numel()
+    pos = torch.zeros(total, dtype=torch.int64, device=scores.device)
+    sc = torch.empty(total, dtype=torch.float32, device=scores.device)
+    if total:
+        if int(ids_t.min()) < 0 or int(ids_t.max()) >= n:
+            raise IndexError("labelled id out of range [0,%d)" % n)
+        with torch.cuda.device(scores.device):
+            check(_lib.lib().mdx_rank_of(sp, n, nq, _vp(ids_t.data_ptr()), _vp(off_t.data_ptr()), total,
+                                         _vp(sc.data_ptr()), _vp(pos.data_ptr()), _stream()), "mdx_rank_of")
+    return pos, sc, offsets
+
+
+def gather_scores(scores, ids_t, off_t):
+    sp = _dev(scores, torch.float32, "scores")
+    nq, n = scores.shape
+    out = torch.empty(ids_t.numel(), dtype=torch.float32, device=scores.device)
+    if ids_t.numel():
+        with torch.cuda.device(scores.device):
+            check(_lib.lib().mdx_gather_scores(sp, n, nq, _dev(ids_t, torch.int64, "ids"),
+                                               _dev(off_t, torch.int64, "offsets"), ids_t.numel(),
+                                               _vp(out.data_ptr()), _stream()), "mdx_gather_scores")
+    return out
+
+
+def rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, off_t):
+    """cnt[t] += number of rows of this shard's ``scores`` that rank before
+    (ref_scores[t], ref_ids[t]); the per-shard term of a global rank position."""
+    sp = _dev(scores, torch.float32, "scores")
+    nq, n = scores.shape
+    if ref_ids.numel():
+        with torch.cuda.device(scores.device):
+            check(_lib.lib().mdx_rank_count(sp, n, nq, int(id_offset), _dev(ref_scores, torch.float32, "ref_scores"),
+                                            _dev(ref_ids, torch.int64, "ref_ids"), _dev(off_t, torch.int64, "offsets"),
+                                            ref_ids.numel(), _dev(cnt, torch.int64, "cnt"), _stream()),
+                  "mdx_rank_count")
+    return cnt

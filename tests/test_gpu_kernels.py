@@ -1,0 +1,188 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Bar: bit-exact for ids / positions; scores bit-exact against the fmaf-chain oracle
+(oracle/chain.c) and within 1e-5 of the reference's np.dot; pooled / normalised
+floats within rtol 1e-5 (tolerance of BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sparse_map
+from oracle import chain as OC
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mdir_amd import ops as _ops
+    return _ops
+
+
+def _unit_rows(rng, n, d):
+    v = rng.standard_normal((n, d)).astype(np.float32)
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("n,d,nq", [(4993, 2048, 70), (1000, 512, 1), (333, 100, 17), (16, 64, 16),
+                                    (5000, 256, 130), (70, 2048, 70)])
+def test_scores_bit_exact_vs_chain(ops, n, d, nq):
+    rng = np.random.default_rng(n + d + nq)
+    db, qv = _unit_rows(rng, n, d), _unit_rows(rng, nq, d)
+    vecs, qvecs = np.ascontiguousarray(db.T), np.ascontiguousarray(qv.T)   # reference layout [D,N],[D,Q]
+    want = OC.scores_chain(vecs, qvecs)
+    ix = ops.DescriptorIndex(dev(vecs), "DN")
+    got = ix.scores(dev(qvecs), "DN").cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # row-major inputs give the same bits
+    ix2 = ops.DescriptorIndex(dev(db), "ND")
+    got2 = ix2.scores(dev(qv), "ND").cpu().numpy()
+    np.testing.assert_array_equal(got2, want)
+    # and the reference's BLAS result is within the north-star tolerance
+    np.testing.assert_allclose(got.T, O.scores(vecs, qvecs), rtol=0, atol=1e-5)
+
+
+def test_scores_golden_small(ops, golden):
+    g = golden("g7_ranking.npz")
+    for name in "abc":
+        ix = ops.DescriptorIndex(dev(g[f"{name}_vecs"]), "DN")
+        sc = ix.scores(dev(g[f"{name}_qvecs"]), "DN")
+        np.testing.assert_allclose(sc.cpu().numpy().T, g[f"{name}_scores"], rtol=0, atol=1e-6)
+        rk = ops.rank_full(sc).cpu().numpy()
+        np.testing.assert_array_equal(rk.T, g[f"{name}_ranks"])
+
+
+def test_scores_center(ops):
+    rng = np.random.default_rng(3)
+    P, X = rng.standard_normal((96, 80)).astype(np.float32), rng.standard_normal((9, 80)).astype(np.float32)
+    m = rng.standard_normal(80).astype(np.float32)
+    ix = ops.DescriptorIndex(dev(P), "ND")
+    got = ix.scores(dev(X), "ND", center=dev(m)).cpu().numpy()
+    np.testing.assert_array_equal(got, OC.gemm_nt_chain(X - m, P))
+
+
+@pytest.mark.parametrize("n,nq", [(4993, 70), (1, 1), (63, 3), (4096, 2), (4097, 2), (70000, 5)])
+def test_rank_full_bit_exact(ops, n, nq):
+    rng = np.random.default_rng(n * 7 + nq)
+    sc = rng.standard_normal((nq, n)).astype(np.float32)
+    if n > 100:
+        sc[:, 10:40] = sc[:, 5:6]      # runs of exact ties
+        sc[0, 50] = np.nan
+        sc[0, 51] = -0.0
+        sc[0, 52] = 0.0
+    want = OC.rank_full(sc)
+    got = ops.rank_full(dev(sc)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    got = ops.rank_full(dev(sc), id_offset=1000).cpu().numpy()
+    np.testing.assert_array_equal(got, want + 1000)
+
+
+def test_rank_tie_fixture(ops, golden):
+    g = golden("g7_ranking.npz")
+    ix = ops.DescriptorIndex(dev(g["tie_vecs"]), "DN")
+    sc = ix.scores(dev(g["tie_qvecs"]), "DN")
+    np.testing.assert_array_equal(sc.cpu().numpy().T, g["tie_scores"])
+    rk = ops.rank_full(sc).cpu().numpy().T
+    np.testing.assert_array_equal(rk, O.ranks(g["tie_scores"]))
+
+
+def test_topk_and_rank_of(ops):
+    rng = np.random.default_rng(11)
+    nq, n = 6, 20000
+    sc = rng.standard_normal((nq, n)).astype(np.float32)
+    sc[:, 100:164] = sc[:, 99:100]
+    full = OC.rank_full(sc)
+    ids, vals = ops.topk(dev(sc), 100)
+    np.testing.assert_array_equal(ids.cpu().numpy(), full[:, :100])
+    np.testing.assert_array_equal(vals.cpu().numpy(), np.take_along_axis(sc, full[:, :100], axis=1))
+    lists = [rng.choice(n, size=s, replace=False) for s in (5, 0, 300, 1, 64, 17)]
+    lists[2][:10] = np.arange(100, 110)   # inside the tie run
+    pos, idsc, off = ops.rank_of(dev(sc), lists)
+    pos, idsc = pos.cpu().numpy(), idsc.cpu().numpy()
+    for q in range(nq):
+        np.testing.assert_array_equal(pos[off[q]:off[q + 1]], OC.rank_of(sc[q], lists[q]))
+        np.testing.assert_array_equal(idsc[off[q]:off[q + 1]], sc[q][lists[q]])
+
+
+def test_pool_l2n_golden(ops, golden):
+    g = golden("g1_pool.npz")
+    for c, h, w in [(2048, 24, 32), (2048, 17, 23), (512, 48, 64), (256, 7, 5)]:
+        x = sparse_map(int(g[f"seed_c{c}_h{h}_w{w}"]), (1, c, h, w))
+        xd = dev(x)
+        for p in (3.0, 2.2, 1.0):
+            got = ops.pool_l2n(xd, "gem", p, l2n_eps=None).cpu().numpy()[0]
+            np.testing.assert_allclose(got, g[f"gem_c{c}_h{h}_w{w}_p{p}"], rtol=1e-5, atol=1e-7)
+            both = ops.pool_l2n(xd, "gem", p).cpu().numpy()
+            np.testing.assert_allclose(both, O.l2n(O.gem(x, p)), rtol=1e-5, atol=1e-7)
+        np.testing.assert_array_equal(ops.pool_l2n(xd, "mac", l2n_eps=None).cpu().numpy()[0], g[f"mac_c{c}_h{h}_w{w}"])
+        np.testing.assert_allclose(ops.pool_l2n(xd, "spoc", l2n_eps=None).cpu().numpy()[0], g[f"spoc_c{c}_h{h}_w{w}"],
+                                   rtol=1e-5)
+
+
+def test_pool_batch_and_zero_map(ops):
+    x = sparse_map(5, (3, 64, 6, 9))
+    x[1] = 0.0
+    got = ops.pool_l2n(dev(x), "gem", 2.92).cpu().numpy()
+    np.testing.assert_allclose(got, O.l2n(O.gem(x, 2.92)), rtol=1e-5, atol=1e-7)
+    assert not np.isnan(got).any()
+
+
+def test_l2n_rows_golden(ops, golden):
+    g = golden("g2_l2n.npz")
+    got = ops.l2n_rows_(dev(g["x"].copy())).cpu().numpy()
+    np.testing.assert_allclose(got, g["y"], rtol=1e-6, atol=1e-9)
+    assert np.all(got[2] == 0)
+
+
+def test_forward_tail_golden(ops, golden):
+    """pool -> L2N -> nn.Linear whitening -> L2N (imageretrievalnet.py:107-115)."""
+    g = golden("g3_tail.npz")
+    feat = dev(g["feat"])
+    wix = ops.DescriptorIndex(dev(g["w"]), "ND")
+    for p in (3.0, 2.92):
+        o = ops.pool_l2n(feat, "gem", p)
+        np.testing.assert_allclose(o.cpu().numpy().T, g[f"out_plain_p{p}"], rtol=1e-5, atol=1e-7)
+        y = wix.scores(o, "ND")                       # [B, D] = o @ W^T
+        ops.l2n_rows_(y, bias=dev(g["b"]))
+        np.testing.assert_allclose(y.cpu().numpy().T, g[f"out_whiten_p{p}"], rtol=1e-5, atol=2e-7)
+
+
+def test_ms_aggregate_golden(ops, golden):
+    g = golden("g4_aggregate.npz")
+    vs = [dev(v) for v in g["vecs"]]
+    for msp in (1.0, 3.0, 2.92):
+        got = ops.ms_aggregate(vs, msp).cpu().numpy()
+        np.testing.assert_allclose(got, g[f"agg_msp{msp}"], rtol=1e-5, atol=1e-8)
+
+
+def test_whiten_golden(ops, golden):
+    """CirtorchWhiten.postprocess as index-of-P x centred descriptors (wrapper.py:193-195)."""
+    g = golden("g5_whiten.npz")
+    P32, m32 = g["P"].astype(np.float32), g["m"].astype(np.float32).reshape(-1)
+    X = g["X"]
+    for dims in (None, 48):
+        d = dims or P32.shape[0]
+        pix = ops.DescriptorIndex(dev(P32[:d]), "ND")
+        y = pix.scores(dev(X), "DN", center=dev(m32))      # [N, d]
+        np.testing.assert_array_equal(y.cpu().numpy(), OC.gemm_nt_chain((X.T - m32), P32[:d]))
+        ops.l2n_rows_(y, eps=1e-6)
+        np.testing.assert_allclose(y.cpu().numpy().T, g[f"wrapper_dims{dims}"], rtol=1e-5, atol=2e-7)
+
+
+def test_errors_are_loud(ops):
+    with pytest.raises(RuntimeError):
+        ops.pool_l2n(torch.zeros(1, 4, 2, 2), "gem")           # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        ops.pool_l2n(torch.zeros(1, 4, 2, 2, device=DEV), "gem", p=-1.0)
+    ix = ops.DescriptorIndex(torch.zeros(8, 40, device=DEV), "DN")
+    with pytest.raises(ValueError):
+        ix.scores(torch.zeros(9, 3, device=DEV), "DN")
+    with pytest.raises(IndexError):
+        ops.rank_of(torch.zeros(1, 10, device=DEV), [[10]])
