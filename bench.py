@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec of the ranking hot path on the rOxford5k +
+1M-distractor shaped workload (BASELINE.json configs[2]; configs[3] for --gpus N).
+
+A "step" = one pass of the hot path over one batch of 70 queries against the
+resident database: similarity (mdx_scores, fp32 MFMA) + exact full ranking
+(mdx_rank_full), i.e. the reference's `np.dot(vecs.T, qvecs)` + `np.argsort(-scores,
+axis=0)` (mdir/components/optim/score/cirscore.py:69-70).  Inputs are resident in
+HBM when the timed region starts.  With --gpus N the 1M database is row-sharded
+(strong scaling); see mdir_amd/sharded.py for the exchange.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n ROWS] [--no-cpu-baseline]
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+N_ROXFORD, N_DISTRACTORS = 4993, 1_000_000
+NQ, DIM = 70, 2048
+GEN_BLOCK = 4096
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def gen_rows(lo, hi, device):
+    """Rows [lo,hi) of the synthetic database as [hi-lo, D]: i.i.d. N(0,1), unit norm.
+    Block-seeded so that any rank regenerates any row identically."""
+    out = torch.empty((hi - lo, DIM), dtype=torch.float32, device=device)
+    b = lo // GEN_BLOCK
+    while b * GEN_BLOCK < hi:
+        g = torch.Generator(device=device)
+        g.manual_seed(1000 + b)
+        blk = torch.randn((GEN_BLOCK, DIM), generator=g, device=device, dtype=torch.float32)
+        blk /= blk.norm(dim=1, keepdim=True)
+        s, e = max(lo, b * GEN_BLOCK), min(hi, (b + 1) * GEN_BLOCK)
+        out[s - lo:e - lo] = blk[s - b * GEN_BLOCK:e - b * GEN_BLOCK]
+        b += 1
+    return out
+
+
+def gen_queries(n_total, device):
+    """70 queries = 70 distinct database rows + 0.05 N(0,1) noise, re-normalised ([D,Q])."""
+    rng = np.random.default_rng(0)
+    qid = np.sort(rng.choice(n_total, size=NQ, replace=False))
+    rows = torch.cat([gen_rows(int(i), int(i) + 1, device) for i in qid])
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    q = rows + 0.05 * torch.randn((NQ, DIM), generator=g, device=device)
+    q /= q.norm(dim=1, keepdim=True)
+    return q.t().contiguous(), qid
+
+
+def synth_gnd(n_labelled):
+    """rOxford-shaped ground truth: easy 5 / hard 10 / junk 5 disjoint random ids per
+    query among the first 4993 rows."""
+    rng = np.random.default_rng(1)
+    gnd = []
+    for _ in range(NQ):
+        ids = rng.choice(n_labelled, size=20, replace=False)
+        gnd.append({"easy": np.sort(ids[:5]), "hard": np.sort(ids[5:15]), "junk": np.sort(ids[15:]), "bbx": None})
+    return gnd
+
+
+def cpu_baseline(vecs_dn_host, qvecs_host):
+    """The reference's two ranking statements through the numpy oracle, host cores."""
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    sc = O.scores(vecs_dn_host, qvecs_host)
+    t1 = time.perf_counter()
+    rk = np.argsort(-sc, axis=0)     # the reference's literal statement (default kind)
+    t2 = time.perf_counter()
+    return sc, rk, t1 - t0, t2 - t1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_ROXFORD + N_DISTRACTORS, help="database rows (default 1 004 993)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from mdir_amd import ops
+    from mdir_amd.sharded import ShardedIndex, shard_bounds
+    from mdir_amd.evaluate import compute_map_and_print, compute_map_and_print_from_scores
+
+    n_total = args.n
+    lo, hi = shard_bounds(n_total, world, rank)
+    rows = gen_rows(lo, hi, device)                 # [n_local, D]
+    qvecs, qid = gen_queries(n_total, device)       # [D, Q]
+    t0 = time.perf_counter()
+    sharded = ShardedIndex(rows, "ND", n_total)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    n_local = hi - lo
+
+    if world == 1:
+        sc = torch.empty((NQ, n_total), dtype=torch.float32, device=device)
+        rk = torch.empty((NQ, n_total), dtype=torch.int64, device=device)
+        ws = torch.empty(ops.rank_workspace_bytes(n_total, NQ), dtype=torch.uint8, device=device)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+        def step(i=None):
+            if i is not None:
+                ev[i][0].record()
+            sharded.index.scores(qvecs, "DN", out=sc)
+            if i is not None:
+                ev[i][1].record()
+            ops.rank_full(sc, out=rk, workspace=ws)
+    else:
+        ev = []
+        keep = {}
+
+        def step(i=None):
+            keep["rk"], keep["sc"], keep["q"] = sharded.rank_queries(qvecs, "DN")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i if world == 1 else None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- results check + mAP (untimed) --------------------------------------
+    gnd = synth_gnd(min(N_ROXFORD, n_total))
+    extra = {}
+    if world == 1:
+        avg_s, _ = compute_map_and_print_from_scores("roxford5k", sc, gnd)           # counting kernel, no sort
+        avg_r, _ = compute_map_and_print("roxford5k", rk.t(), gnd)                   # from the full ranking
+        assert avg_s == avg_r, (avg_s, avg_r)
+        assert bool((rk[:, 0].cpu() == torch.from_numpy(qid)).all()), "every query must retrieve its source row first"
+        extra["map_medium"] = avg_r["map_medium"]
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        flops = 2.0 * NQ * n_total * DIM
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        algo_bytes = 4.0 * n_total * DIM + 4.0 * NQ * DIM + 4.0 * NQ * n_total
+        traffic = None
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        if tf:
+            traffic = json.load(open(tf[-1])).get("scores_kernel_hbm_bytes_per_launch")
+        roofline = {"kernel": "mdx::scores_kernel<5,2> (fp32 MFMA 16x16x4)", "bound": "mfma",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops, "algorithmic_bytes": algo_bytes,
+                    "hbm_GBps_at_algorithmic_bytes": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 1),
+                    "hbm_frac_of_8TBps": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        extra["roofline"] = roofline
+        extra["rank_ms_per_step"] = round(elapsed / args.steps * 1e3 - kernel_ms, 4)
+    else:
+        rk_mine, sc_mine, (qlo, qhi) = keep["rk"], keep["sc"], keep["q"]
+        ok = torch.tensor([1], device=device)
+        if qhi > qlo:
+            ok[0] = int(bool((rk_mine[:, 0].cpu() == torch.from_numpy(qid[qlo:qhi])).all()))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        assert int(ok.item()) == 1, "sharded ranking lost a query's source row"
+        # mAP without any ranking: counting kernel + two tiny all-reduces
+        s_local = sharded.local_scores(qvecs, "DN")
+        from mdir_amd.evaluate import map_from_positions
+        oks = [np.concatenate([g["easy"], g["hard"]]) for g in gnd]
+        junks = [g["junk"] for g in gnd]
+        pos, off = sharded.positions(s_local, [np.concatenate([o, j]) for o, j in zip(oks, junks)])
+        pos = pos.cpu().numpy()
+        pl = [pos[off[q]:off[q] + len(oks[q])] for q in range(NQ)]
+        jl = [pos[off[q] + len(oks[q]):off[q + 1]] for q in range(NQ)]
+        extra["map_medium"] = map_from_positions(pl, jl, [len(o) for o in oks])[0]
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            vecs_host = rows.t().contiguous().cpu().numpy()       # reference layout [D,N]
+            _, rk_cpu, t_dot, t_sort = cpu_baseline(vecs_host, qvecs.cpu().numpy())
+            import multiprocessing
+            extra["cpu_baseline"] = {
+                "value": round(NQ / (t_dot + t_sort), 3), "unit": "queries/s",
+                "cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else multiprocessing.cpu_count(),
+                "kind": "port",
+                "sample": "full workload once (no warm-up): np.dot %.2f s (BLAS, all cores) + np.argsort %.2f s (1 thread), "
+                          "N=%d Q=%d D=%d fp32" % (t_dot, t_sort, n_total, NQ, DIM)}
+            agree = float((rk_cpu[:100] == rk[:, :100].t().cpu().numpy()).mean())
+            extra["cpu_top100_id_agreement"] = round(agree, 6)
+            del vecs_host, rk_cpu
+        except MemoryError:
+            extra["cpu_baseline"] = None
+
+    if rank == 0:
+        qps = NQ * args.steps / elapsed
+        line = {"metric": "queries/sec, exact full ranking (rOxford5k+1M-distractor shape, 2048-d fp32); mAP-medium alongside",
+                "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[2]: roxford5k+1M synthetic distractors, N=%d Q=%d D=%d, "
+                                       "similarity + exact full ranking per step" % (n_total, NQ, DIM),
+                           "db_rows_per_gpu": n_local, "parallelism": "db-row-shard x%d, query-split sort" % world,
+                           "index_build_s": round(build_s, 4)}}
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+"""Mean average precision -- the cirtorch evaluation API, position-based.
+
+Drop-in for ``mdir/external/cirtorch/utils/evaluate.py`` (``compute_ap`` :3-37,
+``compute_map`` :39-111, ``compute_map_and_print`` :114-152, the mdir-patched
+variant that returns dictionaries).  Same signatures, same return values, same
+float64 accumulation order, so results are bit-identical to the reference's.
+
+The per-query work is expressed on rank POSITIONS of the labelled ids.  Positions
+come either from a materialised ranking (``ranks[:, q]``, numpy or torch, any
+device -- the reference call style) or straight from the scores through the HIP
+counting kernel (``positions_from_scores`` -> ``mdx_rank_of``), which yields the
+same numbers without sorting a million-row database.
+"""
+import numpy as np
+
+try:  # torch is only needed when rankings live on the GPU
+    import torch
+except ImportError:  # pragma: no cover
+    torch = None
+
+
+def compute_ap(ranks, nres):
+    """AP from ascending zero-based ranks of the positives (evaluate.py:3-37)."""
+    ap = 0.0
+    recall_step = 1.0 / nres
+    for j, rank in enumerate(ranks):
+        rank = int(rank)
+        p0 = 1.0 if rank == 0 else float(j) / rank
+        p1 = float(j + 1) / (rank + 1)
+        ap += (p0 + p1) * recall_step / 2.0
+    return ap
+
+
+def _ap_and_precisions(pos, junk, nok, kappas):
+    """One query: positions (ascending) of positives / junk -> (ap, P@kappas).
+    evaluate.py:85-106: positives move up by the junk ranked before them."""
+    pos = np.asarray(pos, dtype=np.int64)
+    junk = np.asarray(junk, dtype=np.int64)
+    if len(junk):
+        pos = pos - np.searchsorted(junk, pos, side="left")
+    ap = compute_ap(pos, nok)
+    prs = np.zeros(len(kappas))
+    if len(kappas):
+        pos1 = pos + 1
+        top = int(pos1.max())
+        for j, kappa in enumerate(kappas):
+            kq = min(top, kappa)
+            prs[j] = (pos1 <= kq).sum() / kq
+    return ap, prs
+
+
+def _column_positions(ranks, q, ids):
+    """Ascending positions at which ``ids`` occur in column q of ``ranks`` [N,Q]."""
+    if len(ids) == 0:
+        return np.empty(0, dtype=np.int64)
+    if torch is not None and isinstance(ranks, torch.Tensor):
+        col = ranks[:, q]
+        want = torch.as_tensor(np.asarray(ids, dtype=np.int64), device=col.device)
+        return torch.nonzero(torch.isin(col, want)).reshape(-1).cpu().numpy()
+    return np.nonzero(np.isin(ranks[:, q], np.asarray(ids)))[0]
+
+
+def map_from_positions(pos_lists, junk_lists, nok, kappas=()):
+    """mAP from per-query position arrays (unsorted ok; ``nok[q]`` positives).
+
+    Same outputs as :func:`compute_map`: ``(map, aps, pr, prs)``."""
+    nq = len(pos_lists)
+    aps = np.zeros(nq)
+    pr = np.zeros(len(kappas))
+    prs = np.zeros((nq, len(kappas)))
+    total, nempty = 0.0, 0
+    for q in range(nq):
+        if nok[q] == 0:
+            aps[q] = float("nan")
+            prs[q, :] = float("nan")
+            nempty += 1
+            continue
+        ap, prs[q, :] = _ap_and_precisions(np.sort(pos_lists[q]), np.sort(junk_lists[q]), nok[q], kappas)
+        aps[q] = ap
+        total += ap
+        pr = pr + prs[q, :]
+    return total / (nq - nempty), aps, pr / (nq - nempty), prs
+
+
+def compute_map(ranks, gnd, kappas=[]):
+    """mAP of a ranking (evaluate.py:39-111).
+
+    ``ranks``: ``[N,Q]`` ids best-to-worst per column -- numpy array or torch tensor
+    (CPU or GPU; a transposed view of the ``[Q,N]`` matrix mdx_rank_full writes is
+    fine).  ``gnd[q]``: ``ok`` ids, optional ``junk`` ids.  Queries with no
+    positives are NaN and excluded from the mean.
+    Returns ``(map, aps, pr, prs)``.
+    """
+    nq = len(gnd)
+    pos_lists, junk_lists, nok = [], [], []
+    for q in range(nq):
+        ok = np.asarray(gnd[q]["ok"])
+        nok.append(ok.shape[0])
+        if ok.shape[0] == 0:
+            pos_lists.append(np.empty(0, dtype=np.int64))
+            junk_lists.append(np.empty(0, dtype=np.int64))
+            continue
+        junk = np.asarray(gnd[q]["junk"]) if "junk" in gnd[q] else np.empty(0)
+        pos_lists.append(_column_positions(ranks, q, ok))
+        junk_lists.append(_column_positions(ranks, q, junk))
+    return map_from_positions(pos_lists, junk_lists, nok, kappas)
+
+
+def positions_from_scores(scores, id_lists):
+    """Rank positions of labelled ids from a device score matrix ``[Q,N]`` through
+    the HIP counting kernel -- no ranking is materialised.  Returns a list of numpy
+    arrays aligned with ``id_lists``."""
+    from . import ops
+    pos, _, off = ops.rank_of(scores, id_lists)
+    pos = pos.cpu().numpy()
+    return [pos[off[q]:off[q + 1]] for q in range(len(id_lists))]
+
+
+def compute_map_from_scores(scores, gnd, kappas=[]):
+    """:func:`compute_map` on scores ``[Q,N]`` (device) instead of a ranking."""
+    nq = len(gnd)
+    oks = [np.asarray(g["ok"], dtype=np.int64).reshape(-1) for g in gnd]
+    junks = [np.asarray(g["junk"], dtype=np.int64).reshape(-1) if "junk" in g else np.empty(0, dtype=np.int64)
+             for g in gnd]
+    junks = [j if len(o) else np.empty(0, dtype=np.int64) for o, j in zip(oks, junks)]
+    both = positions_from_scores(scores, [np.concatenate([o, j]) for o, j in zip(oks, junks)])
+    pos_lists = [b[:len(o)] for b, o in zip(both, oks)]
+    junk_lists = [b[len(o):] for b, o in zip(both, oks)]
+    return map_from_positions(pos_lists, junk_lists, [len(o) for o in oks], kappas)
+
+
+def _protocol_gnd(gnd, ok_keys, junk_keys):
+    return [{"ok": np.concatenate([g[k] for k in ok_keys]),
+             "junk": np.concatenate([g[k] for k in junk_keys])} for g in gnd]
+
+
+_LEVELS = (("easy", ("easy",), ("junk", "hard")),
+           ("medium", ("easy", "hard"), ("junk",)),
+           ("hard", ("hard",), ("junk", "easy")))
+
+
+def _evaluate(dataset, gnd, kappas, one_map):
+    """Protocol dispatch shared by the ranking- and the scores-based entry points."""
+    if "ok" in gnd[0]:  # old protocol (evaluate.py:117-120)
+        m, aps, _, _ = one_map(gnd, [])
+        print(">> {}: mAP {:.2f}".format(dataset, np.around(m * 100, decimals=2)))
+        return {"map": m}, {"ap": aps}
+    if dataset.startswith("roxford5k") or dataset.startswith("rparis6k"):  # evaluate.py:123-152
+        avg, per, mpr = {}, {}, {}
+        for level, ok_keys, junk_keys in _LEVELS:
+            m, aps, pr, _ = one_map(_protocol_gnd(gnd, ok_keys, junk_keys), list(kappas))
+            avg["map_" + level], per["ap_" + level], mpr[level] = m, aps, pr
+        r = lambda v: np.around(v * 100, decimals=2)
+        print(">> {}: mAP E: {}, M: {}, H: {}".format(dataset, r(avg["map_easy"]), r(avg["map_medium"]),
+                                                      r(avg["map_hard"])))
+        print(">> {}: mP@k{} E: {}, M: {}, H: {}".format(dataset, list(kappas), r(mpr["easy"]), r(mpr["medium"]),
+                                                         r(mpr["hard"])))
+        return avg, per
+    return None  # the reference falls off the end for other datasets
+
+
+def compute_map_and_print(dataset, ranks, gnd, kappas=[1, 5, 10]):
+    """``(averages, per_query)`` dicts with the reference's keys (evaluate.py:114-152)."""
+    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map(ranks, g, k))
+
+
+def compute_map_and_print_from_scores(dataset, scores, gnd, kappas=[1, 5, 10]):
+    """Same as :func:`compute_map_and_print`, from device scores ``[Q,N]``."""
+    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map_from_scores(scores, g, k))

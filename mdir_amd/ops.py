@@ -100,12 +100,14 @@ class DescriptorIndex:
     ``extract_vectors`` output) or ``[N,D]`` (layout "ND")."""
 
     def __init__(self, vecs, layout="DN", row_offset=0):
+        self._h = None
+        vp = _dev(vecs, torch.float32, "vecs")
         n, d, lay = _layout(vecs, layout, "vecs")
         self._h = ctypes.c_void_p()
         self.device = vecs.device
         self.n, self.d, self.row_offset = n, d, int(row_offset)
         with torch.cuda.device(self.device):
-            check(_lib.lib().mdx_index_create(ctypes.byref(self._h), _dev(vecs, torch.float32, "vecs"), n, d,
+            check(_lib.lib().mdx_index_create(ctypes.byref(self._h), vp, n, d,
                                               lay, self.row_offset, _stream()), "mdx_index_create")
             # the source tensor may be freed by the caller right after: finish the re-tiling first
             torch.cuda.current_stream().synchronize()

@@ -1,0 +1,130 @@
+"""Row-sharded database over the GPUs of one node (one process per GPU).
+
+The reference has no distributed code; this is the
+MI355X-native scale-out of ``cirscore.py:69-70``.  Database rows are independent,
+so rank g keeps rows ``[row_offset, row_offset + n_local)`` resident as its own
+``DescriptorIndex`` and computes ``S_g [Q, n_local]`` with no communication.  Two
+exchange patterns sit on top, both through ``torch.distributed`` (backend "nccl"
+= RCCL over xGMI on the GPU box, "gloo" in the CPU tests):
+
+* ``rank_queries``  -- exact FULL ranking.  One all-to-all re-partitions the
+  partial scores from "all queries x my rows" to "my queries x all rows"
+  (each rank sends 1/G of its block to every peer: point-to-point xGMI links, no
+  ring), then every rank sorts only its own ceil(Q/G) queries, so the sort is
+  G-way parallel too.  Query q's ranking lives on rank ``owner(q)``.
+* ``positions``     -- rank positions of labelled ids WITHOUT sorting: labelled
+  scores are summed over shards (all-reduce, a few kB), each shard counts how many
+  of its rows precede each labelled item, and the counts are all-reduced.
+
+The compute backend is injected so the exchange logic is testable on CPU: the
+product default is the HIP library (``HipBackend``) and raises without a GPU;
+tests pass an oracle-backed object explicitly.
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipBackend:
+    """libmdx.so through mdir_amd.ops (the only backend the product ships)."""
+
+    def make_index(self, vecs, layout, row_offset):
+        from . import ops
+        return ops.DescriptorIndex(vecs, layout, row_offset)
+
+    def rank_full(self, scores, id_offset=0):
+        from . import ops
+        return ops.rank_full(scores, id_offset)
+
+    def gather_scores(self, scores, ids, offsets):
+        from . import ops
+        return ops.gather_scores(scores, ids, offsets)
+
+    def rank_count_(self, cnt, scores, id_offset, ref_scores, ref_ids, offsets):
+        from . import ops
+        return ops.rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, offsets)
+
+
+def shard_bounds(n_total, world, rank):
+    """Rows ``[lo, hi)`` of shard ``rank``: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def query_bounds(nq, world, rank):
+    return shard_bounds(nq, world, rank)
+
+
+class ShardedIndex:
+    def __init__(self, local_vecs, layout, n_total, group=None, backend=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_total = int(n_total)
+        self.lo, self.hi = shard_bounds(self.n_total, self.world, self.rank)
+        n_local = local_vecs.shape[1] if layout in ("DN", "dim_major") else local_vecs.shape[0]
+        if n_local != self.hi - self.lo:
+            raise ValueError("rank %d holds %d rows, expected %d" % (self.rank, n_local, self.hi - self.lo))
+        self.backend = backend or HipBackend()
+        self.index = self.backend.make_index(local_vecs, layout, self.lo)
+        self.device = local_vecs.device
+
+    # ------------------------------------------------------------------ scores
+    def local_scores(self, queries, qlayout="DN"):
+        """``[Q, n_local]`` similarities against this rank's rows (no communication)."""
+        return self.index.scores(queries, qlayout)
+
+    # ----------------------------------------------------------- full ranking
+    def exchange(self, s_local):
+        """``[Q, n_local]`` on every rank  ->  ``[Q_mine, N]`` on every rank."""
+        nq = s_local.shape[0]
+        if self.world == 1:
+            return s_local, (0, nq)
+        qlo, qhi = query_bounds(nq, self.world, self.rank)
+        in_split = [(query_bounds(nq, self.world, r)[1] - query_bounds(nq, self.world, r)[0]) * s_local.shape[1]
+                    for r in range(self.world)]
+        widths = [shard_bounds(self.n_total, self.world, r)[1] - shard_bounds(self.n_total, self.world, r)[0]
+                  for r in range(self.world)]
+        out_split = [(qhi - qlo) * w for w in widths]
+        recv = torch.empty(sum(out_split), dtype=s_local.dtype, device=s_local.device)
+        dist.all_to_all_single(recv, s_local.reshape(-1), out_split, in_split, group=self.group)
+        blocks, o = [], 0
+        for w, sz in zip(widths, out_split):
+            blocks.append(recv[o:o + sz].view(qhi - qlo, w))
+            o += sz
+        return torch.cat(blocks, dim=1), (qlo, qhi)
+
+    def rank_queries(self, queries, qlayout="DN"):
+        """Exact full ranking, query-partitioned: returns ``(ranks [Q_mine, N] int64
+        with GLOBAL ids, scores [Q_mine, N], (qlo, qhi))``."""
+        s_mine, (qlo, qhi) = self.exchange(self.local_scores(queries, qlayout))
+        if qhi == qlo:
+            return torch.empty((0, self.n_total), dtype=torch.int64, device=self.device), s_mine, (qlo, qhi)
+        return self.backend.rank_full(s_mine, 0), s_mine, (qlo, qhi)
+
+    # -------------------------------------------------- positions w/o sorting
+    def positions(self, s_local, id_lists):
+        """Global zero-based rank positions of labelled GLOBAL ids, per query.
+
+        Returns ``(pos int64 [total], offsets list)`` identical on every rank."""
+        nq = s_local.shape[0]
+        offsets, flat = [0], []
+        for ids in id_lists:
+            flat.extend(int(i) for i in ids)
+            offsets.append(len(flat))
+        ids_t = torch.tensor(flat, dtype=torch.int64, device=self.device)
+        off_t = torch.tensor(offsets, dtype=torch.int64, device=self.device)
+        total = ids_t.numel()
+        cnt = torch.zeros(total, dtype=torch.int64, device=self.device)
+        if total == 0:
+            return cnt, offsets
+        mine = (ids_t >= self.lo) & (ids_t < self.hi)
+        local_ids = torch.where(mine, ids_t - self.lo, torch.zeros_like(ids_t))
+        ref = self.backend.gather_scores(s_local, local_ids, off_t)
+        ref = torch.where(mine, ref, torch.zeros_like(ref))
+        if self.world > 1:
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)   # exactly one owner per id
+        self.backend.rank_count_(cnt, s_local, self.lo, ref, ids_t, off_t)
+        if self.world > 1:
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)
+        return cnt, offsets

@@ -1,0 +1,56 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/mdx.h declares.
+(No compute calls here: they need a GPU and live in the -m gpu tests.)"""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mdx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_path():
+    names = _declared()
+    for must in ("mdx_pool_l2n", "mdx_ms_aggregate", "mdx_index_create", "mdx_scores", "mdx_rank_full",
+                 "mdx_topk", "mdx_rank_of", "mdx_rank_count", "mdx_l2n_rows"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from mdir_amd import _lib
+    _lib.build()
+    handle = _lib.lib()
+    for name in _declared():
+        assert hasattr(handle, name), name
+    assert set(_declared()) == set(_lib.EXPORTS)
+    assert handle.mdx_abi_version() == 1
+    # pure host-side helpers may be called without a GPU
+    assert handle.mdx_scores_workspace(70, 2048) == 80 * 2048 * 4
+    assert handle.mdx_scores_workspace(0, 2048) == 0
+    assert handle.mdx_rank_workspace(1004993, 70) > 16 * 1004993 * 70
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    import ctypes
+    from mdir_amd import _lib
+    h = _lib.lib()
+    rc = h.mdx_pool_l2n(None, 1, 1, 1, 1, 0, 3.0, 1e-6, 1e-6, None, None)
+    assert rc == -1 and b"NULL" in h.mdx_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "mdx_pool_l2n")
+    out = ctypes.c_void_p()
+    assert h.mdx_index_create(ctypes.byref(out), ctypes.c_void_p(16), -5, 8, 0, 0, None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from mdir_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.pool_l2n(torch.zeros(1, 2, 3, 3), "gem")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.rank_full(torch.zeros(2, 5))

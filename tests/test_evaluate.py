@@ -1,0 +1,65 @@
+"""mdir_amd.evaluate (the shipped host code) against the reference's outputs (golden) and the oracle."""
+import json
+
+import numpy as np
+import torch
+
+from mdir_amd import evaluate as E
+from oracle import oracle as O
+
+
+def _gnd(g):
+    return json.loads(bytes(g["gnd_json"]).decode())
+
+
+def test_compute_map_matches_reference_outputs(golden):
+    g = golden("g8_map.npz")
+    rk, gnd = g["ranks"].astype(np.int64), _gnd(g)
+    avg, per = E.compute_map_and_print("roxford5k", rk, gnd)
+    for lvl in ("easy", "medium", "hard"):
+        assert avg["map_" + lvl] == float(g["rox_map_" + lvl])
+        np.testing.assert_array_equal(per["ap_" + lvl], g["rox_ap_" + lvl])
+    m, aps, pr, prs = E.compute_map(rk, O.protocol_gnd(gnd, "medium"), [1, 5, 10])
+    assert m == float(g["medium_map"])
+    np.testing.assert_array_equal(aps, g["medium_aps"])
+    np.testing.assert_array_equal(pr, g["medium_pr"])
+    np.testing.assert_array_equal(prs, g["medium_prs"])
+    old = [{"ok": x["easy"] + x["hard"], "junk": x["junk"]} for x in gnd]
+    avg, per = E.compute_map_and_print("247tokyo1k", rk, old)
+    assert avg["map"] == float(g["old_map"])
+    np.testing.assert_array_equal(per["ap"], g["old_ap"])
+    m, aps, _, _ = E.compute_map(rk, [{"ok": x["ok"]} for x in old])
+    assert m == float(g["nojunkkey_map"])
+    assert E.compute_map_and_print("oxford5k", rk, gnd) is None
+    assert E.compute_ap([0], 1) == 1.0 and E.compute_ap([1], 1) == 0.25
+    assert E.compute_ap([0, 2], 2) == float(g["ap_r02_n2"]) and E.compute_ap([], 3) == 0
+
+
+def test_torch_and_transposed_inputs(golden):
+    g = golden("g8_map.npz")
+    rk, gnd = g["ranks"].astype(np.int64), _gnd(g)
+    want = E.compute_map(rk, O.protocol_gnd(gnd, "medium"), [1, 5, 10])
+    qn = torch.from_numpy(np.ascontiguousarray(rk.T))          # [Q,N] as mdx_rank_full writes it
+    got = E.compute_map(qn.t(), O.protocol_gnd(gnd, "medium"), [1, 5, 10])
+    for a, b in zip(want, got):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_positions_route_equals_ranking_route():
+    rng = np.random.default_rng(2)
+    n, nq = 300, 9
+    sc = rng.standard_normal((nq, n)).astype(np.float32)
+    rk = O.ranks(sc.T)
+    gnd = [{"ok": rng.choice(n, rng.integers(0, 6), replace=False), "junk": rng.choice(n, 4, replace=False)}
+           for _ in range(nq)]
+    for g_ in gnd:
+        g_["junk"] = np.setdiff1d(g_["junk"], g_["ok"])
+    want = E.compute_map(rk, gnd, [1, 5])
+    pos = [O.rank_of(sc[q], gnd[q]["ok"]) for q in range(nq)]
+    junk = [O.rank_of(sc[q], gnd[q]["junk"]) if len(gnd[q]["ok"]) else np.empty(0, np.int64) for q in range(nq)]
+    got = E.map_from_positions(pos, junk, [len(g_["ok"]) for g_ in gnd], [1, 5])
+    for a, b in zip(want, got):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    ref = O.compute_map(rk, gnd, [1, 5])
+    for a, b in zip(want, ref):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))

@@ -1,0 +1,125 @@
+"""N>1 path on CPU: 2 (and 3) processes over gloo run mdir_amd.sharded.ShardedIndex with the
+compute backend replaced by the oracle (tests may; the product default is the HIP library).
+Checks that shard -> all-to-all -> query-split ranking and the sort-free positions route
+give exactly the single-process oracle result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+class OracleBackend:
+    """Same four calls as mdir_amd.sharded.HipBackend, computed by the CPU oracle."""
+
+    class _Index:
+        def __init__(self, vecs, layout, row_offset):
+            v = vecs.numpy()
+            self.dn = np.ascontiguousarray(v if layout == "DN" else v.T)
+            self.row_offset = row_offset
+
+        def scores(self, queries, qlayout="DN"):
+            from oracle import chain as OC
+            q = queries.numpy()
+            return torch.from_numpy(OC.scores_chain(self.dn, np.ascontiguousarray(q if qlayout == "DN" else q.T)))
+
+    def make_index(self, vecs, layout, row_offset):
+        return self._Index(vecs, layout, row_offset)
+
+    def rank_full(self, scores, id_offset=0):
+        from oracle import chain as OC
+        return torch.from_numpy(OC.rank_full(scores.numpy()) + id_offset)
+
+    def gather_scores(self, scores, ids, offsets):
+        s, off = scores.numpy(), offsets.numpy()
+        out = np.empty(len(ids), dtype=np.float32)
+        for q in range(len(off) - 1):
+            out[off[q]:off[q + 1]] = s[q][ids.numpy()[off[q]:off[q + 1]]]
+        return torch.from_numpy(out)
+
+    def rank_count_(self, cnt, scores, id_offset, ref_scores, ref_ids, offsets):
+        from oracle import chain as OC
+        s, off = scores.numpy(), offsets.numpy()
+        for q in range(len(off) - 1):
+            keys = np.array([OC.desc_key(x) for x in s[q]], dtype=np.uint64)
+            gid = np.arange(s.shape[1]) + id_offset
+            for t in range(off[q], off[q + 1]):
+                rk, ri = OC.desc_key(float(ref_scores[t])), int(ref_ids[t])
+                cnt[t] += int(np.count_nonzero((keys < rk) | ((keys == rk) & (gid < ri))))
+        return cnt
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, nq, d, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mdir_amd.sharded import ShardedIndex, shard_bounds
+    from oracle import oracle as O
+    from test_sharded_gloo import OracleBackend
+    vecs, qvecs, _ = O.synth_ranking_problem(n, nq, d, seed=4)
+    vecs[:, 7] = vecs[:, 3]; vecs[:, n - 1] = vecs[:, 3]       # exact ties across shards
+    lo, hi = shard_bounds(n, world, rank)
+    sh = ShardedIndex(torch.from_numpy(np.ascontiguousarray(vecs[:, lo:hi])), "DN", n, backend=OracleBackend())
+    rk, sc, (qlo, qhi) = sh.rank_queries(torch.from_numpy(qvecs), "DN")
+    gnd = O.synth_gnd(nq, n, seed=1, easy=3, hard=4, junk=2)
+    lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
+    lists[0] = np.array([3, 7, n - 1])
+    pos, off = sh.positions(sh.local_scores(torch.from_numpy(qvecs), "DN"), lists)
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), ranks=rk.numpy(), scores=sc.numpy(), q=np.array([qlo, qhi]),
+             pos=pos.numpy(), off=np.array(off))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,nq", [(2, 301, 7), (3, 100, 2)])
+def test_sharded_equals_single_process(tmp_path, world, n, nq):
+    from oracle import chain as OC
+    from oracle import oracle as O
+    d = 32
+    mp.spawn(_worker, args=(world, _free_port(), n, nq, d, str(tmp_path)), nprocs=world, join=True)
+    vecs, qvecs, _ = O.synth_ranking_problem(n, nq, d, seed=4)
+    vecs[:, 7] = vecs[:, 3]; vecs[:, n - 1] = vecs[:, 3]
+    want_sc = OC.scores_chain(vecs, qvecs)
+    want_rk = OC.rank_full(want_sc)
+    gnd = O.synth_gnd(nq, n, seed=1, easy=3, hard=4, junk=2)
+    lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
+    lists[0] = np.array([3, 7, n - 1])
+    covered = 0
+    for r in range(world):
+        g = np.load(tmp_path / ("r%d.npz" % r))
+        qlo, qhi = g["q"]
+        np.testing.assert_array_equal(g["scores"], want_sc[qlo:qhi])
+        np.testing.assert_array_equal(g["ranks"], want_rk[qlo:qhi])
+        covered += qhi - qlo
+        for q in range(nq):
+            np.testing.assert_array_equal(g["pos"][g["off"][q]:g["off"][q + 1]], OC.rank_of(want_sc[q], lists[q]))
+    assert covered == nq
+
+
+def test_shard_bounds_cover_everything():
+    from mdir_amd.sharded import shard_bounds
+    for n in (1, 7, 70, 1004993):
+        for w in (1, 2, 3, 8):
+            edges = [shard_bounds(n, w, r) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_default_backend_is_hip_and_refuses_cpu():
+    from mdir_amd.sharded import ShardedIndex
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ShardedIndex(torch.zeros(8, 16), "DN", 16)
