@@ -53,7 +53,8 @@ def gen_rows(lo, hi, device):
 def gen_queries(n_total, device):
     """70 queries = 70 distinct database rows + 0.05 N(0,1) noise, re-normalised ([D,Q])."""
     rng = np.random.default_rng(0)
-    qid = np.sort(rng.choice(n_total, size=NQ, replace=False))
+    first = N_ROXFORD if n_total >= N_ROXFORD + NQ else 0      # keep query sources off the labelled rows
+    qid = first + np.sort(rng.choice(n_total - first, size=NQ, replace=False))
     rows = torch.cat([gen_rows(int(i), int(i) + 1, device) for i in qid])
     g = torch.Generator(device=device)
     g.manual_seed(7)
@@ -71,6 +72,22 @@ def synth_gnd(n_labelled):
         ids = rng.choice(n_labelled, size=20, replace=False)
         gnd.append({"easy": np.sort(ids[:5]), "hard": np.sort(ids[5:15]), "junk": np.sort(ids[15:]), "bbx": None})
     return gnd
+
+
+def plant_positives(rows, lo, hi, gnd, qid, device):
+    """Make the labelled rows relevant: row = normalise(source_row(q) + b * N(0,1)) with
+    b = 0.03 (easy; cos to the query ~0.24), 0.1 (hard; ~0.09, inside the top distractors'
+    range so that mAP < 1), 0.02 (junk, near duplicates).  Only rows in [lo,hi) are touched."""
+    for q, g in enumerate(gnd):
+        src = gen_rows(int(qid[q]), int(qid[q]) + 1, device)[0]
+        for key, b in (("easy", 0.03), ("hard", 0.1), ("junk", 0.02)):
+            for i in g[key]:
+                i = int(i)
+                if lo <= i < hi:
+                    gen = torch.Generator(device=device)
+                    gen.manual_seed(50_000_000 + i)
+                    v = src + b * torch.randn(DIM, generator=gen, device=device)
+                    rows[i - lo] = v / v.norm()
 
 
 def cpu_baseline(vecs_dn_host, qvecs_host):
@@ -117,6 +134,8 @@ def main():
     lo, hi = shard_bounds(n_total, world, rank)
     rows = gen_rows(lo, hi, device)                 # [n_local, D]
     qvecs, qid = gen_queries(n_total, device)       # [D, Q]
+    gnd = synth_gnd(min(N_ROXFORD, n_total))
+    plant_positives(rows, lo, hi, gnd, qid, device)
     t0 = time.perf_counter()
     sharded = ShardedIndex(rows, "ND", n_total)
     torch.cuda.synchronize()
@@ -163,7 +182,6 @@ def main():
         elapsed = float(t.item())
 
     # ---- results check + mAP (untimed) --------------------------------------
-    gnd = synth_gnd(min(N_ROXFORD, n_total))
     extra = {}
     if world == 1:
         avg_s, _ = compute_map_and_print_from_scores("roxford5k", sc, gnd)           # counting kernel, no sort

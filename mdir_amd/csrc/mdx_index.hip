@@ -115,55 +115,56 @@ __global__ __launch_bounds__(256) void scores_kernel(const f32x4 *__restrict__ d
 #pragma unroll
         for (int q = 0; q < QT; ++q) acc[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 bcur[R][KBC], bnxt[R][KBC], qreg[COPIES];
+    // Two named register sets for the database stream (ping-pong, statically indexed):
+    // while chunk c is multiplied out of one set, chunk c+1 lands in the other, so the
+    // only wait in steady state is for data requested a whole chunk (~5k cycles) ago.
+    f32x4 bA[R][KBC], bB[R][KBC], qreg[COPIES];
+
+#define MDX_LOAD_B(dst, c)                                                          \
+    _Pragma("unroll") for (int r = 0; r < R; ++r)                                   \
+        _Pragma("unroll") for (int kb = 0; kb < KBC; ++kb)                          \
+            dst[r][kb] = bp[r][((c) * KBC + kb) * 64];
+#define MDX_LOAD_Q(c)                                                               \
+    _Pragma("unroll") for (int i = 0; i < COPIES; ++i)                              \
+        qreg[i] = qtiles[qsrc[i] + (c) * KBC * 64];
+#define MDX_STORE_Q(buf)                                                            \
+    _Pragma("unroll") for (int i = 0; i < COPIES; ++i) lds[buf][tid + i * 256] = qreg[i];
+#define MDX_COMPUTE(buf, bset)                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < KBC; ++kb) {                            \
+        f32x4 a[QT];                                                                \
+        _Pragma("unroll") for (int q = 0; q < QT; ++q)                              \
+            a[q] = lds[buf][(q * KBC + kb) * 64 + lane];                            \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                               \
+            _Pragma("unroll") for (int r = 0; r < R; ++r)                           \
+                _Pragma("unroll") for (int q = 0; q < QT; ++q)                      \
+                    acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(               \
+                        a[q][t], bset[r][kb][t], acc[r][q], 0, 0, 0);               \
+    }
 
     // prologue: chunk 0
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int kb = 0; kb < KBC; ++kb) bcur[r][kb] = bp[r][kb * 64];
-#pragma unroll
-    for (int i = 0; i < COPIES; ++i) qreg[i] = qtiles[qsrc[i]];
-#pragma unroll
-    for (int i = 0; i < COPIES; ++i) lds[0][tid + i * 256] = qreg[i];
+    MDX_LOAD_Q(0);
+    MDX_LOAD_B(bA, 0);
+    MDX_STORE_Q(0);
 
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = (c + 1 < nchunks);
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int kb = 0; kb < KBC; ++kb) bnxt[r][kb] = bp[r][((c + 1) * KBC + kb) * 64];
-#pragma unroll
-            for (int i = 0; i < COPIES; ++i) qreg[i] = qtiles[qsrc[i] + (c + 1) * KBC * 64];
-        }
-        __syncthreads();  // lds[c&1] written (prologue or previous iteration) and visible
-        const f32x4 *lq = lds[c & 1];
-#pragma unroll
-        for (int kb = 0; kb < KBC; ++kb) {
-            f32x4 a[QT];
-#pragma unroll
-            for (int q = 0; q < QT; ++q) a[q] = lq[(q * KBC + kb) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int q = 0; q < QT; ++q)
-                        acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][t], bcur[r][kb][t],
-                                                                         acc[r][q], 0, 0, 0);
-        }
-        if (more) {
-            // lds[(c+1)&1] was last read in iteration c-1; every wave is past this
-            // iteration's barrier, hence done with it.
-#pragma unroll
-            for (int i = 0; i < COPIES; ++i) lds[(c + 1) & 1][tid + i * 256] = qreg[i];
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int kb = 0; kb < KBC; ++kb) bcur[r][kb] = bnxt[r][kb];
-        }
+    // One barrier per chunk.  lds[x] is rewritten (MDX_STORE_Q) only after the barrier
+    // of the half that follows its last read, so every wave is done reading it.
+    for (int c = 0; c < nchunks; c += 2) {
+        const bool more1 = c + 1 < nchunks;
+        if (more1) { MDX_LOAD_Q(c + 1); MDX_LOAD_B(bB, c + 1); }
+        __syncthreads();
+        MDX_COMPUTE(0, bA);
+        if (!more1) break;
+        MDX_STORE_Q(1);
+        const bool more2 = c + 2 < nchunks;
+        if (more2) { MDX_LOAD_Q(c + 2); MDX_LOAD_B(bA, c + 2); }
+        __syncthreads();
+        MDX_COMPUTE(1, bB);
+        if (more2) MDX_STORE_Q(0);
     }
+#undef MDX_LOAD_B
+#undef MDX_LOAD_Q
+#undef MDX_STORE_Q
+#undef MDX_COMPUTE
 
     // C/D map of 16x16x4: reg i of lane l is (M = 4*(l>>4)+i, N = l&15)
     const int qrow = 4 * (lane >> 4);

@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ b
 
 // stable scatter of one tile.  Element order inside a query = (tile, wave, round,
 // lane); each wave ranks its 64 elements of a round with ballots (lanes with the
-// same digit, lower lane first) and keeps a running per-digit count in LDS.
+// same digit, lower lane first) and keeps a running per-digit count in LDS.  The
+// tile is then put in digit order in LDS, so that consecutive lanes write
+// consecutive global addresses inside each digit run (coalesced scatter).
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(256) void sort_scatter_kernel(
     const float *__restrict__ scores, const uint32_t *__restrict__ keys_in,
@@ -96,7 +98,11 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(
     int64_t n, int nblk, int shift, const uint32_t *__restrict__ block_hist,
     const uint32_t *__restrict__ digit_base, int64_t id_offset, int64_t klimit)
 {
-    __shared__ uint32_t wcnt[4][RADIX];
+    __shared__ uint32_t wcnt[4][RADIX];     // per-wave digit counts, then tile-local offsets
+    __shared__ uint32_t gdelta[RADIX];      // global position of a digit run minus its tile offset
+    __shared__ uint32_t scan[RADIX];
+    __shared__ uint32_t skey[SORT_TILE];
+    __shared__ uint32_t sval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.y, b = blockIdx.x;
 #pragma unroll
@@ -104,7 +110,9 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(
     __syncthreads();
 
     const int64_t base = q * n;
-    const int64_t sub0 = b * SORT_TILE + wave * SUB_TILE;
+    const int64_t tile0 = b * SORT_TILE;
+    const int64_t sub0 = tile0 + wave * SUB_TILE;
+    const int tile_n = (int)((n - tile0) < SORT_TILE ? (n - tile0) : SORT_TILE);
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS], pos[SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -134,30 +142,48 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(
         pos[r] = old + rank;
     }
     __syncthreads();
-    {   // thread = digit: global base + prefix over the 4 waves, written back over wcnt
-        uint32_t run = digit_base[q * RADIX + tid] + block_hist[(q * nblk + b) * RADIX + tid];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t c = wcnt[w][tid];
-            wcnt[w][tid] = run;
-            run += c;
-        }
+    // thread = digit: tile count, exclusive scan over digits, per-wave tile offsets
+    const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    scan[tid] = tot;
+    __syncthreads();
+    for (int off = 1; off < RADIX; off <<= 1) {
+        const uint32_t v = tid >= off ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
     }
+    const uint32_t toff = scan[tid] - tot;                 // first slot of this digit in the tile
+    wcnt[0][tid] = toff;
+    wcnt[1][tid] = toff + c0;
+    wcnt[2][tid] = toff + c0 + c1;
+    wcnt[3][tid] = toff + c0 + c1 + c2;
+    gdelta[tid] = digit_base[q * RADIX + tid] + block_hist[(q * nblk + b) * RADIX + tid] - toff;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const bool valid = (sub0 + r * 64 + lane) < n;
         if (!valid) continue;
         const uint32_t d = (key[r] >> shift) & 255u;
-        const int64_t dst = (int64_t)wcnt[wave][d] + pos[r];
+        const uint32_t lp = wcnt[wave][d] + pos[r];
+        skey[lp] = key[r];
+        sval[lp] = val[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int i = r * 256 + tid;
+        if (i >= tile_n) continue;
+        const uint32_t k = skey[i], v = sval[i];
+        const int64_t dst = (int64_t)(uint32_t)(gdelta[(k >> shift) & 255u] + (uint32_t)i);
         if (LAST) {
             if (dst < klimit) {
-                if (ranks) ranks[q * klimit + dst] = (int64_t)val[r] + id_offset;
-                if (top_scores) top_scores[q * klimit + dst] = scores[base + val[r]];
+                if (ranks) ranks[q * klimit + dst] = (int64_t)v + id_offset;
+                if (top_scores) top_scores[q * klimit + dst] = scores[base + v];
             }
         } else {
-            keys_out[base + dst] = key[r];
-            vals_out[base + dst] = val[r];
+            keys_out[base + dst] = k;
+            vals_out[base + dst] = v;
         }
     }
 }
