@@ -14,6 +14,7 @@
 #include <stdarg.h>
 
 #include "mdx_common.h"
+#include "mdx_scores_kernel.h"
 
 namespace mdx {
 
@@ -26,14 +27,6 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
 }
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int TILE_ROWS = 16;   // rows per tile  (MFMA N / M)
-constexpr int TILE_K = 16;      // k per tile     (4 MFMA k-steps of 4)
-constexpr int KBC = 4;          // k-blocks per LDS chunk  (64 k)
-constexpr int WAVES = 4;        // waves per workgroup
-constexpr int MAX_QT = 8;       // query tiles (of 16) per launch
 
 // ---------------------------------------------------------------------------
 // re-tiling: any strided [rows, k] fp32 matrix -> fragment-order tiles
@@ -71,140 +64,29 @@ __global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ s
     tiles[(rt * KB + kb) * 64 + lane] = v;
 }
 
-// ---------------------------------------------------------------------------
-// similarity: one workgroup = 4 waves, each wave owns R row tiles (16*R database
-// rows) and ALL QT query tiles; the dimension is walked in chunks of 64.
-//   - database: streamed once from HBM, register double-buffered one chunk ahead
-//   - queries : chunk staged through LDS (double-buffered, one barrier per chunk),
-//               read back as ds_read_b128 = 4 A operands
-//   - fp32 MFMA 16x16x4: A = queries (M), B = database rows (N)
-// ---------------------------------------------------------------------------
-template <int QT, int R>
-__global__ __launch_bounds__(256) void scores_kernel(const f32x4 *__restrict__ db,
-                                                     const f32x4 *__restrict__ qtiles,
-                                                     float *__restrict__ out, int64_t n, int KB,
-                                                     int nq_valid)
-{
-    constexpr int CHUNK4 = QT * KBC * 64;          // float4 per LDS buffer
-    constexpr int COPIES = QT * KBC / WAVES;       // float4 per thread per chunk
-    __shared__ f32x4 lds[2][CHUNK4];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int64_t rt0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
-    const int nchunks = KB / KBC;
-
-    const f32x4 *bp[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) bp[r] = db + ((rt0 + r) * KB) * 64 + lane;
-
-    // per-thread source offsets of the query-chunk copy (chunk 0), in float4
-    int qsrc[COPIES];
-#pragma unroll
-    for (int i = 0; i < COPIES; ++i) {
-        const int e = tid + i * 256;
-        const int tl = e >> 6, ln = e & 63;
-        const int qt = tl / KBC, kbc = tl % KBC;
-        qsrc[i] = (qt * KB + kbc) * 64 + ln;
-    }
-
-    f32x4 acc[R][QT];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int q = 0; q < QT; ++q) acc[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // Two named register sets for the database stream (ping-pong, statically indexed):
-    // while chunk c is multiplied out of one set, chunk c+1 lands in the other, so the
-    // only wait in steady state is for data requested a whole chunk (~5k cycles) ago.
-    f32x4 bA[R][KBC], bB[R][KBC], qreg[COPIES];
-
-#define MDX_LOAD_B(dst, c)                                                          \
-    _Pragma("unroll") for (int r = 0; r < R; ++r)                                   \
-        _Pragma("unroll") for (int kb = 0; kb < KBC; ++kb)                          \
-            dst[r][kb] = bp[r][((c) * KBC + kb) * 64];
-#define MDX_LOAD_Q(c)                                                               \
-    _Pragma("unroll") for (int i = 0; i < COPIES; ++i)                              \
-        qreg[i] = qtiles[qsrc[i] + (c) * KBC * 64];
-#define MDX_STORE_Q(buf)                                                            \
-    _Pragma("unroll") for (int i = 0; i < COPIES; ++i) lds[buf][tid + i * 256] = qreg[i];
-#define MDX_COMPUTE(buf, bset)                                                      \
-    _Pragma("unroll") for (int kb = 0; kb < KBC; ++kb) {                            \
-        f32x4 a[QT];                                                                \
-        _Pragma("unroll") for (int q = 0; q < QT; ++q)                              \
-            a[q] = lds[buf][(q * KBC + kb) * 64 + lane];                            \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                               \
-            _Pragma("unroll") for (int r = 0; r < R; ++r)                           \
-                _Pragma("unroll") for (int q = 0; q < QT; ++q)                      \
-                    acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(               \
-                        a[q][t], bset[r][kb][t], acc[r][q], 0, 0, 0);               \
-    }
-
-    // prologue: chunk 0
-    MDX_LOAD_Q(0);
-    MDX_LOAD_B(bA, 0);
-    MDX_STORE_Q(0);
-
-    // One barrier per chunk.  lds[x] is rewritten (MDX_STORE_Q) only after the barrier
-    // of the half that follows its last read, so every wave is done reading it.
-    for (int c = 0; c < nchunks; c += 2) {
-        const bool more1 = c + 1 < nchunks;
-        if (more1) { MDX_LOAD_Q(c + 1); MDX_LOAD_B(bB, c + 1); }
-        __syncthreads();
-        MDX_COMPUTE(0, bA);
-        if (!more1) break;
-        MDX_STORE_Q(1);
-        const bool more2 = c + 2 < nchunks;
-        if (more2) { MDX_LOAD_Q(c + 2); MDX_LOAD_B(bA, c + 2); }
-        __syncthreads();
-        MDX_COMPUTE(1, bB);
-        if (more2) MDX_STORE_Q(0);
-    }
-#undef MDX_LOAD_B
-#undef MDX_LOAD_Q
-#undef MDX_STORE_Q
-#undef MDX_COMPUTE
-
-    // C/D map of 16x16x4: reg i of lane l is (M = 4*(l>>4)+i, N = l&15)
-    const int qrow = 4 * (lane >> 4);
-    const int64_t col = lane & 15;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t row = (rt0 + r) * TILE_ROWS + col;
-        if (row >= n) continue;
-#pragma unroll
-        for (int q = 0; q < QT; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int qi = q * 16 + qrow + i;
-                if (qi < nq_valid) out[(int64_t)qi * n + row] = acc[r][q][i];
-            }
-    }
-}
-
-template <int QT, int R>
+// NW waves per workgroup, one row tile per wave.
+template <int QT, int NW>
 static void launch_scores(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
                           int KB, int nq_valid, hipStream_t s)
 {
-    const int64_t blocks = ceil_div(RT, (int64_t)WAVES * R);
-    hipLaunchKernelGGL((scores_kernel<QT, R>), dim3((unsigned)blocks), dim3(256), 0, s, db, qt, out,
-                       n, KB, nq_valid);
+    const int64_t blocks = ceil_div(RT, (int64_t)NW);
+    hipLaunchKernelGGL((scores_kernel<QT, 1, 0, false, true, 3, 2, false, NW>), dim3((unsigned)blocks),
+                       dim3(NW * 64), 0, s, db, qt, out, n, KB, nq_valid, (int64_t)0);
 }
 
-template <int R>
+template <int NW>
 static void dispatch_qt(int qt, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
                         int KB, int nq_valid, hipStream_t s)
 {
     switch (qt) {
-        case 1: launch_scores<1, R>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 2: launch_scores<2, R>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 3: launch_scores<3, R>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 4: launch_scores<4, R>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 5: launch_scores<5, R>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 6: launch_scores<6, R>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 7: launch_scores<7, R>(db, q, out, n, RT, KB, nq_valid, s); break;
-        default: launch_scores<8, R>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 1: launch_scores<1, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 2: launch_scores<2, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 3: launch_scores<3, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 4: launch_scores<4, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 5: launch_scores<5, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 6: launch_scores<6, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 7: launch_scores<7, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
+        default: launch_scores<8, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
     }
 }
 
@@ -250,7 +132,7 @@ int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, in
     ix->d_pad = round_up(d, TILE_K * KBC);
     ix->KB = ix->d_pad / TILE_K;
     ix->RT = ceil_div(n, TILE_ROWS);
-    ix->RT_pad = round_up(ix->RT, WAVES * 2);  // every wave of every workgroup has tiles to read
+    ix->RT_pad = round_up(ix->RT, 8);  // every wave of every workgroup has a tile to read
     ix->row_offset = row_offset;
     ix->bytes = ix->RT_pad * ix->KB * 1024;
     hipError_t e = hipMalloc((void **)&ix->tiles, (size_t)ix->bytes);
@@ -321,16 +203,16 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
     int rc = retile(queries, nq, ix->d, qlayout, center, qtiles, QT_total, ix->KB, s);
     if (rc != MDX_OK) return rc;
 
-    // Small shards: one row tile per wave so that more CUs get work.
-    const bool small = ix->RT < 256 * WAVES * 2 * 2;
+    // Small shards: 4-wave workgroups so that more CUs get work.
+    const bool small = ix->RT < 256 * 8 * 2;
     for (int64_t qt0 = 0; qt0 < QT_total; qt0 += MAX_QT) {
         const int qt = (int)((QT_total - qt0) < MAX_QT ? (QT_total - qt0) : MAX_QT);
         const int64_t q0 = qt0 * TILE_ROWS;
         const int nq_valid = (int)((nq - q0) < qt * TILE_ROWS ? (nq - q0) : qt * TILE_ROWS);
         const f32x4 *qp = qtiles + qt0 * ix->KB * 64;
         float *op = scores + q0 * ix->n;
-        if (small) dispatch_qt<1>(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
-        else       dispatch_qt<2>(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        if (small) dispatch_qt<4>(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        else       dispatch_qt<8>(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
         MDX_LAUNCH_CHECK();
     }
     return MDX_OK;
