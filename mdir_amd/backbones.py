@@ -1,0 +1,123 @@
+"""Convolutional feature stacks declared with torch only (no torchvision, no downloads).
+
+``init_network`` of the reference takes ``torchvision.models.<arch>`` and keeps the
+convolutional children (``cirtorch/networks/imageretrievalnet.py:155-181``).  The
+module trees below reproduce torchvision's child order and parameter names, so a
+reference ``state_dict`` (``features.0.weight``, ``features.4.0.conv1.weight`` ...)
+loads unchanged.  The convolutions themselves stay on PyTorch-ROCm / MIOpen: the
+backbone is not part of the hand-written hot path (BASELINE.json north_star).
+"""
+import torch.nn as nn
+
+
+def _conv3x3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv3x3(cin, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv3x3(planes, planes, stride)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+_RESNET = {"resnet18": (BasicBlock, (2, 2, 2, 2)), "resnet34": (BasicBlock, (3, 4, 6, 3)),
+           "resnet50": (Bottleneck, (3, 4, 6, 3)), "resnet101": (Bottleneck, (3, 4, 23, 3)),
+           "resnet152": (Bottleneck, (3, 8, 36, 3))}
+
+
+def _resnet_features(arch):
+    block, layers = _RESNET[arch]
+    state = {"cin": 64}
+
+    def make_layer(planes, blocks, stride):
+        down = None
+        if stride != 1 or state["cin"] != planes * block.expansion:
+            down = nn.Sequential(nn.Conv2d(state["cin"], planes * block.expansion, 1, stride, bias=False),
+                                 nn.BatchNorm2d(planes * block.expansion))
+        mods = [block(state["cin"], planes, stride, down)]
+        state["cin"] = planes * block.expansion
+        mods += [block(state["cin"], planes) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    # children of torchvision's ResNet minus (avgpool, fc): imageretrievalnet.py:172-173
+    return [nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, 2, 1), make_layer(64, layers[0], 1), make_layer(128, layers[1], 2),
+            make_layer(256, layers[2], 2), make_layer(512, layers[3], 2)]
+
+
+_VGG = {"vgg11": [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"],
+        "vgg13": [64, 64, "M", 128, 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"],
+        "vgg16": [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
+        "vgg19": [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M",
+                  512, 512, 512, 512, "M"]}
+
+
+def _vgg_features(arch):
+    mods, cin = [], 3
+    for v in _VGG[arch]:
+        if v == "M":
+            mods.append(nn.MaxPool2d(2, 2))
+        else:
+            mods += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return mods[:-1]   # the last max-pool is dropped: imageretrievalnet.py:170-171
+
+
+def _alexnet_features():
+    mods = [nn.Conv2d(3, 64, 11, 4, 2), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2),
+            nn.Conv2d(64, 192, 5, padding=2), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2),
+            nn.Conv2d(192, 384, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(384, 256, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(256, 256, 3, padding=1), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2)]
+    return mods[:-1]   # imageretrievalnet.py:168-169
+
+
+# imageretrievalnet.py:58-75 (densenet / squeezenet are not re-declared here)
+OUTPUT_DIM = {"alexnet": 256, "vgg11": 512, "vgg13": 512, "vgg16": 512, "vgg19": 512, "resnet18": 512,
+              "resnet34": 512, "resnet50": 2048, "resnet101": 2048, "resnet152": 2048}
+
+
+def build_features(architecture):
+    """List of feature modules for ``architecture`` (randomly initialised)."""
+    if architecture == "alexnet":
+        return _alexnet_features()
+    if architecture in _VGG:
+        return _vgg_features(architecture)
+    if architecture in _RESNET:
+        return _resnet_features(architecture)
+    raise ValueError("Unsupported or unknown architecture: {}!".format(architecture))

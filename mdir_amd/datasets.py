@@ -1,0 +1,176 @@
+"""Image lists, test-set configuration and the ``pil2np | totensor | normalize`` chain.
+
+CPU-side loader of the hot path; mirrors
+``cirtorch/datasets/genericdataset.py:10-81`` (ImagesFromList),
+``datahelpers.py:24-50`` (pil_loader, imresize), ``testdataset.py:4-38``
+(configdataset), ``utils/general.py:4-11`` (get_data_root) and mdir's transform DSL
+(``mdir/components/data/transform/__init__.py:35-44``, ``core_transforms.py:33-63``).
+Only the transforms eval.py uses are provided; CLAHE & co. are CPU/OpenCV
+preprocessing upstream of the tensor this path consumes.
+"""
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+import torch.utils.data as data
+from PIL import Image, ImageFile
+
+ImageFile.LOAD_TRUNCATED_IMAGES = True   # datahelpers.py:7
+
+DATASETS = ["oxford5k", "paris6k", "roxford5k", "rparis6k", "247tokyo1k"]
+
+
+def get_root():
+    if os.environ.get("CIRTORCH_ROOT", ""):
+        return os.environ["CIRTORCH_ROOT"]
+    return os.path.abspath(os.path.join(os.path.dirname(os.path.realpath(__file__)), ".."))
+
+
+def get_data_root():
+    return os.path.join(get_root(), "data")
+
+
+def pil_loader(path):
+    """RGB PIL image, or the OSError instance if it cannot be opened (reference contract)."""
+    try:
+        with open(path, "rb") as f:
+            return Image.open(f).convert("RGB")
+    except OSError as e:
+        return e
+
+
+default_loader = pil_loader
+
+
+def imresize(img, imsize):
+    """Aspect-preserving DOWN-scale so that the longer side is <= imsize
+    (``thumbnail`` + ANTIALIAS, which Pillow >= 10 calls LANCZOS)."""
+    img.thumbnail((imsize, imsize), Image.LANCZOS)
+    return img
+
+
+class ImagesFromList(data.Dataset):
+    def __init__(self, root, images, imsize=None, bbxs=None, transform=None, loader=default_loader,
+                 ignore_errors=False):
+        images_fn = [os.path.join(root, images[i]) for i in range(len(images))]
+        if len(images_fn) == 0:
+            raise RuntimeError("Dataset contains 0 images!")
+        self.root, self.images, self.imsize, self.images_fn = root, images, imsize, images_fn
+        self.bbxs, self.transform, self.loader, self.ignore_errors = bbxs, transform, loader, ignore_errors
+
+    def __getitem__(self, index):
+        path = self.images_fn[index]
+        img = self.loader(path)
+        if isinstance(img, Exception):
+            sys.stderr.write("Warning: Image '%s' was not found\n" % path)
+            if self.ignore_errors:
+                return {}
+            raise img
+        if self.bbxs and self.bbxs[index]:
+            img = img.crop(self.bbxs[index])
+        if self.imsize is not None:
+            img = imresize(img, self.imsize)
+        if self.transform is not None:
+            img = self.transform(img)
+        return img
+
+    def __len__(self):
+        return len(self.images_fn)
+
+
+def config_imname(cfg, i):
+    return os.path.join(cfg["dir_images"], cfg["imlist"][i] + cfg["ext"])
+
+
+def config_qimname(cfg, i):
+    return os.path.join(cfg["dir_images"], cfg["qimlist"][i] + cfg["qext"])
+
+
+def configdataset(dataset, dir_main):
+    dataset = dataset.lower()
+    if dataset not in DATASETS:
+        raise ValueError("Unknown dataset: {}!".format(dataset))
+    gnd_fname = os.path.join(dir_main, dataset, "gnd_{}.pkl".format(dataset))
+    with open(gnd_fname, "rb") as f:
+        cfg = pickle.load(f)
+    cfg["gnd_fname"] = gnd_fname
+    cfg["ext"] = cfg["qext"] = ".jpg"
+    cfg["dir_data"] = os.path.join(dir_main, dataset)
+    cfg["dir_images"] = os.path.join(cfg["dir_data"], "jpg")
+    cfg["n"], cfg["nq"] = len(cfg["imlist"]), len(cfg["qimlist"])
+    cfg["im_fname"], cfg["qim_fname"] = config_imname, config_qimname
+    cfg["dataset"] = dataset
+    return cfg
+
+
+# ------------------------------------------------------------------ transforms
+
+class Pil2Numpy:
+    """PIL -> float32 HWC array in [0,1] (core_transforms.py:56-60)."""
+
+    def __call__(self, *pics):
+        return [np.array(x.convert("RGB"), dtype=np.float32) / 255.0 for x in pics]
+
+
+class ToTensor:
+    """HWC array (or PIL) -> CHW float tensor; uint8 inputs are scaled by 1/255 like
+    torchvision's ToTensor (core_transforms.py:33-36)."""
+
+    def __call__(self, *pics):
+        out = []
+        for x in pics:
+            if isinstance(x, Image.Image):
+                x = np.array(x)
+            t = torch.from_numpy(np.ascontiguousarray(x if x.ndim == 3 else x[:, :, None]).transpose(2, 0, 1))
+            out.append(t.float().div(255) if t.dtype == torch.uint8 else t.float())
+        return out
+
+
+class Normalize:
+    def __init__(self, mean, std, strict_shape=True):
+        if isinstance(strict_shape, str):
+            strict_shape = strict_shape.lower() != "false"
+        assert len(mean) == len(std)
+        self.mean, self.std, self.strict_shape = list(mean), list(std), bool(strict_shape)
+
+    def __call__(self, *pics):
+        out = []
+        for pic in pics:
+            c = pic.size(0)
+            if self.strict_shape:
+                assert c == len(self.mean), (c, len(self.mean))
+            else:
+                assert c <= len(self.mean), (c, len(self.mean))
+            mean = torch.tensor(self.mean[:c], dtype=pic.dtype).view(-1, 1, 1)
+            std = torch.tensor(self.std[:c], dtype=pic.dtype).view(-1, 1, 1)
+            out.append((pic - mean) / std)
+        return out
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, *pics):
+        for t in self.transforms:
+            pics = t(*pics)
+        return pics[0] if len(pics) == 1 else pics
+
+
+TRANSFORMS = {"totensor": ToTensor, "normalize": Normalize, "pil2np": Pil2Numpy}
+
+
+def initialize_transforms(augmentations, mean_std):
+    """Parse ``"a | b:arg:arg"``; ``normalize`` receives ``mean_std`` first
+    (transform/__init__.py:35-44)."""
+    trans = []
+    for aug in [x.strip() for x in augmentations.split("|") if x.strip()]:
+        tname, *args = aug.split(":", 1)
+        args = args[0].split(":") if args else []
+        if tname not in TRANSFORMS:
+            raise KeyError("transform '%s' is outside the MI355X hot path (only %s are provided)"
+                           % (tname, sorted(TRANSFORMS)))
+        trans.append(TRANSFORMS[tname](*(list(mean_std) + args)) if "normalize" in aug else TRANSFORMS[tname](*args))
+    return Compose(trans)

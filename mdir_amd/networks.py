@@ -1,0 +1,196 @@
+"""Image-retrieval network and descriptor extraction -- the cirtorch operator API.
+
+Drop-in for ``mdir/external/cirtorch/networks/imageretrievalnet.py``:
+``ImageRetrievalNet`` (:82-115), ``init_network`` (:138-274), ``extract_vectors`` /
+``extract_ss`` / ``extract_ms`` (:277-324).  The convolutional ``features`` run on
+PyTorch-ROCm; everything after them (pool -> L2N -> whitening -> L2N, multi-scale
+aggregation) runs in the HIP library.  Differences from the reference, all
+MI355X-motivated and result-preserving:
+
+* descriptors are written into ONE device-resident ``[N,D]`` buffer and copied to the
+  host once, instead of a blocking ``.cpu()`` per image (imageretrievalnet.py:307);
+* the in-network whitening ``nn.Linear`` is applied as a resident ``mdx_index`` of its
+  weight (re-tiled once), not a per-image mat-vec through torch;
+* nothing is ever downloaded: ``pretrained`` only loads files that already exist
+  under ``model_dir`` / ``$CIRTORCH_ROOT/data``.
+"""
+import os
+import pickle
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .backbones import OUTPUT_DIM, build_features
+from .datasets import ImagesFromList, get_data_root
+from .layers import POOLING, L2N, pool_kind
+
+
+class ImageRetrievalNet(nn.Module):
+    def __init__(self, features, lwhiten, pool, whiten, meta):
+        super().__init__()
+        self.features = nn.Sequential(*features)
+        self.lwhiten = lwhiten
+        self.pool = pool
+        self.whiten = whiten
+        self.norm = L2N()
+        self.meta = meta
+        self._whiten_index = (None, None)
+
+    def _whiten_shard(self):
+        """Resident, re-tiled copy of ``whiten.weight`` ([D_out, D_in] row-major = D_out
+        "database rows"); rebuilt only when the parameter changes."""
+        w = self.whiten.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if self._whiten_index[0] != key:
+            self._whiten_index = (key, ops.DescriptorIndex(w.detach().contiguous(), "ND"))
+        return self._whiten_index[1]
+
+    def forward(self, x):
+        o = self.features(x)
+        if self.lwhiten is not None:   # local whitening: plain torch, not on the eval.py path
+            s = o.size()
+            o = o.permute(0, 2, 3, 1).contiguous().view(-1, s[1])
+            o = self.lwhiten(o)
+            o = o.view(s[0], s[2], s[3], self.lwhiten.out_features).permute(0, 3, 1, 2)
+        kind = pool_kind(self.pool)
+        if kind is not None:           # fused pool + L2N: mdx_pool_l2n
+            o = ops.pool_l2n(o.contiguous(), kind[0], kind[1], kind[2], l2n_eps=self.norm.eps)
+        else:
+            o = self.norm(self.pool(o)).squeeze(-1).squeeze(-1)
+        if self.whiten is not None:    # W o + b, then L2N: mdx_scores on the weight shard + mdx_l2n_rows
+            y = self._whiten_shard().scores(o.contiguous(), "ND")
+            bias = self.whiten.bias.detach() if self.whiten.bias is not None else None
+            o = ops.l2n_rows_(y, bias=bias, eps=self.norm.eps)
+        return o.permute(1, 0)
+
+    def meta_repr(self):
+        lines = ["  (meta): dict( "]
+        for key in ("architecture", "local_whitening", "pooling", "regional", "whitening"):
+            lines.append("     {}: {}".format(key, self.meta[key]))
+        lines.append("     outputdim: {}".format(self.meta.get("out_channels", self.meta.get("outputdim"))))
+        if "mean" in self.meta and "std" in self.meta:
+            lines += ["     mean: {}".format(self.meta["mean"]), "     std: {}".format(self.meta["std"])]
+        return "\n".join(lines) + "\n  )\n"
+
+    def __repr__(self):
+        return super().__repr__()[:-1] + self.meta_repr() + ")"
+
+
+def _local_file(url_or_path, directory):
+    """A file that is already on disk for a reference URL / path, else None."""
+    if not url_or_path:
+        return None
+    if os.path.exists(url_or_path):
+        return url_or_path
+    cand = os.path.join(directory, os.path.basename(url_or_path))
+    return cand if os.path.exists(cand) else None
+
+
+def init_network(params):
+    """Build an ``ImageRetrievalNet`` from the reference's parameter dict
+    (architecture, local_whitening, pooling, regional, whitening, mean, std,
+    pretrained, model_dir).  Regional pooling is out of scope."""
+    architecture = params.get("architecture", "resnet101")
+    local_whitening = params.get("local_whitening", False)
+    pooling = params.get("pooling", "gem")
+    regional = params.get("regional", False)
+    whitening = params.get("whitening", False)
+    mean = params.get("mean", [0.485, 0.456, 0.406])
+    std = params.get("std", [0.229, 0.224, 0.225])
+    pretrained = params.get("pretrained", True)
+    model_dir = params.get("model_dir", None)
+
+    if architecture not in OUTPUT_DIM:
+        raise ValueError("Unsupported or unknown architecture: {}!".format(architecture))
+    if regional:
+        raise NotImplementedError("regional pooling (Rpool) is outside the MI355X hot path")
+    if pooling not in POOLING:
+        raise KeyError("pooling '%s' is outside the MI355X hot path (%s)" % (pooling, sorted(POOLING)))
+    dim = OUTPUT_DIM[architecture]
+    features = build_features(architecture)
+    lwhiten = nn.Linear(dim, dim, bias=True) if local_whitening else None
+    pool = POOLING[pooling]()
+
+    whiten = None
+    if whitening:
+        whiten = nn.Linear(dim, dim, bias=True)
+        if isinstance(whitening, str):   # pickled {'P','m'}: W = P, b = -P m  (imageretrievalnet.py:229-233)
+            with open(whitening, "rb") as handle:
+                w = pickle.load(handle)
+            P = torch.tensor(w["P"], dtype=torch.float32)
+            m = torch.tensor(w["m"], dtype=torch.float32)
+            whiten.load_state_dict({"weight": P, "bias": -torch.mm(P, m).squeeze()})
+
+    meta = {"architecture": architecture, "local_whitening": local_whitening, "pooling": pooling,
+            "regional": regional, "whitening": whitening, "mean": mean, "std": std, "outputdim": dim}
+    net = ImageRetrievalNet(features, lwhiten, pool, whiten, meta)
+
+    if pretrained:
+        found = _local_file(params.get("features_file"), model_dir or os.path.join(get_data_root(), "networks"))
+        if found:
+            net.features.load_state_dict(torch.load(found, map_location="cpu"))
+            print(">> {}: features loaded from '{}'".format(os.path.basename(__file__), found))
+        else:
+            print(">> {}: '{}' built with random weights (no downloads on this path; "
+                  "load a checkpoint's state_dict to fill them)".format(os.path.basename(__file__), architecture))
+    return net
+
+
+def _out_dim(net):
+    return net.meta["out_channels"] if "out_channels" in net.meta else net.meta["outputdim"]
+
+
+def extract_ss(net, input):
+    """One image, one scale -> device vector ``[D]`` (no host copy)."""
+    return net(input).reshape(-1)
+
+
+def extract_ms(net, input, ms, msp):
+    """One image, several scales -> device vector ``[D]`` (imageretrievalnet.py:309-324)."""
+    per_scale = []
+    for s in ms:
+        if s == 1:
+            input_t = input
+        else:
+            input_t = F.interpolate(input, scale_factor=s, mode="bilinear", align_corners=False)
+        per_scale.append(net(input_t).reshape(-1).contiguous())
+    return ops.ms_aggregate(per_scale, msp)
+
+
+def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1], msp=1, print_freq=10,
+                           device=None, num_workers=None):
+    """Like :func:`extract_vectors` but the result stays on the GPU as ``[N,D]``
+    (one descriptor per row), ready to become an index shard."""
+    if not device:
+        net.cuda()
+        device = torch.device("cuda")
+    net.eval()
+    if num_workers is None:
+        num_workers = int(os.environ.get("MDIR_AMD_WORKERS", "6"))
+    loader = torch.utils.data.DataLoader(
+        ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),
+        batch_size=1, shuffle=False, num_workers=num_workers, pin_memory=True)
+    with torch.no_grad():
+        vecs = None
+        for i, input in enumerate(loader):
+            input = input.to(device, non_blocking=True)
+            v = extract_ss(net, input) if len(ms) == 1 else extract_ms(net, input, ms, msp)
+            if vecs is None:
+                # width from the first descriptor: a dimension-reducing whitening wrapper
+                # (cirwhiten dimensions=d) yields d < meta['out_channels'], which the
+                # reference's fixed-size buffer (imageretrievalnet.py:291) cannot hold
+                vecs = torch.empty(len(images), v.numel(), dtype=torch.float32, device=device)
+            vecs[i].copy_(v.reshape(-1), non_blocking=True)
+            if (i + 1) % print_freq == 0 or (i + 1) == len(images):
+                print("\r>>>> {}/{} done...".format(i + 1, len(images)), end="")
+        print("")
+    return vecs
+
+
+def extract_vectors(net, images, image_size, transform, bbxs=None, ms=[1], msp=1, print_freq=10, device=None):
+    """Descriptors of a list of images as a CPU ``torch.float32 [D,N]`` tensor -- the
+    reference's signature and return layout (imageretrievalnet.py:277-304)."""
+    vecs = extract_vectors_device(net, images, image_size, transform, bbxs, ms, msp, print_freq, device)
+    return vecs.t().contiguous().cpu()

@@ -1,0 +1,102 @@
+"""The retrieval score of the eval scenarios -- the orchestrator of the hot path.
+
+Drop-in for ``mdir/components/optim/score/cirscore.py`` (``CirDatasetAp`` :16-80) and
+the ``SCORES`` registry (``score/__init__.py:3-8``): same parameters, same logger
+rows, same printed lines.  What changed underneath (cirscore.py:54-71):
+
+    extract_vectors(...)            -> descriptors stay on the GPU as [N,D]
+    np.dot(vecs.T, qvecs)           -> DescriptorIndex(vecs).scores(qvecs)   (mdx_scores)
+    np.argsort(-scores, axis=0)     -> rank_full(scores)                     (mdx_rank_full)
+    compute_map_and_print(ranks)    -> same function on the device ranking
+
+``ranking="positions"`` skips the full ranking and feeds compute_map from
+``mdx_rank_of`` (identical APs, no N-long sort); the default keeps the reference's
+dot + argsort + compute_map sequence.
+"""
+import os.path
+
+from . import ops
+from .datasets import configdataset, get_data_root, initialize_transforms
+from .evaluate import compute_map_and_print, compute_map_and_print_from_scores
+from .networks import extract_vectors_device
+from .scenario import StopWatch, path_join
+
+
+def _read_table(path, keys):
+    """TSV/CSV with a header row; list-valued cells are JSON (daan file_readers.py:100-130)."""
+    import csv
+    import json
+    with open(path, newline="") as handle:
+        rows = list(csv.DictReader(handle, delimiter="\t" if path.endswith(".tsv") else ","))
+    out = {k: [] for k in keys}
+    for row in rows:
+        for k in keys:
+            cell = row[k]
+            out[k].append(json.loads(cell) if cell[:1] in "[{" else cell)
+    return out
+
+
+class CirDatasetAp:
+    def __init__(self, params):
+        self.image_size = params.pop("image_size")
+        self.dataset = params.pop("dataset")
+        self.transforms = initialize_transforms(params.pop("transforms"), params.pop("mean_std"))
+        self.ranking = params.pop("ranking", "full")
+        assert self.ranking in {"full", "positions"}, self.ranking
+        if isinstance(self.dataset, dict):
+            assert self.dataset.keys() == {"name", "queries", "db", "imgdir"}
+            imgdir = self.dataset["imgdir"]
+            data = _read_table(self.dataset["db"], ["identifier"])
+            self.images = [path_join(imgdir, x) for x in data["identifier"]]
+            mapping = {x: i for i, x in enumerate(data["identifier"])}
+            data = _read_table(self.dataset["queries"], ["query", "bbx", "ok", "junk"])
+            self.qimages = [path_join(imgdir, x) for x in data["query"]]
+            self.bbxs = [tuple(x) if x else None for x in data["bbx"]]
+            self.gnd = [{"ok": [mapping[x] for x in ok], "junk": [mapping[x] for x in junk]}
+                        for ok, junk in zip(data["ok"], data["junk"])]
+            self.dataset = self.dataset["name"]
+        else:
+            cfg = configdataset(self.dataset, os.path.join(get_data_root(), "test"))
+            self.images = [cfg["im_fname"](cfg, i) for i in range(cfg["n"])]
+            self.qimages = [cfg["qim_fname"](cfg, i) for i in range(cfg["nq"])]
+            self.bbxs = [tuple(cfg["gnd"][i]["bbx"]) if cfg["gnd"][i]["bbx"] else None for i in range(cfg["nq"])]
+            self.gnd = cfg["gnd"]
+        assert not params, params.keys()
+
+    def __call__(self, network, device, logger):
+        stopwatch = StopWatch()
+        print(">> {}: database images...".format(self.dataset))
+        vecs = extract_vectors_device(network, self.images, self.image_size, self.transforms, device=device)
+        print(">> {}: query images...".format(self.dataset))
+        if self.images == self.qimages and set(self.bbxs) == {None}:
+            qvecs = vecs.clone()
+        else:
+            qvecs = extract_vectors_device(network, self.qimages, self.image_size, self.transforms, device=device,
+                                           bbxs=self.bbxs)
+        stopwatch.lap("extract_descriptors")
+
+        print(">> {}: Evaluating...".format(self.dataset))
+        index = ops.DescriptorIndex(vecs, "ND")
+        scores = index.scores(qvecs, "ND")                      # [Q,N] = (vecs.T @ qvecs).T
+        if self.ranking == "full":
+            ranks = ops.rank_full(scores)                       # [Q,N] = argsort(-scores, axis=0).T
+            averages, scores_per_query = compute_map_and_print(self.dataset, ranks.t(), self.gnd)
+        else:
+            averages, scores_per_query = compute_map_and_print_from_scores(self.dataset, scores, self.gnd)
+        stopwatch.lap("compute_score")
+        index.close()
+
+        first_score = scores_per_query[list(scores_per_query.keys())[0]]
+        logger(None, len(first_score), "dataset", stopwatch.reset(), "scalar/time")
+        logger(None, len(first_score), "score_avg", averages, "scalar/score")
+        assert len({len(x) for x in scores_per_query.values()}) == 1
+        for i, _ in enumerate(first_score):
+            logger(i, len(first_score), "score", {x: scores_per_query[x][i] for x in scores_per_query},
+                   "scalar/score")
+
+
+SCORES = {"cirdatasetap": CirDatasetAp}
+
+
+def initialize_score(params):
+    return SCORES[params.pop("type")](params)

@@ -1,0 +1,164 @@
+"""Inference wrappers: multi-scale aggregation and learned whitening.
+
+Drop-in for ``mdir/components/data/wrapper.py``: ``Compose`` (:8-41), ``Wrapper``
+(:44-57), ``CirMultiscaleAggregation`` (:84-136), ``CirtorchWhiten`` (:181-195),
+``WRAPPERS_LABELS`` / ``initialize_wrappers`` (:198-220).  Same registry keys, same
+constructor arguments, same preprocess/postprocess protocol and ordering
+(pre-processing in list order, post-processing reversed).  The arithmetic is
+``mdx_ms_aggregate`` and ``mdx_scores`` + ``mdx_l2n_rows``; the whitening matrix is
+re-tiled ONCE into a resident shard instead of being re-read as a torch mat-vec for
+every image.  FakeBatch / CirFakeTupleBatch / ReflectPadMakeDivisible belong to
+training and the U-Net pre-networks and are out of scope.
+"""
+import pickle
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def load_path(path):
+    """Pickle from a local path (mdir/tools/utils.py:44-51; URLs need a network the
+    MI355X boxes do not have, so they are refused loudly)."""
+    assert path.endswith(".pkl"), "Cannot load anything else than pickle at the moment"
+    if path.startswith("http://") or path.startswith("https://"):
+        raise RuntimeError("no network on this path: download '%s' first and pass the local file" % path)
+    with open(path, "rb") as handle:
+        return pickle.load(handle)
+
+
+class Compose(object):
+    def __init__(self, wrappers, device):
+        self.wrappers = wrappers
+        self.device = device
+
+    def __call__(self, tensor, inference, model=None):
+        if not self.wrappers:
+            return inference(tensor.to(self.device))
+        if model is None:
+            model = inference
+        metadata = []
+        for wrapper in self.wrappers:
+            tensor, meta = wrapper.preprocess(tensor, model)
+            metadata.append(meta)
+        if isinstance(tensor, list):
+            tensor = [inference(x.to(self.device)) for x in tensor]
+        else:
+            tensor = inference(tensor.to(self.device))
+        for wrapper, meta in reversed(list(zip(self.wrappers, metadata))):
+            tensor = wrapper.postprocess(tensor, model, meta)
+        return tensor
+
+    def __repr__(self):
+        nice = "\n" + "".join("    %s\n" % x for x in self.wrappers) if self.wrappers else ""
+        return "%s([%s])" % (self.__class__.__name__, nice)
+
+
+class Wrapper(object):
+    def __init__(self, device):
+        pass
+
+    def preprocess(self, tensor, _model):
+        return tensor, None
+
+    def postprocess(self, tensor, _model, _metadata):
+        return tensor
+
+
+class CirMultiscaleAggregation(Wrapper):
+    """Evaluate the network on an image pyramid and aggregate the descriptors."""
+
+    def __init__(self, scales, device):
+        super().__init__(device)
+        if isinstance(scales, str):
+            scales = {"True": True, "False": False}[scales]
+        if isinstance(scales, bool):
+            scales = [1, 1. / np.sqrt(2), 1. / 2] if scales else [1]
+        self.scales = scales
+
+    def _pyramid(self, tensor):
+        # torch >= 1.6 semantics: output size floor(in * s), coordinates scaled by s
+        return [F.interpolate(tensor, scale_factor=scale, mode="bilinear", align_corners=False)
+                for scale in self.scales]
+
+    def preprocess(self, tensor, _model):
+        if len(self.scales) == 1:
+            return tensor if isinstance(tensor, list) else [tensor], isinstance(tensor, list)
+        if isinstance(tensor, list):
+            acc = []
+            for single in tensor:
+                acc += self._pyramid(single)
+            return acc, True
+        return self._pyramid(tensor), False
+
+    @staticmethod
+    def aggregate_tensor(tensor, nscales, outputdim, msp):
+        assert len(tensor) == nscales, "%s != %s" % (len(tensor), nscales)
+        flat = [t.reshape(-1).contiguous() for t in tensor]
+        assert all(t.numel() == outputdim for t in flat)
+        return ops.ms_aggregate(flat, msp)
+
+    def postprocess(self, tensor, model, waslist):
+        msp = 1
+        if len(self.scales) > 1 and model.meta["pooling"] == "gem" and not model.meta["regional"] \
+                and not model.meta["whitening"]:
+            msp = model.pool.p_value() if hasattr(model.pool, "p_value") else model.pool.p.item()
+        n = len(self.scales)
+        if not waslist:
+            return self.aggregate_tensor(tensor, n, model.meta["out_channels"], msp)
+        assert len(tensor) % n == 0, "%s %% %s != 0" % (len(tensor), n)
+        return [self.aggregate_tensor(tensor[i:i + n], n, model.meta["out_channels"], msp)
+                for i in range(0, len(tensor), n)]
+
+    def __repr__(self):
+        return "%s(scales=%s)" % (self.__class__.__name__, self.scales)
+
+
+class CirtorchWhiten(Wrapper):
+    """Whiten descriptors with optional dimensionality reduction: ``P[:d] (v - m)``,
+    then ``/(||.|| + 1e-6)``."""
+
+    def __init__(self, whitening, dimensions, device):
+        super().__init__(device)
+        whitening = load_path(whitening) if isinstance(whitening, str) else whitening
+        P = torch.tensor(np.asarray(whitening["P"]), dtype=torch.float32, device=device)
+        self.m = torch.tensor(np.asarray(whitening["m"]), dtype=torch.float32, device=device).reshape(-1).contiguous()
+        self.dimensions = dimensions or P.shape[0]
+        self.shard = ops.DescriptorIndex(P[:self.dimensions].contiguous(), "ND")   # resident, re-tiled once
+        self.P = P
+
+    def whiten_rows(self, vecs_nd):
+        """``[n, D]`` device descriptors -> ``[n, d]`` whitened rows (batched form)."""
+        y = self.shard.scores(vecs_nd.contiguous(), "ND", center=self.m)
+        return ops.l2n_rows_(y, eps=1e-6)
+
+    def postprocess(self, tensor, model, _meta):
+        if isinstance(tensor, list):
+            return [self.postprocess(t, model, _meta) for t in tensor]
+        return self.whiten_rows(tensor.reshape(1, -1)).reshape(-1)
+
+    def __repr__(self):
+        return "%s(dimensions=%s)" % (self.__class__.__name__, self.dimensions)
+
+
+WRAPPERS_LABELS = {
+    "cirmultiscale": CirMultiscaleAggregation,
+    "cirwhiten": CirtorchWhiten,
+}
+
+
+def initialize_wrappers(net_wrappers, device):
+    """``None`` | ``"name:arg,arg,name2"`` | ``{"<order>_<name>": kwargs}`` (sorted by key)."""
+    if net_wrappers is None:
+        wraps = []
+    elif isinstance(net_wrappers, str):
+        wraps = []
+        for wrap in [x for x in net_wrappers.split(",") if x]:
+            wname, *args = wrap.split(":", 1)
+            args = args[0].split(",") if args else []
+            wraps.append(WRAPPERS_LABELS[wname](*args, device=device))
+    else:
+        wraps = [WRAPPERS_LABELS[x.split("_", 1)[1]](**net_wrappers[x], device=device) for x in sorted(net_wrappers)]
+    return Compose(wraps, device)

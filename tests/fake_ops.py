@@ -1,0 +1,83 @@
+"""Oracle-backed stand-ins for mdir_amd.ops, for the CPU-only host-logic tests.
+
+TEST-ONLY: the product never imports this.  `install(monkeypatch)` swaps the functions
+of `mdir_amd.ops` that launch HIP kernels for CPU equivalents computed by the oracle, so
+that wrappers / networks / scores / scenarios can be exercised without a GPU.  The same
+host code is run against the real library in the -m gpu tests.
+"""
+import numpy as np
+import torch
+
+from oracle import chain as OC
+from oracle import oracle as O
+
+
+def pool_l2n(feat, kind="gem", p=3.0, pool_eps=1e-6, l2n_eps=1e-6):
+    x = feat.detach().numpy()
+    pooled = {"gem": lambda: O.gem(x, p, pool_eps), "mac": lambda: O.mac(x), "spoc": lambda: O.spoc(x)}[kind]()
+    if l2n_eps is not None:
+        pooled = O.l2n(pooled, l2n_eps)
+    return torch.from_numpy(np.ascontiguousarray(pooled))
+
+
+def l2n_rows_(x, bias=None, eps=1e-6):
+    v = x.detach().numpy()
+    if bias is not None:
+        v = v + bias.detach().numpy()[None, :]
+    nrm = np.sqrt(np.sum(v * v, axis=1, keepdims=True, dtype=np.float32), dtype=np.float32)
+    x.copy_(torch.from_numpy((v / (nrm + np.float32(eps))).astype(np.float32)))
+    return x
+
+
+def ms_aggregate(vecs, msp=1.0):
+    return torch.from_numpy(O.ms_aggregate(np.stack([v.detach().numpy().reshape(-1) for v in vecs]), msp))
+
+
+class DescriptorIndex:
+    def __init__(self, vecs, layout="DN", row_offset=0):
+        v = vecs.detach().numpy()
+        self.nd = np.ascontiguousarray(v.T if layout in ("DN", "dim_major") else v)
+        self.n, self.d = self.nd.shape
+        self.row_offset = row_offset
+        self.device = vecs.device
+
+    def scores(self, queries, qlayout="DN", center=None, out=None):
+        q = queries.detach().numpy()
+        q = np.ascontiguousarray(q.T if qlayout in ("DN", "dim_major") else q)
+        if center is not None:
+            q = q - center.detach().numpy().reshape(1, -1)
+        res = torch.from_numpy(OC.gemm_nt_chain(q, self.nd))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def close(self):
+        pass
+
+
+def rank_full(scores, id_offset=0, out=None, workspace=None):
+    return torch.from_numpy(OC.rank_full(scores.detach().numpy()) + id_offset)
+
+
+def topk(scores, k, id_offset=0, workspace=None):
+    rk = OC.rank_full(scores.detach().numpy())[:, :k]
+    return torch.from_numpy(rk + id_offset), torch.from_numpy(np.take_along_axis(scores.numpy(), rk, axis=1))
+
+
+def rank_of(scores, id_lists):
+    s = scores.detach().numpy()
+    off, pos, sc = [0], [], []
+    for q, ids in enumerate(id_lists):
+        ids = np.asarray(ids, dtype=np.int64)
+        pos.append(OC.rank_of(s[q], ids))
+        sc.append(s[q][ids])
+        off.append(off[-1] + len(ids))
+    return (torch.from_numpy(np.concatenate(pos) if pos else np.empty(0, np.int64)),
+            torch.from_numpy(np.concatenate(sc).astype(np.float32) if sc else np.empty(0, np.float32)), off)
+
+
+def install(monkeypatch):
+    from mdir_amd import ops
+    for name in ("pool_l2n", "l2n_rows_", "ms_aggregate", "DescriptorIndex", "rank_full", "topk", "rank_of"):
+        monkeypatch.setattr(ops, name, globals()[name])

@@ -1,0 +1,396 @@
+"""Host logic of the drop-in API on CPU: the product's Python layer with the HIP calls
+replaced by the oracle (tests/fake_ops.py), checked against outputs of the reference
+(tests/golden).  The same layer runs against the real library in tests/test_gpu_api.py."""
+import copy
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from PIL import Image
+
+import fake_ops
+from conftest import GOLDEN
+from oracle import oracle as O
+
+
+@pytest.fixture()
+def fops(monkeypatch):
+    fake_ops.install(monkeypatch)
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    return fake_ops
+
+
+def _jsonkeys(o):
+    """Undo the 'int:N' key encoding of g11_scenario.json."""
+    if isinstance(o, dict):
+        return {(int(k[4:]) if isinstance(k, str) and k.startswith("int:") else k): _jsonkeys(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_jsonkeys(v) for v in o]
+    return o
+
+
+# ------------------------------------------------------------------ scenario / events
+
+def test_dict_deep_overlay_matches_reference():
+    from mdir_amd.scenario import dict_deep_overlay
+    g = json.load(open(os.path.join(GOLDEN, "g11_scenario.json")))
+    for case in g["overlay"]:
+        got = dict_deep_overlay(copy.deepcopy(_jsonkeys(case["base"])), copy.deepcopy(_jsonkeys(case["over"])))
+        assert got == _jsonkeys(case["result"]), case
+    with pytest.raises(ValueError):
+        dict_deep_overlay({"l": [1]}, {"l": [2]})
+    assert dict_deep_overlay({"a": 1, "b": {"c": 1}}, {"b": {"d": 2}}, {"a": 3, "b": {"c": 7}}) == g["three_way"]
+
+
+def test_event_metadata_matches_reference():
+    from mdir_amd.events import initialize_processor
+    want = json.load(open(os.path.join(GOLDEN, "g11_scenario.json")))["metadata"]
+    events = initialize_processor({"progress": {"print_each": 100}}, dataroot=None)
+    lg = lambda it, size, label, value, dtype: events.register_data(0, it, size, "roxford5k/validation/%s" % label,
+                                                                    value, dtype)
+    lg(None, 4, "dataset", {"extract_descriptors": 1.0, "compute_score": 2.0, "total_s": 3.0}, "scalar/time")
+    lg(None, 4, "score_avg", {"map_medium": 0.58333}, "scalar/score")
+    for i, a in enumerate([0.5, float("nan"), 0.25, 1.0]):
+        lg(i, 4, "score", {"ap_medium": a, "ap_easy": a / 2}, "scalar/score")
+    events.close_epoch()
+    got = {k: [float(x) for x in v] for k, v in events.metadata.metadata().items()}
+    assert got == want
+
+
+def test_eval_scenarios_parse_and_overlay():
+    import eval as evalcli
+    sc = evalcli.load_scenarios(["synthetic"])          # shortcut -> eval.yml + eval_synthetic.yml
+    assert sc.keys() == {"network", "validation", "data"}
+    assert sc["network"]["runtime"]["wrappers"]["eval"]["0_cirwhiten"] == {
+        "whitening": "/tmp/mdir_synth/whiten.pkl", "dimensions": None}
+    assert sc["network"]["runtime"]["wrappers"]["eval"]["1_cirmultiscale"] == {"scales": True}
+    assert sc["validation"]["rparis6k"] is False and sc["validation"]["roxford5k"]["criterion"]["image_size"] == 1024
+    assert sorted(evalcli.SCORES) == ["247tokyo1k/validation/score:ap_avg.4",
+                                      "roxford5k/validation/score:ap_medium_avg.4",
+                                      "rparis6k/validation/score:ap_medium_avg.4"]
+
+
+# ------------------------------------------------------------------ layers / network tail
+
+def test_layers_state_dict_and_registry():
+    from mdir_amd.layers import POOLING, GeM, L2N
+    g = GeM()
+    assert list(g.state_dict().keys()) == ["p"] and g.state_dict()["p"].shape == (1,)
+    assert float(g.p) == 3.0 and g.eps == 1e-6 and L2N().eps == 1e-6
+    assert set(POOLING) == {"mac", "spoc", "gem"}
+    g.load_state_dict({"p": torch.tensor([2.5])})
+    assert g.p_value() == 2.5
+    with torch.no_grad():
+        g.p.fill_(2.75)
+    assert g.p_value() == 2.75      # cache follows in-place updates
+    assert repr(g) == "GeM(p=2.7500, eps=1e-06)"
+
+
+def test_forward_tail_matches_reference(fops, golden):
+    from mdir_amd.layers import GeM
+    from mdir_amd.networks import ImageRetrievalNet
+    g = golden("g3_tail.npz")
+    C = g["w"].shape[0]
+    meta = {"architecture": "toy", "local_whitening": False, "pooling": "gem", "regional": False,
+            "whitening": True, "mean": [0, 0, 0], "std": [1, 1, 1], "outputdim": C}
+    lin = nn.Linear(C, C)
+    lin.load_state_dict({"weight": torch.from_numpy(g["w"]), "bias": torch.from_numpy(g["b"])})
+    for p in (3.0, 2.92):
+        net = ImageRetrievalNet([nn.Identity()], None, GeM(p=p), lin, dict(meta)).eval()
+        with torch.no_grad():
+            out = net(torch.from_numpy(g["feat"]))
+        assert tuple(out.shape) == (C, 2)
+        np.testing.assert_allclose(out.numpy(), g[f"out_whiten_p{p}"], rtol=1e-5, atol=2e-7)
+        net = ImageRetrievalNet([nn.Identity()], None, GeM(p=p), None, dict(meta)).eval()
+        with torch.no_grad():
+            np.testing.assert_allclose(net(torch.from_numpy(g["feat"])).numpy(), g[f"out_plain_p{p}"],
+                                       rtol=1e-5, atol=1e-7)
+
+
+def _toy_net(g):
+    from mdir_amd.layers import GeM
+    from mdir_amd.networks import ImageRetrievalNet
+    conv = nn.Conv2d(3, g["conv_w"].shape[0], 3, stride=2, padding=1)
+    conv.load_state_dict({"weight": torch.from_numpy(g["conv_w"]), "bias": torch.from_numpy(g["conv_b"])})
+    c = g["conv_w"].shape[0]
+    meta = {"architecture": "toy", "local_whitening": False, "pooling": "gem", "regional": False,
+            "whitening": False, "mean": [0, 0, 0], "std": [1, 1, 1], "outputdim": c, "in_channels": 3,
+            "out_channels": c}
+    return ImageRetrievalNet([conv, nn.ReLU(inplace=True)], None, GeM(p=float(g["gem_p"])), None, meta).eval()
+
+
+def test_wrapper_chain_matches_reference(fops, golden, tmp_path):
+    """0_cirwhiten + 1_cirmultiscale: pyramid -> 3 forwards -> aggregate (msp = p) -> whiten."""
+    from mdir_amd.networks import extract_ms
+    from mdir_amd.wrapper import WRAPPERS_LABELS, initialize_wrappers
+    g = golden("g6_chain.npz")
+    net = _toy_net(g)
+    pkl = str(tmp_path / "whiten.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({"P": g["P"], "m": g["m"]}, f)
+    img = torch.from_numpy(g["img"])
+    assert set(WRAPPERS_LABELS) == {"cirmultiscale", "cirwhiten"}
+    with torch.no_grad():
+        chain = initialize_wrappers({"0_cirwhiten": {"whitening": pkl, "dimensions": None},
+                                     "1_cirmultiscale": {"scales": True}}, "cpu")
+        assert [w.__class__.__name__ for w in chain.wrappers] == ["CirtorchWhiten", "CirMultiscaleAggregation"]
+        np.testing.assert_allclose(chain(img.clone(), net).numpy(), g["chain_out"], rtol=2e-5, atol=5e-7)
+        chain32 = initialize_wrappers({"0_cirwhiten": {"whitening": pkl, "dimensions": 32},
+                                       "1_cirmultiscale": {"scales": True}}, "cpu")
+        out32 = chain32(img.clone(), net).numpy()
+        assert out32.shape == (32,)
+        np.testing.assert_allclose(out32, g["chain_out_dims32"], rtol=2e-5, atol=5e-7)
+        ms_only = initialize_wrappers("cirmultiscale:True", "cpu")
+        np.testing.assert_allclose(ms_only(img.clone(), net).numpy(), g["ms_only_out"], rtol=2e-5, atol=5e-7)
+        np.testing.assert_allclose(net(img.clone()).numpy(), g["single_scale_out"], rtol=2e-5, atol=5e-7)
+        scales = [1, 1. / np.sqrt(2), 1. / 2]
+        np.testing.assert_allclose(extract_ms(net, img.clone(), scales, 2.5).numpy(), g["extract_ms_out"],
+                                   rtol=2e-5, atol=5e-7)
+        # no wrappers at all: plain inference
+        none = initialize_wrappers(None, "cpu")
+        np.testing.assert_allclose(none(img.clone(), net).numpy(), g["single_scale_out"], rtol=2e-5, atol=5e-7)
+
+
+def test_pyramid_semantics_match_reference(golden):
+    from mdir_amd.wrapper import CirMultiscaleAggregation
+    g = golden("g6_chain.npz")
+    w = CirMultiscaleAggregation(True, "cpu")
+    assert w.scales == [1, 1. / np.sqrt(2), 1. / 2]
+    pyr, waslist = w.preprocess(torch.from_numpy(g["img"]), None)
+    assert waslist is False and len(pyr) == 3
+    np.testing.assert_allclose(pyr[1].numpy(), g["interp_s1"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pyr[2].numpy(), g["interp_s2"], rtol=0, atol=1e-6)
+    big, _ = w.preprocess(torch.zeros(1, 1, 768, 1024), None)
+    assert [list(t.shape[2:]) for t in big] == g["interp_size_1024x768"].tolist() == [[768, 1024], [543, 724], [384, 512]]
+    assert CirMultiscaleAggregation("False", "cpu").scales == [1]
+
+
+def test_msp_rule(fops):
+    """msp = pool.p only for >1 scale, gem, not regional, no IN-NETWORK whitening (wrapper.py:121-124)."""
+    from mdir_amd.layers import GeM
+    from mdir_amd.wrapper import CirMultiscaleAggregation
+
+    class M:
+        pool = GeM(p=2.0)
+        meta = {"pooling": "gem", "regional": False, "whitening": False, "out_channels": 8}
+    v = [torch.rand(8, 1) for _ in range(3)]
+    w = CirMultiscaleAggregation(True, "cpu")
+    np.testing.assert_allclose(w.postprocess(v, M, False).numpy(),
+                               O.ms_aggregate(np.stack([t.numpy().reshape(-1) for t in v]), 2.0), rtol=1e-6)
+    M.meta = dict(M.meta, whitening=True)
+    np.testing.assert_allclose(w.postprocess(v, M, False).numpy(),
+                               O.ms_aggregate(np.stack([t.numpy().reshape(-1) for t in v]), 1.0), rtol=1e-6)
+    assert O.ms_power({"pooling": "gem", "regional": False, "whitening": False}, 3, 2.0) == 2.0
+    assert O.ms_power({"pooling": "mac", "regional": False, "whitening": False}, 3, 2.0) == 1.0
+
+
+def test_whitenapply_matches_reference(fops, golden):
+    from mdir_amd.whiten import whitenapply
+    g = golden("g5_whiten.npz")
+    for dims in (None, 48):
+        got = whitenapply(g["X"], g["m"].astype(np.float32), g["P"].astype(np.float32), dims, device="cpu")
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, g[f"whitenapply_f32_dims{dims}"], rtol=1e-5, atol=2e-7)
+        got64 = whitenapply(g["X"].astype(np.float64), g["m"], g["P"], dims, device="cpu")
+        assert got64.dtype == np.float64
+        np.testing.assert_allclose(got64, g[f"whitenapply_f64_dims{dims}"], rtol=1e-5, atol=5e-7)
+
+
+# ------------------------------------------------------------------ backbones / init_network
+
+@pytest.mark.parametrize("arch,dim,nkeys,probe", [
+    ("alexnet", 256, 10, "features.10.weight"),
+    ("vgg16", 512, 26, "features.28.bias"),
+    ("resnet18", 512, 100, "features.7.1.bn2.running_var"),
+    ("resnet101", 2048, 520, "features.6.22.conv3.weight"),
+])
+def test_backbone_state_dict_names(arch, dim, nkeys, probe):
+    """Key names / counts follow torchvision's module tree, so reference checkpoints load."""
+    from mdir_amd.networks import init_network
+    net = init_network({"architecture": arch, "pooling": "gem", "whitening": True, "pretrained": False})
+    sd = net.state_dict()
+    fk = [k for k in sd if k.startswith("features.") and not k.endswith("num_batches_tracked")]
+    assert len(fk) == nkeys and probe in sd
+    assert {"pool.p", "whiten.weight", "whiten.bias"} <= set(sd)
+    assert tuple(sd["whiten.weight"].shape) == (dim, dim) and net.meta["outputdim"] == dim
+    if arch == "resnet101":
+        assert tuple(sd["features.4.0.downsample.0.weight"].shape) == (256, 64, 1, 1)
+        assert tuple(sd["features.7.0.conv2.weight"].shape) == (512, 512, 3, 3)
+    with torch.no_grad():
+        feat = net.features(torch.zeros(1, 3, 64, 96))
+    stride = {"alexnet": None, "vgg16": 16, "resnet18": 32, "resnet101": 32}[arch]
+    assert feat.shape[1] == dim and (stride is None or tuple(feat.shape[2:]) == (64 // stride, 96 // stride))
+    assert float(feat.min()) >= 0.0           # stacks end with a ReLU (imageretrievalnet.py:166)
+
+
+def test_init_network_whitening_from_pickle(tmp_path):
+    from mdir_amd.networks import init_network
+    rng = np.random.default_rng(0)
+    P, m = rng.standard_normal((256, 256)), rng.standard_normal((256, 1))
+    pkl = str(tmp_path / "w.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({"P": P, "m": m}, f)
+    net = init_network({"architecture": "alexnet", "whitening": pkl, "pretrained": False})
+    np.testing.assert_allclose(net.whiten.weight.detach().numpy(), P.astype(np.float32))
+    np.testing.assert_allclose(net.whiten.bias.detach().numpy(), -(P.astype(np.float32) @ m.astype(np.float32)).squeeze(),
+                               rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        init_network({"architecture": "nope"})
+
+
+# ------------------------------------------------------------------ datasets / extraction / score
+
+def _write_images(root, names, rng, size=(96, 64)):
+    os.makedirs(root, exist_ok=True)
+    for i, n in enumerate(names):
+        w, h = (size[0] + 8 * (i % 3), size[1] + 4 * (i % 2))
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, n + ".jpg"), quality=95)
+
+
+def test_images_from_list_contract(tmp_path):
+    from mdir_amd.datasets import ImagesFromList, configdataset, imresize, initialize_transforms
+    rng = np.random.default_rng(0)
+    _write_images(str(tmp_path), ["a", "b"], rng, size=(200, 100))
+    tr = initialize_transforms("pil2np | totensor | normalize", [[0.5, 0.5, 0.5], [0.25, 0.25, 0.25]])
+    ds = ImagesFromList("", [str(tmp_path / "a.jpg"), str(tmp_path / "b.jpg")], imsize=64,
+                        bbxs=[(10, 10, 110, 60), None], transform=tr)
+    a, b = ds[0], ds[1]
+    assert tuple(a.shape) == (3, 32, 64) and a.dtype == torch.float32         # crop 100x50 -> thumbnail 64x32
+    assert max(b.shape[1:]) == 64
+    assert float(a.max()) <= 2.0 and float(a.min()) >= -2.0
+    big = imresize(Image.new("RGB", (30, 20)), 64)
+    assert big.size == (30, 20)                                             # thumbnail never up-scales
+    with pytest.raises(RuntimeError):
+        ImagesFromList("", [])
+    with pytest.raises(OSError):
+        ImagesFromList("", [str(tmp_path / "missing.jpg")])[0]
+    assert ImagesFromList("", [str(tmp_path / "missing.jpg")], ignore_errors=True)[0] == {}
+    with pytest.raises(ValueError):
+        configdataset("nosuchset", str(tmp_path))
+    with pytest.raises(KeyError):
+        initialize_transforms("pil2np | apply_clahe", None)
+
+
+def _synthetic_dataset(tmp_path, monkeypatch, n=9, nq=3):
+    rng = np.random.default_rng(5)
+    root = tmp_path / "data" / "test" / "roxford5k"
+    names = ["im%02d" % i for i in range(n)]
+    _write_images(str(root / "jpg"), names, rng, size=(224, 160))
+    gnd = []
+    for q in range(nq):
+        gnd.append({"bbx": [4.0, 4.0, 204.0, 150.0] if q != 1 else None, "easy": [q, (q + 3) % n], "hard": [(q + 5) % n],
+                    "junk": [(q + 6) % n]})
+    with open(root / "gnd_roxford5k.pkl", "wb") as f:
+        pickle.dump({"imlist": names, "qimlist": names[:nq], "gnd": gnd}, f)
+    monkeypatch.setenv("CIRTORCH_ROOT", str(tmp_path))
+    return names, gnd
+
+
+def test_extract_vectors_and_score_end_to_end(fops, tmp_path, monkeypatch, capsys):
+    """CirDatasetAp on a synthetic roxford5k directory: the product orchestration (with the oracle
+    standing in for the kernels) equals the reference's statement sequence restated with numpy."""
+    from mdir_amd.network import CirNetwork, SingleNetwork
+    from mdir_amd.networks import extract_vectors, init_network
+    from mdir_amd.score import SCORES, initialize_score
+    names, gnd = _synthetic_dataset(tmp_path, monkeypatch)
+    torch.manual_seed(0)
+    model = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False})
+    model.meta["in_channels"], model.meta["out_channels"] = 3, model.meta["outputdim"]
+    rng = np.random.default_rng(1)
+    P, m = rng.standard_normal((256, 256)) / 16, rng.normal(0, 0.01, (256, 1))
+    pkl = str(tmp_path / "whiten.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({"P": P, "m": m}, f)
+    runtime = {"wrappers": {"train": None, "eval": {"0_cirwhiten": {"whitening": pkl, "dimensions": 64},
+                                                    "1_cirmultiscale": {"scales": True}}}}
+    net = CirNetwork(model, SingleNetwork.NetworkParams({"architecture": "cirnet"}, runtime), "cpu", frozen=False).eval()
+    assert net.network_params.runtime["data"]["mean_std"] == [model.meta["mean"], model.meta["std"]]
+    assert set(SCORES) == {"cirdatasetap"}
+    score = initialize_score({"type": "cirdatasetap", "image_size": 224, "dataset": "roxford5k",
+                              "transforms": "pil2np | totensor | normalize",
+                              "mean_std": net.network_params.runtime["data"]["mean_std"]})
+    assert len(score.images) == 9 and score.bbxs == [(4.0, 4.0, 204.0, 150.0), None, (4.0, 4.0, 204.0, 150.0)]
+    rows = []
+    with torch.no_grad():
+        score(net, "cpu", lambda it, size, label, value, dtype: rows.append((it, size, label, value, dtype)))
+        vecs = extract_vectors(net, score.images, 224, score.transforms, device="cpu")
+        qvecs = extract_vectors(net, score.qimages, 224, score.transforms, device="cpu", bbxs=score.bbxs)
+    assert tuple(vecs.shape) == (64, 9) and vecs.is_contiguous() and vecs.dtype == torch.float32
+    np.testing.assert_allclose(np.linalg.norm(vecs.numpy(), axis=0), 1.0, atol=1e-4)
+    # the reference's statements (cirscore.py:69-71) on those descriptors, through the oracle
+    sc = O.scores(vecs.numpy(), qvecs.numpy())
+    avg, per = O.compute_map_and_print("roxford5k", O.ranks(sc), gnd)
+    labels = [r[2] for r in rows]
+    assert labels[:2] == ["dataset", "score_avg"] and labels[2:] == ["score"] * 3
+    assert set(rows[0][3]) == {"extract_descriptors", "compute_score", "total_s"} and rows[0][4] == "scalar/time"
+    got_avg = rows[1][3]
+    for k in ("map_easy", "map_medium", "map_hard"):
+        np.testing.assert_allclose(got_avg[k], avg[k], rtol=0, atol=1e-12)
+    for i in range(3):
+        assert rows[2 + i][0] == i and rows[2 + i][1] == 3
+        for k in ("ap_easy", "ap_medium", "ap_hard"):
+            np.testing.assert_allclose(rows[2 + i][3][k], per[k][i], rtol=0, atol=1e-12)
+    assert ">> roxford5k: mAP E:" in capsys.readouterr().out
+    # positions route gives the same averages
+    score2 = initialize_score({"type": "cirdatasetap", "image_size": 224, "dataset": "roxford5k", "ranking": "positions",
+                               "transforms": "pil2np | totensor | normalize",
+                               "mean_std": net.network_params.runtime["data"]["mean_std"]})
+    rows2 = []
+    with torch.no_grad():
+        score2(net, "cpu", lambda it, size, label, value, dtype: rows2.append((label, value)))
+    assert rows2[1][1] == got_avg
+
+
+def test_checkpoint_roundtrip_and_validate_tree(fops, tmp_path, monkeypatch):
+    """Checkpoint dict layout (network.py:142-170) -> load_network -> validation tree -> metadata keys."""
+    from mdir_amd import stages
+    from mdir_amd.network import CirNetwork, SingleNetwork, load_network
+    from mdir_amd.networks import init_network
+    _synthetic_dataset(tmp_path, monkeypatch)
+    torch.manual_seed(0)
+    model_params = {"architecture": "cirnet", "cir_architecture": "alexnet", "local_whitening": False,
+                    "pooling": "gem", "regional": False, "whitening": False, "pretrained": True}
+    model = init_network({"architecture": "alexnet", "pretrained": False})
+    model.meta["in_channels"], model.meta["out_channels"] = 3, 256
+    runtime = {"wrappers": "", "data": {"transforms": "pil2np | totensor | normalize"}}
+    net = CirNetwork(model, SingleNetwork.NetworkParams(model_params, runtime), "cpu", frozen=True)
+    ckpt = str(tmp_path / "net.pth")
+    torch.save(net.state_dict()["net"], ckpt)
+    rng = np.random.default_rng(1)
+    pkl = str(tmp_path / "whiten.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({"P": rng.standard_normal((256, 256)) / 16, "m": rng.normal(0, 0.01, (256, 1))}, f)
+    overrides = {"wrappers": {"train": None, "eval": {"0_cirwhiten": {"whitening": pkl, "dimensions": None},
+                                                      "1_cirmultiscale": {"scales": True}}}}
+    loaded = load_network({"path": ckpt, "runtime": overrides}, "cpu")
+    assert isinstance(loaded, CirNetwork) and loaded.frozen and loaded.stage == "eval"
+    assert loaded.meta == {"in_channels": 3, "out_channels": 256}
+    for (k1, v1), (k2, v2) in zip(net.model.state_dict().items(), loaded.model.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert [w.__class__.__name__ for w in loaded.wrappers["eval"].wrappers] == ["CirtorchWhiten",
+                                                                               "CirMultiscaleAggregation"]
+    with pytest.raises(RuntimeError):
+        load_network({"path": "http://example.org/x.pth", "runtime": {}}, "cpu")
+
+    scenario = {"network": {"path": ckpt, "runtime": overrides},
+                "validation": {"type": "MultiCriterialValidation", "decisive_criterion": None,
+                               "roxford5k": {"type": "SingleValidation", "frequency": None, "network_overlay": None,
+                                             "data": None,
+                                             "criterion": {"type": "cirdatasetap", "image_size": 224,
+                                                           "dataset": "roxford5k"}},
+                               "rparis6k": False},
+                "data": {}}
+    metadata, = stages.validate(copy.deepcopy(scenario), (), device="cpu")   # kernels are faked here
+    with pytest.raises(RuntimeError, match="MI355X"):
+        stages.validate(copy.deepcopy(scenario), ())                         # default device: GPU or nothing
+    keys = set(metadata["eval"])
+    assert {"roxford5k/validation/score:ap_medium_avg.4", "roxford5k/validation/score:ap_easy_avg.4",
+            "roxford5k/validation/score:ap_hard_avg.4", "roxford5k/validation/score_avg:map_medium"} <= keys
+    assert metadata["eval"]["roxford5k/validation/score:ap_medium_avg.4"] == pytest.approx(
+        metadata["eval"]["roxford5k/validation/score_avg:map_medium"], abs=1e-12)
+    with pytest.raises(AssertionError):
+        stages.validate({"network": {}, "validation": {}}, (), device="cpu")
