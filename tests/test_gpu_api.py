@@ -1,0 +1,244 @@
+"""The host API against the REAL library on an MI355X, plus full-size property checks.
+
+Small cases compare with outputs of the reference (tests/golden) and the oracle; the
+BASELINE.json-size cases (N = 1 004 993, Q = 70, D = 2048) use size-independent
+properties and oracle checks on samples."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import ROOT
+from oracle import chain as OC
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _toy_net(g):
+    from mdir_amd.layers import GeM
+    from mdir_amd.networks import ImageRetrievalNet
+    conv = nn.Conv2d(3, g["conv_w"].shape[0], 3, stride=2, padding=1)
+    conv.load_state_dict({"weight": torch.from_numpy(g["conv_w"]), "bias": torch.from_numpy(g["conv_b"])})
+    c = g["conv_w"].shape[0]
+    meta = {"architecture": "toy", "local_whitening": False, "pooling": "gem", "regional": False,
+            "whitening": False, "mean": [0, 0, 0], "std": [1, 1, 1], "outputdim": c, "in_channels": 3, "out_channels": c}
+    return ImageRetrievalNet([conv, nn.ReLU(inplace=True)], None, GeM(p=float(g["gem_p"])), None, meta).eval().to(DEV)
+
+
+def test_wrapper_chain_on_gpu_matches_reference(golden, tmp_path):
+    from mdir_amd.networks import extract_ms
+    from mdir_amd.wrapper import initialize_wrappers
+    g = golden("g6_chain.npz")
+    net = _toy_net(g)
+    pkl = str(tmp_path / "whiten.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({"P": g["P"], "m": g["m"]}, f)
+    img = torch.from_numpy(g["img"])
+    with torch.no_grad():
+        chain = initialize_wrappers({"0_cirwhiten": {"whitening": pkl, "dimensions": None},
+                                     "1_cirmultiscale": {"scales": True}}, DEV)
+        out = chain(img.clone(), net)
+        assert out.is_cuda
+        np.testing.assert_allclose(out.cpu().numpy(), g["chain_out"], rtol=2e-5, atol=1e-6)
+        chain32 = initialize_wrappers({"0_cirwhiten": {"whitening": pkl, "dimensions": 32},
+                                       "1_cirmultiscale": {"scales": True}}, DEV)
+        np.testing.assert_allclose(chain32(img.clone(), net).cpu().numpy(), g["chain_out_dims32"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(net(img.to(DEV)).cpu().numpy(), g["single_scale_out"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(extract_ms(net, img.to(DEV), [1, 1. / np.sqrt(2), 1. / 2], 2.5).cpu().numpy(),
+                                   g["extract_ms_out"], rtol=2e-5, atol=1e-6)
+
+
+def test_forward_tail_and_whitenapply_on_gpu(golden):
+    from mdir_amd.layers import GeM, gem, l2n
+    from mdir_amd.networks import ImageRetrievalNet
+    from mdir_amd.whiten import whitenapply
+    g = golden("g3_tail.npz")
+    C = g["w"].shape[0]
+    meta = {"architecture": "toy", "local_whitening": False, "pooling": "gem", "regional": False,
+            "whitening": True, "mean": [0, 0, 0], "std": [1, 1, 1], "outputdim": C}
+    lin = nn.Linear(C, C)
+    lin.load_state_dict({"weight": torch.from_numpy(g["w"]), "bias": torch.from_numpy(g["b"])})
+    for p in (3.0, 2.92):
+        net = ImageRetrievalNet([nn.Identity()], None, GeM(p=p), lin, dict(meta)).eval().to(DEV)
+        with torch.no_grad():
+            np.testing.assert_allclose(net(dev(g["feat"])).cpu().numpy(), g[f"out_whiten_p{p}"], rtol=1e-5, atol=2e-7)
+    x = dev(g["feat"])
+    np.testing.assert_allclose(l2n(gem(x, p=torch.ones(1) * 3)).cpu().numpy().reshape(2, C).T, g["out_plain_p3.0"],
+                               rtol=1e-5, atol=1e-7)
+    w = golden("g5_whiten.npz")
+    for dims in (None, 48):
+        got = whitenapply(w["X"], w["m"].astype(np.float32), w["P"].astype(np.float32), dims)
+        np.testing.assert_allclose(got, w[f"whitenapply_f32_dims{dims}"], rtol=1e-5, atol=2e-7)
+
+
+def test_eval_py_end_to_end(tmp_path):
+    """./eval.py on a generated roxford5k + 247tokyo1k set-up; the printed numbers equal an
+    independent oracle pipeline (torch-CPU backbone + numpy tail + reference statements)."""
+    root = str(tmp_path / "synth")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_eval.py"), root])
+    env = dict(os.environ, CIRTORCH_ROOT=root, MDIR_AMD_WORKERS="2")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py"), "eval.yml", os.path.join(root, "eval_synth.yml")],
+                          env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = proc.stdout
+    assert proc.returncode == 0, out[-3000:]
+    printed = {}
+    for line in out.splitlines():
+        for label in ("roxford.5k medium", "247tokyo.1k"):
+            if line.strip().startswith(label):
+                printed[label] = float(line.split()[-1])
+    assert set(printed) == {"roxford.5k medium", "247tokyo.1k"}, out
+
+    # independent pipeline on the CPU
+    from mdir_amd.datasets import ImagesFromList, configdataset, initialize_transforms
+    from mdir_amd.network import load_checkpoint
+    from mdir_amd.networks import init_network
+    import torch.nn.functional as F
+    state = load_checkpoint(os.path.join(root, "net.pth"))["net"]
+    model = init_network({"architecture": "alexnet", "pretrained": False})
+    model.load_state_dict(state["model_state"])
+    model.eval()
+    p = float(model.pool.p)
+    wh = pickle.load(open(os.path.join(root, "whiten.pkl"), "rb"))
+    tr = initialize_transforms("pil2np | totensor | normalize", [model.meta["mean"], model.meta["std"]])
+
+    def describe(paths, bbxs):
+        vecs = []
+        for img in ImagesFromList("", paths, imsize=320, bbxs=bbxs, transform=tr):
+            per = []
+            for s in O.MS_SCALES:
+                x = img[None] if s == 1 else F.interpolate(img[None], scale_factor=float(s), mode="bilinear",
+                                                          align_corners=False)
+                with torch.no_grad():
+                    per.append(O.l2n(O.gem(model.features(x).numpy(), p))[0])
+            vecs.append(O.whiten_wrapper(O.ms_aggregate(np.stack(per), p), wh["m"], wh["P"]))
+        return np.stack(vecs, axis=1)
+
+    want = {}
+    for ds, label, key in (("roxford5k", "roxford.5k medium", "ap_medium"), ("247tokyo1k", "247tokyo.1k", "ap")):
+        cfg = configdataset(ds, os.path.join(root, "data", "test"))
+        ims = [cfg["im_fname"](cfg, i) for i in range(cfg["n"])]
+        qims = [cfg["qim_fname"](cfg, i) for i in range(cfg["nq"])]
+        bbxs = [tuple(g["bbx"]) if g.get("bbx") else None for g in cfg["gnd"]]
+        vecs = describe(ims, None)
+        qvecs = vecs.copy() if ims == qims and set(bbxs) == {None} else describe(qims, bbxs)
+        _, per = O.compute_map_and_print(ds, O.ranks(O.scores(vecs, qvecs)), cfg["gnd"])
+        want[label] = round(100 * O.nanmean_metric(per[key]), 2)
+    assert printed == want, (printed, want, out)
+
+
+# --------------------------------------------------------------- full-size properties
+
+@pytest.fixture(scope="module")
+def big():
+    """rOxford5k+1M shaped problem resident on the GPU (BASELINE.json configs[2])."""
+    from mdir_amd import ops
+    n, nq, d = 1_004_993, 70, 2048
+    g = torch.Generator(device=DEV)
+    g.manual_seed(0)
+    rows = torch.empty((n, d), dtype=torch.float32, device=DEV)
+    for s in range(0, n, 65536):
+        e = min(n, s + 65536)
+        blk = torch.randn((e - s, d), generator=g, device=DEV)
+        rows[s:e] = blk / blk.norm(dim=1, keepdim=True)
+    qid = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:nq]
+    q = rows[qid.to(DEV)] + 0.05 * torch.randn((nq, d), generator=g, device=DEV)
+    q /= q.norm(dim=1, keepdim=True)
+    rows[123] = rows[77]          # exact duplicates -> tied scores
+    rows[900_000] = rows[77]
+    rows[5] = 0.0                 # zero vector -> score exactly 0
+    ix = ops.DescriptorIndex(rows, "ND")
+    sc = ix.scores(q.contiguous(), "ND")
+    rk = ops.rank_full(sc)
+    torch.cuda.synchronize()
+    return {"rows": rows, "q": q, "qid": qid, "ix": ix, "sc": sc, "rk": rk, "n": n, "nq": nq}
+
+
+def test_full_size_scores_bit_exact_on_samples(big):
+    """Sampled database rows: GPU scores == fmaf-chain oracle, bit for bit."""
+    rng = np.random.default_rng(0)
+    ids = np.unique(np.concatenate([rng.choice(big["n"], 3000, replace=False), [0, 5, 77, 123, 900_000, big["n"] - 1],
+                                    big["qid"].numpy()]))
+    sub = big["rows"][torch.from_numpy(ids).to(DEV)].cpu().numpy()
+    want = OC.scores_chain(np.ascontiguousarray(sub.T), np.ascontiguousarray(big["q"].cpu().numpy().T))
+    got = big["sc"][:, torch.from_numpy(ids).to(DEV)].cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert np.all(got[:, list(ids).index(5)] == 0.0)
+    ref = O.scores(np.ascontiguousarray(sub.T), np.ascontiguousarray(big["q"].cpu().numpy().T)).T
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)        # vs the reference's BLAS: north-star tolerance
+
+
+def test_full_size_ranking_properties(big):
+    sc, rk, n, nq = big["sc"], big["rk"], big["n"], big["nq"]
+    # a permutation of 0..n-1 per query
+    srt, _ = torch.sort(rk, dim=1)
+    assert bool((srt == torch.arange(n, device=DEV)[None, :]).all())
+    del srt
+    # non-increasing scores; inside a run of equal scores ids ascend (the documented tie rule)
+    g = torch.gather(sc, 1, rk)
+    assert bool((g[:, 1:] <= g[:, :-1]).all())
+    tie = g[:, 1:] == g[:, :-1]
+    assert int(tie.sum()) >= nq                                     # rows 77 / 123 / 900000 tie for every query
+    assert bool((rk[:, 1:][tie] > rk[:, :-1][tie]).all())
+    # every query retrieves its (noisy) source row first
+    assert bool((rk[:, 0].cpu() == big["qid"]).all())
+    # three full columns against the CPU oracle, bit-exact
+    for qi in (0, 33, 69):
+        np.testing.assert_array_equal(rk[qi].cpu().numpy(), OC.rank_full(sc[qi:qi + 1].cpu().numpy())[0])
+
+
+def test_full_size_topk_rank_of_and_map(big):
+    from mdir_amd import ops
+    from mdir_amd.evaluate import compute_map, compute_map_from_scores
+    sc, rk, n, nq = big["sc"], big["rk"], big["n"], big["nq"]
+    ids, vals = ops.topk(sc, 1000)
+    assert bool((ids == rk[:, :1000]).all())
+    assert bool((vals == torch.gather(sc, 1, rk[:, :1000])).all())
+    gnd = O.synth_gnd(nq, 4993, seed=1)
+    gnd[3]["easy"], gnd[3]["hard"] = np.array([77, 123]), np.array([900_000 % 4993])   # tied items among the labels
+    lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
+    pos, _, off = ops.rank_of(sc, lists)
+    inv = torch.empty_like(rk)
+    inv.scatter_(1, rk, torch.arange(n, device=DEV)[None, :].expand(nq, n))
+    for qi in range(nq):
+        want = inv[qi][torch.from_numpy(lists[qi]).to(DEV)]
+        assert bool((pos[off[qi]:off[qi + 1]] == want).all())
+    gm = O.protocol_gnd(gnd, "medium")
+    a = compute_map(rk.t(), gm, [1, 5, 10])
+    b = compute_map_from_scores(sc, gm, [1, 5, 10])
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_full_size_shards_equal_whole(big):
+    """Row-sharding is exact: per-shard scores concatenate to the full matrix and per-shard
+    counts add up to the global positions (what ShardedIndex does across GPUs)."""
+    from mdir_amd import ops
+    from mdir_amd.sharded import shard_bounds
+    sc, rk, n, nq = big["sc"], big["rk"], big["n"], big["nq"]
+    G = 3
+    lists = [np.array([77, 123, 900_000, 5, int(big["qid"][qi])]) for qi in range(nq)]
+    ids_t, off_t, off = ops._csr(lists, torch.device(DEV))
+    ref = ops.gather_scores(sc, ids_t, off_t)
+    cnt = torch.zeros(ids_t.numel(), dtype=torch.int64, device=DEV)
+    for r in range(G):
+        lo, hi = shard_bounds(n, G, r)
+        shard = ops.DescriptorIndex(big["rows"][lo:hi], "ND", row_offset=lo)
+        s_local = shard.scores(big["q"].contiguous(), "ND")
+        assert bool((s_local == sc[:, lo:hi]).all())
+        ops.rank_count_(cnt, s_local, lo, ref, ids_t, off_t)
+        shard.close()
+    inv = torch.empty_like(rk)
+    inv.scatter_(1, rk, torch.arange(n, device=DEV)[None, :].expand(nq, n))
+    for qi in range(nq):
+        assert bool((cnt[off[qi]:off[qi + 1]] == inv[qi][ids_t[off[qi]:off[qi + 1]]]).all())
