@@ -9,7 +9,7 @@ axis=0)` (mdir/components/optim/score/cirscore.py:69-70).  Inputs are resident i
 HBM when the timed region starts.  With --gpus N the 1M database is row-sharded
 (strong scaling); see mdir_amd/sharded.py for the exchange.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n ROWS] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows ROWS] [--no-cpu-baseline]
 
 Prints ONE JSON line on rank 0.
 """
@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_ROXFORD + N_DISTRACTORS, help="database rows (default 1 004 993)")
+    ap.add_argument("--rows", dest="n", type=int, default=N_ROXFORD + N_DISTRACTORS, help="database rows (default 1 004 993)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -120,11 +120,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # MDIR_AMD_DRYRUN_ONE_GPU=1: every rank uses cuda:0 and gloo (host-staged collectives) --
+    # a functional dry run of the N>1 code path on a 1-GPU box, never a measurement.
+    dryrun = os.environ.get("MDIR_AMD_DRYRUN_ONE_GPU") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if dryrun:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from mdir_amd import ops
     from mdir_amd.sharded import ShardedIndex, shard_bounds
@@ -177,7 +185,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dryrun else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -197,7 +205,7 @@ def main():
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
         if tf:
             traffic = json.load(open(tf[-1])).get("scores_kernel_hbm_bytes_per_launch")
-        roofline = {"kernel": "mdx::scores_kernel<5,2> (fp32 MFMA 16x16x4)", "bound": "mfma",
+        roofline = {"kernel": "mdx::scores_kernel<QT=5> (fp32 MFMA 16x16x4, 8 waves/workgroup)", "bound": "mfma",
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops, "algorithmic_bytes": algo_bytes,
@@ -207,7 +215,7 @@ def main():
         extra["rank_ms_per_step"] = round(elapsed / args.steps * 1e3 - kernel_ms, 4)
     else:
         rk_mine, sc_mine, (qlo, qhi) = keep["rk"], keep["sc"], keep["q"]
-        ok = torch.tensor([1], device=device)
+        ok = torch.tensor([1], device="cpu" if dryrun else device)
         if qhi > qlo:
             ok[0] = int(bool((rk_mine[:, 0].cpu() == torch.from_numpy(qid[qlo:qhi])).all()))
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -245,7 +253,8 @@ def main():
         line = {"metric": "queries/sec, exact full ranking (rOxford5k+1M-distractor shape, 2048-d fp32); mAP-medium alongside",
                 "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic" + (" (DRY RUN: all ranks on one GPU over gloo -- not a measurement)" if dryrun else ""),
                 "config": {"workload": "configs[2]: roxford5k+1M synthetic distractors, N=%d Q=%d D=%d, "
                                        "similarity + exact full ranking per step" % (n_total, NQ, DIM),
                            "db_rows_per_gpu": n_local, "parallelism": "db-row-shard x%d, query-split sort" % world,

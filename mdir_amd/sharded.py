@@ -68,6 +68,25 @@ class ShardedIndex:
         self.backend = backend or HipBackend()
         self.index = self.backend.make_index(local_vecs, layout, self.lo)
         self.device = local_vecs.device
+        # RCCL moves device buffers directly; under gloo (CPU tests, or several ranks
+        # sharing one GPU for a dry run) collectives are staged through host memory.
+        self._host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
+
+    def _all_to_all(self, recv, send, out_split, in_split):
+        if self._host_staged:
+            r = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(r, send.cpu(), out_split, in_split, group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, out_split, in_split, group=self.group)
+
+    def _all_reduce_sum(self, t):
+        if self._host_staged:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # ------------------------------------------------------------------ scores
     def local_scores(self, queries, qlayout="DN"):
@@ -87,7 +106,7 @@ class ShardedIndex:
                   for r in range(self.world)]
         out_split = [(qhi - qlo) * w for w in widths]
         recv = torch.empty(sum(out_split), dtype=s_local.dtype, device=s_local.device)
-        dist.all_to_all_single(recv, s_local.reshape(-1), out_split, in_split, group=self.group)
+        self._all_to_all(recv, s_local.reshape(-1), out_split, in_split)
         blocks, o = [], 0
         for w, sz in zip(widths, out_split):
             blocks.append(recv[o:o + sz].view(qhi - qlo, w))
@@ -123,8 +142,8 @@ class ShardedIndex:
         ref = self.backend.gather_scores(s_local, local_ids, off_t)
         ref = torch.where(mine, ref, torch.zeros_like(ref))
         if self.world > 1:
-            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)   # exactly one owner per id
+            self._all_reduce_sum(ref)   # exactly one owner per id
         self.backend.rank_count_(cnt, s_local, self.lo, ref, ids_t, off_t)
         if self.world > 1:
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce_sum(cnt)
         return cnt, offsets

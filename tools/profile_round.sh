@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round profile on the GPU box (through gpurun): kernel trace + stats of the default bench
+# command, then HBM-traffic / SQ PMC passes in their own runs (MI355X_MICROARCH.md, HBM section).
+# Only small summaries are kept (gpurun_out is capped at 64 MiB).
+#   bash tools/profile_round.sh r01
+R=$GRAFT_REPO_ROOT; TAG=${1:-r01}; OUT=$R/gpurun_out/profile_$TAG; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+W=/tmp/prof_$TAG; rm -rf $W; mkdir -p $W
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats_bench.log 2>&1
+cp $W/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv
+head -1 $W/stats/*/*_kernel_trace.csv > $OUT/kernel_trace_mdx.csv; grep "mdx::" $W/stats/*/*_kernel_trace.csv >> $OUT/kernel_trace_mdx.csv
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAVES"; do
+  n=$(echo $c | cut -d' ' -f1)
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "mdx::" --output-format csv -d $W/pmc_$n -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$n.log 2>&1
+  cp $W/pmc_$n/*/*_counter_collection.csv $OUT/pmc_$n.csv
+done
+tail -1 $OUT/stats_bench.log | cut -c1-300
+du -sh $OUT

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Digest gpurun_out/profile_<tag>/ (tools/profile_round.sh) into tracked files:
+   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (mdx kernels + top others)
+   profiles/<tag>_traffic.json       HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
+   profiles/<tag>_summary.md         human-readable table
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes of a wide
+coalesced streaming read -> doubled here; WRITE_SIZE is exact for 16-B streaming stores.  Both in KiB."""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "profile_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
+keep = [r for r in rows if "mdx::" in r["Name"]]
+with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    for r in keep + [r for r in rows if "mdx::" not in r["Name"]][:8]:
+        w.writerow(r)
+
+
+def short(name):
+    n = name.replace("void ", "")
+    return n[:n.index("(")] if "(" in n else n
+
+
+def pmc(fn):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    p = os.path.join(src, fn)
+    if not os.path.exists(p):
+        return d
+    for r in csv.DictReader(open(p)):
+        d[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+fetch, write, sq = pmc("pmc_FETCH_SIZE.csv"), pmc("pmc_WRITE_SIZE.csv"), pmc("pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv")
+traffic = {}
+for k in sorted(set(fetch) | set(write)):
+    fv = [v for v in fetch[k].get("FETCH_SIZE", []) if v > 0]
+    wv = [v for v in write[k].get("WRITE_SIZE", []) if v > 0]
+    rd = 2.0 * 1024 * (sum(fv) / len(fv)) if fv else 0.0
+    wr = 1024 * (sum(wv) / len(wv)) if wv else 0.0
+    traffic[k] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
+sk = [k for k in traffic if "::scores_kernel" in k]
+out = {"note": "HBM bytes per launch; FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1; KiB -> bytes",
+       "per_kernel": traffic,
+       "scores_kernel_hbm_bytes_per_launch": traffic[sk[0]]["total_bytes"] if sk else None}
+json.dump(out, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
+
+bench = {}
+for line in open(os.path.join(src, "stats_bench.log")):
+    if line.startswith("{"):
+        bench = json.loads(line)
+with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
+    f.write("# rocprofv3 summary, round %s\n\n" % tag)
+    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline` "
+            "(N=1 004 993, Q=70, D=2048 fp32, 20 timed + 3 warm-up steps); PMC passes in separate runs "
+            "(`tools/profile_round.sh`).\n\n")
+    if bench:
+        f.write("bench line under the profiler: %.1f queries/s, %.4f ms/step; scores kernel by HIP events %.4f ms "
+                "(%.1f TFLOP/s = %.1f %% of 157.3).\n\n" % (bench["value"], bench["ms_per_step"],
+                                                           bench["roofline"]["kernel_ms"], bench["roofline"]["achieved"],
+                                                           100 * bench["roofline"]["frac"]))
+    f.write("| kernel | calls | avg us | total ms | HBM read MB/launch | HBM write MB/launch |\n|---|---:|---:|---:|---:|---:|\n")
+    for r in keep:
+        k = short(r["Name"])
+        t = traffic.get(k, {})
+        f.write("| `%s` | %s | %.1f | %.2f | %s | %s |\n" % (
+            k, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6,
+            "%.1f" % (t["read_bytes"] / 1e6) if t else "-", "%.1f" % (t["write_bytes"] / 1e6) if t else "-"))
+    if sq:
+        f.write("\n## SQ counters, scores kernel (per launch, averaged)\n\n")
+        for k in sq:
+            if "::scores_kernel" in k:
+                c = {n: sum(v) / len(v) for n, v in sq[k].items()}
+                f.write("```\n" + "\n".join("%-28s %.4g" % kv for kv in sorted(c.items())) + "\n```\n")
+                if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                    cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+                    f.write("\nMFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) = %.1f %%\n"
+                            % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc))
+print(open(os.path.join(dst, tag + "_summary.md")).read())
