@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdx.so")
+LIB_PATH = os.environ.get("MDIR_AMD_LIB") or os.path.join(_HERE, "libmdx.so")   # override: A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 MDX_DIM_MAJOR, MDX_ROW_MAJOR = 0, 1

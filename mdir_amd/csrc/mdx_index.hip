@@ -64,29 +64,57 @@ __global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ s
     tiles[(rt * KB + kb) * 64 + lane] = v;
 }
 
-// NW waves per workgroup, one row tile per wave.
+// Large shards: loader/consumer kernel (4 MFMA waves + 4 LDS-DMA loader waves), R = 2 row
+// tiles per consumer, chunks of 32 k, ring of 3 stages ((QT+8)*6 KiB of LDS).
+constexpr int LC_R = 2, LC_KC = 2, LC_NSTAGE = 3;
+
+template <int QT>
+static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
+                            int KB, int nq_valid, hipStream_t s)
+{
+    auto kern = scores_lc_kernel<QT, LC_R, LC_KC, LC_NSTAGE>;
+    constexpr int lds = LC_NSTAGE * (QT + 4 * LC_R) * LC_KC * 1024;
+    static bool configured = false;     // per instantiation; benign if two threads race
+    if (!configured) {
+        MDX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    const int64_t blocks = ceil_div(RT, (int64_t)4 * LC_R);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, db, qt, out, n, KB, nq_valid);
+    return MDX_OK;
+}
+
+// Small shards: NW-wave workgroups of the register-streaming kernel, one row tile per wave.
 template <int QT, int NW>
-static void launch_scores(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
-                          int KB, int nq_valid, hipStream_t s)
+static int launch_scores_small(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
+                               int KB, int nq_valid, hipStream_t s)
 {
     const int64_t blocks = ceil_div(RT, (int64_t)NW);
     hipLaunchKernelGGL((scores_kernel<QT, 1, 0, false, true, 3, 2, false, NW>), dim3((unsigned)blocks),
-                       dim3(NW * 64), 0, s, db, qt, out, n, KB, nq_valid, (int64_t)0);
+                       dim3(NW * 64), 0, s, db, qt, out, n, KB, nq_valid, (int64_t)0, nullptr);
+    return MDX_OK;
 }
 
-template <int NW>
-static void dispatch_qt(int qt, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
-                        int KB, int nq_valid, hipStream_t s)
+template <int QT>
+static int launch_qt(bool small, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
+                     int KB, int nq_valid, hipStream_t s)
+{
+    return small ? launch_scores_small<QT, 4>(db, q, out, n, RT, KB, nq_valid, s)
+                 : launch_scores_lc<QT>(db, q, out, n, RT, KB, nq_valid, s);
+}
+
+static int dispatch_qt(int qt, bool small, const f32x4 *db, const f32x4 *q, float *out, int64_t n,
+                       int64_t RT, int KB, int nq_valid, hipStream_t s)
 {
     switch (qt) {
-        case 1: launch_scores<1, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 2: launch_scores<2, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 3: launch_scores<3, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 4: launch_scores<4, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 5: launch_scores<5, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 6: launch_scores<6, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
-        case 7: launch_scores<7, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
-        default: launch_scores<8, NW>(db, q, out, n, RT, KB, nq_valid, s); break;
+        case 1: return launch_qt<1>(small, db, q, out, n, RT, KB, nq_valid, s);
+        case 2: return launch_qt<2>(small, db, q, out, n, RT, KB, nq_valid, s);
+        case 3: return launch_qt<3>(small, db, q, out, n, RT, KB, nq_valid, s);
+        case 4: return launch_qt<4>(small, db, q, out, n, RT, KB, nq_valid, s);
+        case 5: return launch_qt<5>(small, db, q, out, n, RT, KB, nq_valid, s);
+        case 6: return launch_qt<6>(small, db, q, out, n, RT, KB, nq_valid, s);
+        case 7: return launch_qt<7>(small, db, q, out, n, RT, KB, nq_valid, s);
+        default: return launch_qt<8>(small, db, q, out, n, RT, KB, nq_valid, s);
     }
 }
 
@@ -203,7 +231,8 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
     int rc = retile(queries, nq, ix->d, qlayout, center, qtiles, QT_total, ix->KB, s);
     if (rc != MDX_OK) return rc;
 
-    // Small shards: 4-wave workgroups so that more CUs get work.
+    // Small shards (fewer than ~2 workgroups of 128 rows per CU): 64-row workgroups of the
+    // register-streaming kernel so that more CUs get work.
     const bool small = ix->RT < 256 * 8 * 2;
     for (int64_t qt0 = 0; qt0 < QT_total; qt0 += MAX_QT) {
         const int qt = (int)((QT_total - qt0) < MAX_QT ? (QT_total - qt0) : MAX_QT);
@@ -211,8 +240,8 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
         const int nq_valid = (int)((nq - q0) < qt * TILE_ROWS ? (nq - q0) : qt * TILE_ROWS);
         const f32x4 *qp = qtiles + qt0 * ix->KB * 64;
         float *op = scores + q0 * ix->n;
-        if (small) dispatch_qt<4>(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
-        else       dispatch_qt<8>(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        rc = dispatch_qt(qt, small, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK();
     }
     return MDX_OK;

@@ -13,7 +13,12 @@
 namespace mdx {
 
 constexpr int SORT_ITEMS = 16;                 // elements per lane
-constexpr int SORT_TILE = 256 * SORT_ITEMS;    // elements per workgroup
+#ifndef MDX_SORT_WAVES
+#define MDX_SORT_WAVES 8
+#endif
+constexpr int SORT_WAVES = MDX_SORT_WAVES;     // waves per workgroup
+constexpr int SORT_THREADS = 64 * SORT_WAVES;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // elements per workgroup
 constexpr int SUB_TILE = 64 * SORT_ITEMS;      // elements per wave
 constexpr int RADIX = 256;
 
@@ -25,29 +30,33 @@ __device__ __forceinline__ uint32_t load_key(const float *scores, const uint32_t
 
 // per-tile digit histogram -> block_hist[q][b][digit]
 template <bool FIRST>
-__global__ __launch_bounds__(256) void sort_hist_kernel(const float *__restrict__ scores,
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__restrict__ scores,
                                                         const uint32_t *__restrict__ keys,
                                                         int64_t n, int nblk, int shift,
                                                         uint32_t *__restrict__ block_hist)
 {
-    __shared__ uint32_t h[4][RADIX];
+    __shared__ uint32_t h[SORT_WAVES][RADIX];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int64_t q = blockIdx.y, b = blockIdx.x;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) h[w][tid] = 0;
+    for (int e = tid; e < SORT_WAVES * RADIX; e += SORT_THREADS) (&h[0][0])[e] = 0;
     __syncthreads();
     const int64_t base = q * n;
     const int64_t t0 = b * SORT_TILE;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int64_t i = t0 + r * 256 + tid;
+        const int64_t i = t0 + r * SORT_THREADS + tid;
         if (i < n) {
             const uint32_t k = load_key(scores, keys, base + i, FIRST);
             atomicAdd(&h[wave][(k >> shift) & 255u], 1u);
         }
     }
     __syncthreads();
-    block_hist[(q * nblk + b) * RADIX + tid] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    if (tid < RADIX) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) tot += h[w][tid];
+        block_hist[(q * nblk + b) * RADIX + tid] = tot;
+    }
 }
 
 // per query: exclusive prefix over tiles for each digit (in place) + digit bases
@@ -91,22 +100,21 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ b
 // tile is then put in digit order in LDS, so that consecutive lanes write
 // consecutive global addresses inside each digit run (coalesced scatter).
 template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(256) void sort_scatter_kernel(
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
     const float *__restrict__ scores, const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, int64_t *__restrict__ ranks, float *__restrict__ top_scores,
     int64_t n, int nblk, int shift, const uint32_t *__restrict__ block_hist,
     const uint32_t *__restrict__ digit_base, int64_t id_offset, int64_t klimit)
 {
-    __shared__ uint32_t wcnt[4][RADIX];     // per-wave digit counts, then tile-local offsets
+    __shared__ uint32_t wcnt[SORT_WAVES][RADIX];     // per-wave digit counts, then tile-local offsets
     __shared__ uint32_t gdelta[RADIX];      // global position of a digit run minus its tile offset
     __shared__ uint32_t scan[RADIX];
     __shared__ uint32_t skey[SORT_TILE];
     __shared__ uint32_t sval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.y, b = blockIdx.x;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+    for (int e = tid; e < SORT_WAVES * RADIX; e += SORT_THREADS) (&wcnt[0][0])[e] = 0;
     __syncthreads();
 
     const int64_t base = q * n;
@@ -143,22 +151,30 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(
     }
     __syncthreads();
     // thread = digit: tile count, exclusive scan over digits, per-wave tile offsets
-    const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-    const uint32_t tot = c0 + c1 + c2 + c3;
-    scan[tid] = tot;
+    uint32_t tot = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) tot += wcnt[w][tid];
+        scan[tid] = tot;
+    }
     __syncthreads();
     for (int off = 1; off < RADIX; off <<= 1) {
-        const uint32_t v = tid >= off ? scan[tid - off] : 0u;
+        const uint32_t v = (tid < RADIX && tid >= off) ? scan[tid - off] : 0u;
         __syncthreads();
-        scan[tid] += v;
+        if (tid < RADIX) scan[tid] += v;
         __syncthreads();
     }
-    const uint32_t toff = scan[tid] - tot;                 // first slot of this digit in the tile
-    wcnt[0][tid] = toff;
-    wcnt[1][tid] = toff + c0;
-    wcnt[2][tid] = toff + c0 + c1;
-    wcnt[3][tid] = toff + c0 + c1 + c2;
-    gdelta[tid] = digit_base[q * RADIX + tid] + block_hist[(q * nblk + b) * RADIX + tid] - toff;
+    if (tid < RADIX) {
+        const uint32_t toff = scan[tid] - tot;             // first slot of this digit in the tile
+        uint32_t run = toff;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const uint32_t c = wcnt[w][tid];
+            wcnt[w][tid] = run;
+            run += c;
+        }
+        gdelta[tid] = digit_base[q * RADIX + tid] + block_hist[(q * nblk + b) * RADIX + tid] - toff;
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int i = r * 256 + tid;
+        const int i = r * SORT_THREADS + tid;
         if (i >= tile_n) continue;
         const uint32_t k = skey[i], v = sval[i];
         const int64_t dst = (int64_t)(uint32_t)(gdelta[(k >> shift) & 255u] + (uint32_t)i);
@@ -302,7 +318,7 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
     }
     RankWs ws;
     carve(&ws, (char *)workspace, n, nq);
-    const dim3 grid((unsigned)ws.nblk, (unsigned)nq), blk(256);
+    const dim3 grid((unsigned)ws.nblk, (unsigned)nq), blk(SORT_THREADS);
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 8 * pass;
         const uint32_t *kin = pass == 0 ? nullptr : ws.keys[(pass - 1) & 1];
@@ -314,7 +330,7 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
         else
             hipLaunchKernelGGL(sort_hist_kernel<false>, grid, blk, 0, s, scores, kin, n, ws.nblk,
                                shift, ws.block_hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)nq), blk, 0, s, ws.block_hist, ws.nblk,
+        hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)nq), dim3(256), 0, s, ws.block_hist, ws.nblk,
                            ws.digit_base);
         if (pass == 0)
             hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, blk, 0, s, scores, kin, vin,

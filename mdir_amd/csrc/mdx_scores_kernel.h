@@ -28,13 +28,23 @@ constexpr int MAX_QT = 8;       // query tiles (of 16) per launch
 // ABL != 0 builds timing-only ablations for tools/scores_ablate.hip (wrong results):
 //   bit0: no database loads in the loop, bit1: no query staging in the loop,
 //   bit2: no barrier, bit3: no MFMA, bit4: no explicit "set has landed" marker.
-template <int QT, int R, int ABL = 0, bool CM = false, bool NT = true, int NS = 3, int WPS = 2, bool SPREAD = false, int NW = 8>
+template <int QT, int R, int ABL = 0, bool CM = false, bool NT = true, int NS = 3, int WPS = 2, bool SPREAD = false, int NW = 8, int KC = KBC>
 __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__restrict__ db,
                                                      const f32x4 *__restrict__ qtiles,
                                                      float *__restrict__ out, int64_t n, int KB,
-                                                     int nq_valid, int64_t RTS = 0)
+                                                     int nq_valid, int64_t RTS = 0, unsigned long long *dbg = nullptr)
 {
-    constexpr int CHUNK4 = QT * KBC * 64;          // float4 per LDS buffer
+    // ABL bit5: in-kernel cycle stamps (diagnostic build only; sums per segment go to dbg)
+    unsigned long long t_bar = 0, t_land = 0, t_issue = 0, t_mfma = 0, t_stq = 0, ts0 = 0, ts1 = 0;
+#define MDX_STAMP(acc_)                                                              \
+    if (ABL & 32) {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        acc_ += ts1 - ts0; ts0 = ts1;                                                \
+    }
+
+    constexpr int CHUNK4 = QT * KC * 64;          // float4 per LDS buffer
     constexpr int NT_ = NW * 64;                              // threads per workgroup
     constexpr int COPIES = (CHUNK4 + NT_ - 1) / NT_;          // float4 per thread per chunk
     __shared__ f32x4 lds[2][CHUNK4];
@@ -43,12 +53,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int64_t rt0 = ((int64_t)blockIdx.x * NW + wave) * R;
-    const int nchunks = KB / KBC;
+    const int nchunks = KB / KC;
 
     const f32x4 *bp[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) bp[r] = db + (CM ? (rt0 + r) * KBC : (rt0 + r) * KB) * 64 + lane;
-    const int64_t cstride = CM ? RTS * KBC * 64 : KBC * 64;     // float4 between consecutive chunks
+    for (int r = 0; r < R; ++r) bp[r] = db + (CM ? (rt0 + r) * KC : (rt0 + r) * KB) * 64 + lane;
+    const int64_t cstride = CM ? RTS * KC * 64 : KC * 64;     // float4 between consecutive chunks
 
     // per-thread source offsets of the query-chunk copy (chunk 0), in float4
     int qsrc[COPIES];
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
     for (int i = 0; i < COPIES; ++i) {
         const int e = (tid + i * NT_) < CHUNK4 ? (tid + i * NT_) : 0;
         const int tl = e >> 6, ln = e & 63;
-        const int qt = tl / KBC, kbc = tl % KBC;
+        const int qt = tl / KC, kbc = tl % KC;
         qsrc[i] = (qt * KB + kbc) * 64 + ln;
     }
 
@@ -69,24 +79,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
     // Ring of NS statically indexed register sets for the database stream: while chunk c
     // is multiplied out of set c % NS, chunks c+1 .. c+NS-1 are in flight or landed, so
     // the only wait in steady state is for data requested NS-1 chunks (~5k cycles each) ago.
-    f32x4 b[NS][R][KBC], qreg[COPIES];
+    f32x4 b[NS][R][KC], qreg[COPIES];
 
 #define MDX_LOAD_B(set, c)                                                          \
     _Pragma("unroll") for (int r = 0; r < R; ++r)                                   \
-        _Pragma("unroll") for (int kb = 0; kb < KBC; ++kb)                          \
+        _Pragma("unroll") for (int kb = 0; kb < KC; ++kb)                          \
             b[set][r][kb] = NT ? __builtin_nontemporal_load(&bp[r][(c) * cstride + kb * 64]) \
                                : bp[r][(c) * cstride + kb * 64];
 #define MDX_LOAD_Q(c)                                                               \
     _Pragma("unroll") for (int i = 0; i < COPIES; ++i)                              \
-        qreg[i] = qtiles[qsrc[i] + (c) * KBC * 64];
+        qreg[i] = qtiles[qsrc[i] + (c) * KC * 64];
 #define MDX_STORE_Q(buf)                                                            \
     _Pragma("unroll") for (int i = 0; i < COPIES; ++i)                              \
         if (CHUNK4 % NT_ == 0 || tid + i * NT_ < CHUNK4) lds[buf][tid + i * NT_] = qreg[i];
 #define MDX_COMPUTE(buf, set)                                                       \
-    _Pragma("unroll") for (int kb = 0; kb < KBC; ++kb) {                            \
+    _Pragma("unroll") for (int kb = 0; kb < KC; ++kb) {                            \
         f32x4 a[QT];                                                                \
         _Pragma("unroll") for (int q = 0; q < QT; ++q)                              \
-            a[q] = lds[buf][(q * KBC + kb) * 64 + lane];                            \
+            a[q] = lds[buf][(q * KC + kb) * 64 + lane];                            \
         _Pragma("unroll") for (int t = 0; t < 4; ++t)                               \
             _Pragma("unroll") for (int r = 0; r < R; ++r)                           \
                 _Pragma("unroll") for (int q = 0; q < QT; ++q)                      \
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
     {                                                                               \
         f32x4 a[QT];                                                                \
         _Pragma("unroll") for (int q = 0; q < QT; ++q)                              \
-            a[q] = lds[buf][(q * KBC + kb) * 64 + lane];                            \
+            a[q] = lds[buf][(q * KC + kb) * 64 + lane];                            \
         if (do_b) {                                                                 \
             _Pragma("unroll") for (int r = 0; r < R; ++r)                           \
                 b[(set + NS - 1) % NS][r][kb] =                                     \
@@ -109,8 +119,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
                        : bp[r][((c) + NS - 1) * cstride + kb * 64];                 \
         }                                                                           \
         if (do_q) {                                                                 \
-            _Pragma("unroll") for (int i = kb; i < COPIES; i += KBC)                \
-                qreg[i] = qtiles[qsrc[i] + ((c) + 1) * KBC * 64];                   \
+            _Pragma("unroll") for (int i = kb; i < COPIES; i += KC)                \
+                qreg[i] = qtiles[qsrc[i] + ((c) + 1) * KC * 64];                   \
         }                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                          \
         _Pragma("unroll") for (int t = 0; t < 4; ++t)                               \
@@ -146,7 +156,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
                 if (moreq) { MDX_STORE_Q((c + 1) & 1); }
                 continue;
             }
+            MDX_STAMP(t_stq)
             if (!(ABL & 4)) __syncthreads();
+            MDX_STAMP(t_bar)
             // Make "set s has landed" explicit BEFORE new loads are issued: the empty asm
             // uses every register of the set, so the compiler's wait for them sits here,
             // where nothing younger is in flight (they were requested NS-1 chunks ago).
@@ -156,11 +168,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int kb = 0; kb < KBC; ++kb) asm volatile("" : "+v"(b[s][r][kb]));
+                    for (int kb = 0; kb < KC; ++kb) asm volatile("" : "+v"(b[s][r][kb]));
             }
+            MDX_STAMP(t_land)
             if (moreq && !(ABL & 2)) { MDX_LOAD_Q(c + 1); }
             if (c + NS - 1 < nchunks && !(ABL & 1)) { MDX_LOAD_B((s + NS - 1) % NS, c + NS - 1); }
+            MDX_STAMP(t_issue)
             if (!(ABL & 8)) { MDX_COMPUTE(c & 1, s); }
+            MDX_STAMP(t_mfma)
             if (moreq && !(ABL & 2)) { MDX_STORE_Q((c + 1) & 1); }
         }
     }
@@ -170,8 +185,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int kb = 0; kb < KBC; ++kb) acc[r][0] += b[s][r][kb];
+                for (int kb = 0; kb < KC; ++kb) acc[r][0] += b[s][r][kb];
     }
+    if ((ABL & 32) && dbg && lane == 0) {
+        unsigned long long *d = dbg + ((int64_t)blockIdx.x * NW + wave) * 8;
+        d[0] = t_bar; d[1] = t_land; d[2] = t_issue; d[3] = t_mfma; d[4] = t_stq;
+    }
+#undef MDX_STAMP
 #undef MDX_LOAD_B
 #undef MDX_LOAD_Q
 #undef MDX_STORE_Q
@@ -184,6 +204,136 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t row = (rt0 + r) * TILE_ROWS + col;
+        if (row >= n) continue;
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qi = q * 16 + qrow + i;
+                if (qi < nq_valid) out[(int64_t)qi * n + row] = acc[r][q][i];
+            }
+    }
+}
+
+
+// ===========================================================================
+// Loader / consumer form of the similarity kernel.
+//
+// In-kernel stamps on the kernel above (tools/scores_ablate.hip) show where it loses
+// time: a wave spends about a third of its life BLOCKED ISSUING its global loads (a CU
+// holds only a few tens of KiB of reads in flight, so later load instructions stall at
+// issue), and a wave stalled on VMEM issue cannot issue MFMAs.  Here the roles are split:
+//   waves 0-3  (one per SIMD)  consumers: LDS reads + fp32 MFMA only, never touch VMEM
+//                              until the epilogue; each owns R row tiles x all QT query tiles
+//   waves 4-7                  loaders: stream the NEXT chunks of the database tiles and
+//                              of the query tiles into an LDS ring with LDS-DMA
+//                              (global_load_lds_dwordx4: 1 KiB per instruction, lane-linear,
+//                              exactly the tile format), then wait with a COUNTED vmcnt
+// One raw s_barrier per chunk; ring of NSTAGE stages, a stage = (QT + 4R) x KC KiB.
+// B_c = "stage c landed": loaders arrive after vmcnt says stage c is complete, consumers
+// then read it; the slot of stage c-1 is refilled right after B_c (every consumer has
+// finished chunk c-1 by then).  Accumulation order per output is unchanged (k ascending).
+// ===========================================================================
+template <int QT, int R, int KC, int NSTAGE>
+__global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restrict__ db,
+                                                           const f32x4 *__restrict__ qtiles,
+                                                           float *__restrict__ out, int64_t n, int KB,
+                                                           int nq_valid)
+{
+    constexpr int CW = 4;                           // consumer waves
+    constexpr int LW = 4;                           // loader waves
+    constexpr int QTILES = QT * KC;                 // KiB tiles of queries per stage
+    constexpr int BTILES = CW * R * KC;             // KiB tiles of database per stage
+    constexpr int STAGE_TILES = QTILES + BTILES;
+    constexpr int PER_LOADER = (STAGE_TILES + LW - 1) / LW;   // uneven split: the last tile is loaded twice
+    static_assert((NSTAGE - 1) * PER_LOADER <= 63, "vmcnt is 6 bits");
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];   // [NSTAGE][STAGE_TILES][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = KB / KC;
+    const int64_t rt_wg = (int64_t)blockIdx.x * CW * R;            // first row tile of the workgroup
+
+    if (wave >= CW) {
+        // ------------------------------------------------------------- loader
+        const int lw = wave - CW;
+        // this loader's tiles of a stage: i = lw, lw+LW, ...  (query tiles first)
+        const f32x4 *src[PER_LOADER];
+        int dst[PER_LOADER];
+#pragma unroll
+        for (int t = 0; t < PER_LOADER; ++t) {
+            const int i = (lw + t * LW) < STAGE_TILES ? (lw + t * LW) : (STAGE_TILES - 1);
+            dst[t] = i * 64;
+            if (i < QTILES) {
+                const int qt = i / KC, kbc = i % KC;
+                src[t] = qtiles + ((int64_t)qt * KB + kbc) * 64 + lane;
+            } else {
+                const int j = i - QTILES;
+                const int tile = j / KC, kbc = j % KC;              // tile = cw * R + r
+                src[t] = db + ((rt_wg + tile) * KB + kbc) * 64 + lane;
+            }
+        }
+        auto issue = [&](int c) {
+            f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
+#pragma unroll
+            for (int t = 0; t < PER_LOADER; ++t)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src[t] + (int64_t)c * KC * 64),
+                    (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, 0);
+        };
+#pragma unroll
+        for (int c = 0; c < NSTAGE - 1; ++c)
+            if (c < nchunks) issue(c);
+        for (int c = 0; c < nchunks; ++c) {
+            // stage c must have landed: everything but the younger stages c+1 .. c+NSTAGE-2
+            const int younger = (nchunks - 1 - c) < (NSTAGE - 2) ? (nchunks - 1 - c) : (NSTAGE - 2);
+            if (younger >= NSTAGE - 2 && NSTAGE > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PER_LOADER) : "memory");
+            else if (younger == 1 && NSTAGE > 3)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_LOADER) : "memory");
+            else                                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                   // B_c
+            if (c + NSTAGE - 1 < nchunks) issue(c + NSTAGE - 1);            // refill the slot of stage c-1
+        }
+        return;
+    }
+
+    // ----------------------------------------------------------------- consumer
+    f32x4 acc[R][QT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < QT; ++q) acc[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < nchunks; ++c) {
+        __builtin_amdgcn_s_barrier();                                       // B_c
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
+        const f32x4 *qs = slot + lane;
+        const f32x4 *bs = slot + (QTILES + wave * R * KC) * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < KC; ++kb) {
+            f32x4 a[QT], b[R];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) a[q] = qs[(q * KC + kb) * 64];
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = bs[(r * KC + kb) * 64];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int q = 0; q < QT; ++q)
+                        acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][t], b[r][t], acc[r][q], 0, 0, 0);
+        }
+        // all LDS reads of this stage are consumed by the MFMAs above before the next barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    const int qrow = 4 * (lane >> 4);
+    const int64_t col = lane & 15;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (rt_wg + wave * R + r) * TILE_ROWS + col;
         if (row >= n) continue;
 #pragma unroll
         for (int q = 0; q < QT; ++q)

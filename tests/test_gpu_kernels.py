@@ -31,8 +31,11 @@ def _unit_rows(rng, n, d):
     return v / np.linalg.norm(v, axis=1, keepdims=True)
 
 
+# n >= 65536 takes the loader/consumer kernel (LDS-DMA ring), smaller shards the register-streaming one
 @pytest.mark.parametrize("n,d,nq", [(4993, 2048, 70), (1000, 512, 1), (333, 100, 17), (16, 64, 16),
-                                    (5000, 256, 130), (70, 2048, 70)])
+                                    (5000, 256, 130), (70, 2048, 70),
+                                    (70000, 64, 1), (66001, 100, 17), (70001, 256, 130), (65600, 2048, 70),
+                                    (65537, 32, 128), (131072, 96, 33)])
 def test_scores_bit_exact_vs_chain(ops, n, d, nq):
     rng = np.random.default_rng(n + d + nq)
     db, qv = _unit_rows(rng, n, d), _unit_rows(rng, nq, d)

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Descriptors/sec of the extraction path on one GPU (BASELINE.json configs[1]/[4] shape):
+ResNet101-GeM (or VGG16-GeM), random weights, synthetic 1024x768 images already resident on the
+device, 3-scale pyramid + learned whitening through the mdir wrapper chain
+(0_cirwhiten + 1_cirmultiscale), descriptors written to one device [N,D] buffer.
+
+Reports the split the hand-written part is responsible for: backbone (PyTorch-ROCm/MIOpen) vs
+descriptor tail (mdx_pool_l2n, mdx_ms_aggregate, mdx_scores(P)+mdx_l2n_rows), measured with HIP
+events on the current stream, and the same tail expressed with stock torch ops (the reference's
+LF.gem / LF.l2n / aggregate_tensor / CirtorchWhiten.postprocess statements) for comparison.
+
+    python tools/bench_extract.py [--arch resnet101] [--images 30] [--fp16-backbone]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--images", type=int, default=30)
+    ap.add_argument("--channels-last", action="store_true")
+    args = ap.parse_args()
+    from mdir_amd import ops
+    from mdir_amd.networks import init_network
+    from mdir_amd.wrapper import initialize_wrappers
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = init_network({"architecture": args.arch, "pooling": "gem", "whitening": False, "pretrained": False})
+    net.meta["in_channels"], net.meta["out_channels"] = 3, net.meta["outputdim"]
+    net = net.to(dev).eval()
+    if args.channels_last:
+        net.features = net.features.to(memory_format=torch.channels_last)
+    D = net.meta["outputdim"]
+    rng = np.random.default_rng(2)
+    q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    wh = {"P": (q * rng.uniform(0.5, 2.0, (1, D))).T.copy(), "m": rng.normal(0, 0.01, (D, 1))}
+    chain = initialize_wrappers({"0_cirwhiten": {"whitening": wh, "dimensions": None},
+                                 "1_cirmultiscale": {"scales": True}}, dev)
+    imgs = [torch.randn(1, 3, 768, 1024, device=dev) for _ in range(4)]
+    vecs = torch.empty(args.images, D, device=dev)
+    P32 = torch.tensor(wh["P"], dtype=torch.float32, device=dev)
+    m32 = torch.tensor(wh["m"], dtype=torch.float32, device=dev)
+
+    def run(n):
+        for i in range(n):
+            vecs[i % args.images].copy_(chain(imgs[i % 4], net).reshape(-1))
+
+    with torch.no_grad():
+        run(3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.images)
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+
+        # split: features only / tail only (on precomputed feature maps)
+        pyr = [F.interpolate(imgs[0], scale_factor=s, mode="bilinear", align_corners=False) if s != 1 else imgs[0]
+               for s in chain.wrappers[1].scales]
+        feats = [net.features(x).contiguous() for x in pyr]
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        reps = 20
+
+        def timeit(fn):
+            fn(); torch.cuda.synchronize()
+            a, b = ev(), ev()
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps
+
+        t_backbone = timeit(lambda: [net.features(x) for x in pyr])
+        p = net.pool.p_value()
+
+        def tail_mdx():
+            per = [ops.pool_l2n(f, "gem", p, 1e-6, 1e-6).reshape(-1) for f in feats]
+            v = ops.ms_aggregate(per, p)
+            return chain.wrappers[0].whiten_rows(v.reshape(1, -1))
+
+        def tail_torch():   # the reference's statements with stock torch ops
+            per = []
+            for f in feats:
+                o = F.avg_pool2d(f.clamp(min=1e-6).pow(p), (f.size(-2), f.size(-1))).pow(1. / p)
+                per.append((o / (torch.norm(o, p=2, dim=1, keepdim=True) + 1e-6)).squeeze(-1).squeeze(-1).permute(1, 0))
+            v = torch.zeros(D, device=dev)
+            for s in per:
+                v += s.pow(p).squeeze()
+            v = (v / len(per)).pow(1. / p)
+            v /= v.norm()
+            X = P32.mm(v.unsqueeze(1).sub(m32))
+            return X.div(torch.norm(X, p=2, dim=0, keepdim=True) + 1e-6).squeeze()
+
+        a, b = tail_mdx().reshape(-1), tail_torch().reshape(-1)
+        err = float((a - b).abs().max())
+        t_tail, t_tail_torch = timeit(tail_mdx), timeit(tail_torch)
+    print(json.dumps({"metric": "descriptors/sec, %s-GeM, 3 scales of 1024x768 + whitening, 1 GPU" % args.arch,
+                      "value": round(args.images / total, 2), "unit": "descriptors/s",
+                      "ms_per_image": round(1e3 * total / args.images, 3),
+                      "backbone_ms_per_image": round(t_backbone, 3),
+                      "tail_ms_per_image_mdx": round(t_tail, 4), "tail_ms_per_image_torch_ops": round(t_tail_torch, 4),
+                      "tail_max_abs_diff_vs_torch_ops": err, "dtype": "f32", "data": "synthetic"}))
+
+
+main()

@@ -6,14 +6,14 @@
 namespace mdx { void set_error(const char *, ...) {} }
 using namespace mdx;
 
-template <int ABL, int R, bool CM = false, bool NT = false, int NS = 2, int WPS = 2, bool SP = false, int NW = 4>
+template <int ABL, int R, bool CM = false, bool NT = false, int NS = 2, int WPS = 2, bool SP = false, int NW = 4, int KC = 4>
 static float run(const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT, int KB, int reps)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int64_t blocks = (RT + NW * R - 1) / (NW * R);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((scores_kernel<5, R, ABL, CM, NT, NS, WPS, SP, NW>), dim3(blocks), dim3(NW * 64), 0, 0, db, q, out, n, KB, 70, (RT + 7) / 8 * 8);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((scores_kernel<5, R, ABL, CM, NT, NS, WPS, SP, NW, KC>), dim3(blocks), dim3(NW * 64), 0, 0, db, q, out, n, KB, 70, (RT + 7) / 8 * 8);
     hipEventRecord(a);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((scores_kernel<5, R, ABL, CM, NT, NS, WPS, SP, NW>), dim3(blocks), dim3(NW * 64), 0, 0, db, q, out, n, KB, 70, (RT + 7) / 8 * 8);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((scores_kernel<5, R, ABL, CM, NT, NS, WPS, SP, NW, KC>), dim3(blocks), dim3(NW * 64), 0, 0, db, q, out, n, KB, 70, (RT + 7) / 8 * 8);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     return ms / reps;
@@ -24,15 +24,32 @@ int main()
     const int64_t n = 1004993, d = 2048; const int KB = d / 16;
     const int64_t RT = (n + 15) / 16, RTp = (RT + 7) / 8 * 8;
     f32x4 *db, *q; float *out;
-    hipMalloc(&db, (RTp + 64) * KB * 1024); hipMalloc(&q, 5 * KB * 1024); hipMalloc(&out, 70 * n * 4);
+    hipMalloc(&db, (RTp + 256) * KB * 1024); hipMalloc(&q, 5 * KB * 1024); hipMalloc(&out, 70 * n * 4);
     std::vector<float> h(RTp * KB * 256);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xFFFF) / 65536.0f - 0.5f;
     hipMemcpy(db, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(q, h.data(), 5 * KB * 1024, hipMemcpyHostToDevice);
-    printf("no-touch NT: NW4 R2 NS2 %.3f | NW8 R2 NS2 %.3f | NW8 R1 NS3 %.3f | NW8 R1 NS2 %.3f | NW8 R1 NS4 %.3f | NW4 R1 NS3 wps3 %.3f | touch NW8 R1 NS3 %.3f\n",
-           run<0, 2, false, true, 2, 2, false, 4>(db, q, out, n, RT, KB, 10), run<0, 2, false, true, 2, 2, false, 8>(db, q, out, n, RT, KB, 10),
-           run<0, 1, false, true, 3, 2, false, 8>(db, q, out, n, RT, KB, 10), run<0, 1, false, true, 2, 2, false, 8>(db, q, out, n, RT, KB, 10),
-           run<0, 1, false, true, 4, 2, false, 8>(db, q, out, n, RT, KB, 10), run<0, 1, false, true, 3, 3, false, 4>(db, q, out, n, RT, KB, 10),
-           run<16, 1, false, true, 3, 2, false, 8>(db, q, out, n, RT, KB, 10));
+    {
+        auto lc = [&](auto kern, int R_, int KC_, int NST, int QT_) {
+            const size_t lds = (size_t)NST * (QT_ + 4 * R_) * KC_ * 1024;
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const int64_t blocks = (RT + 4 * R_ - 1) / (4 * R_);
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70);
+            hipEventRecord(a);
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
+            return ms / 10;
+        };
+        for (int rep = 0; rep < 2; ++rep)
+        printf("v1 NW8 R1 NS3: %.3f | LC R2 KC4 NST3: %.3f | LC R2 KC4 NST2: %.3f | LC R4 KC2 NST3: %.3f | LC R4 KC2 NST2 %.3f | LC R2 KC2 NST3 %.3f | LC R2 KC2 NST4 %.3f\n",
+               run<0, 1, false, true, 3, 2, false, 8, 4>(db, q, out, n, RT, KB, 10),
+               lc(scores_lc_kernel<5, 2, 4, 3>, 2, 4, 3, 5), lc(scores_lc_kernel<5, 2, 4, 2>, 2, 4, 2, 5),
+               lc(scores_lc_kernel<5, 4, 2, 3>, 4, 2, 3, 5), lc(scores_lc_kernel<5, 4, 2, 2>, 4, 2, 2, 5),
+               lc(scores_lc_kernel<5, 2, 2, 3>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 2, 2, 4>, 2, 2, 4, 5));
+    }
     return 0;
 }
