@@ -329,19 +329,31 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
-    const int qrow = 4 * (lane >> 4);
-    const int64_t col = lane & 15;
+    // Epilogue: the ring is free now (loaders have left, consumers are past their last read);
+    // transpose the accumulators through LDS so that every query row of the workgroup's
+    // 64*R database rows leaves as one contiguous run (full cache lines instead of 64-B pieces).
+    constexpr int ROWS = CW * R * TILE_ROWS;        // database rows per workgroup
+    constexpr int LDW = ROWS + 4;                   // +4: the four 16-lane groups hit different banks
+    static_assert(QT * 16 * LDW * 4 <= NSTAGE * STAGE_TILES * 1024, "output staging must fit in the ring");
+    __builtin_amdgcn_s_barrier();
+    float *stage = (float *)ring;
+    {
+        const int qrow = 4 * (lane >> 4), col = lane & 15;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t row = (rt_wg + wave * R + r) * TILE_ROWS + col;
-        if (row >= n) continue;
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int q = 0; q < QT; ++q)
+            for (int q = 0; q < QT; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int qi = q * 16 + qrow + i;
-                if (qi < nq_valid) out[(int64_t)qi * n + row] = acc[r][q][i];
-            }
+                for (int i = 0; i < 4; ++i)
+                    stage[(q * 16 + qrow + i) * LDW + (wave * R + r) * TILE_ROWS + col] = acc[r][q][i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int64_t row0 = rt_wg * TILE_ROWS;
+    const int rows_valid = (int)((n - row0) < ROWS ? (n - row0) : ROWS);
+    for (int e = tid; e < nq_valid * ROWS; e += CW * 64) {
+        const int qi = e / ROWS, rr = e % ROWS;
+        if (rr < rows_valid) out[(int64_t)qi * n + row0 + rr] = stage[qi * LDW + rr];
     }
 }
 

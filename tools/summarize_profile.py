@@ -49,7 +49,7 @@ for k in sorted(set(fetch) | set(write)):
     rd = 2.0 * 1024 * (sum(fv) / len(fv)) if fv else 0.0
     wr = 1024 * (sum(wv) / len(wv)) if wv else 0.0
     traffic[k] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
-sk = [k for k in traffic if "::scores_kernel" in k]
+sk = [k for k in traffic if "::scores_" in k and "gather" not in k]
 out = {"note": "HBM bytes per launch; FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1; KiB -> bytes",
        "per_kernel": traffic,
        "scores_kernel_hbm_bytes_per_launch": traffic[sk[0]]["total_bytes"] if sk else None}
@@ -79,11 +79,12 @@ with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
     if sq:
         f.write("\n## SQ counters, scores kernel (per launch, averaged)\n\n")
         for k in sq:
-            if "::scores_kernel" in k:
+            if "::scores_" in k and "gather" not in k:
                 c = {n: sum(v) / len(v) for n, v in sq[k].items()}
                 f.write("```\n" + "\n".join("%-28s %.4g" % kv for kv in sorted(c.items())) + "\n```\n")
                 if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
                     cyc = c["GRBM_GUI_ACTIVE"] / 8.0
-                    f.write("\nMFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) = %.1f %%\n"
-                            % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc))
+                    f.write("\nMFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) = %.1f %%; "
+                            "GRBM_GUI_ACTIVE/8 = %.3g cycles per launch (sustained clock = that / the launch's duration "
+                            "in the counter pass, see pmc csv)\n" % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, cyc))
 print(open(os.path.join(dst, tag + "_summary.md")).read())
