@@ -12,7 +12,10 @@
 
 namespace mdx {
 
-constexpr int SORT_ITEMS = 16;                 // elements per lane
+#ifndef MDX_SORT_ITEMS
+#define MDX_SORT_ITEMS 16
+#endif
+constexpr int SORT_ITEMS = MDX_SORT_ITEMS;     // elements per lane
 #ifndef MDX_SORT_WAVES
 #define MDX_SORT_WAVES 8
 #endif
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ b
 // tile is then put in digit order in LDS, so that consecutive lanes write
 // consecutive global addresses inside each digit run (coalesced scatter).
 template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
+__global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : SORT_WAVES / 2)) void sort_scatter_kernel(
     const float *__restrict__ scores, const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, int64_t *__restrict__ ranks, float *__restrict__ top_scores,
@@ -113,7 +116,17 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
     __shared__ uint32_t skey[SORT_TILE];
     __shared__ uint32_t sval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t q = blockIdx.y, b = blockIdx.x;
+    const int64_t q = blockIdx.y;
+    // Neighbouring tiles end their digit runs in the same cache lines.  Workgroups are dealt
+    // round-robin over the 8 XCDs (speed only, never correctness), so give each XCD a
+    // contiguous range of tiles: partial lines then meet in one L2 instead of two.
+    int64_t b = blockIdx.x;
+#ifndef MDX_SORT_NO_XCD
+    {
+        const int qn = nblk / 8, rn = nblk % 8, x = (int)(blockIdx.x % 8), k = (int)(blockIdx.x / 8);
+        b = (x < rn ? (int64_t)x * (qn + 1) : (int64_t)rn * (qn + 1) + (int64_t)(x - rn) * qn) + k;
+    }
+#endif
     for (int e = tid; e < SORT_WAVES * RADIX; e += SORT_THREADS) (&wcnt[0][0])[e] = 0;
     __syncthreads();
 
@@ -129,6 +142,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
         key[r] = valid ? load_key(scores, keys_in, base + i, FIRST) : 0xFFFFFFFFu;
         val[r] = FIRST ? (uint32_t)i : (valid ? vals_in[base + i] : 0u);
     }
+    // global start of every digit run of this tile: requested now, needed after the ranking
+    const uint32_t gbase = tid < RADIX ? digit_base[q * RADIX + tid] + block_hist[(q * nblk + b) * RADIX + tid] : 0u;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -150,30 +165,39 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
         pos[r] = old + rank;
     }
     __syncthreads();
-    // thread = digit: tile count, exclusive scan over digits, per-wave tile offsets
-    uint32_t tot = 0;
+    // per digit: tile count and per-wave offsets inside the digit (thread = digit)
     if (tid < RADIX) {
-#pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) tot += wcnt[w][tid];
-        scan[tid] = tot;
-    }
-    __syncthreads();
-    for (int off = 1; off < RADIX; off <<= 1) {
-        const uint32_t v = (tid < RADIX && tid >= off) ? scan[tid - off] : 0u;
-        __syncthreads();
-        if (tid < RADIX) scan[tid] += v;
-        __syncthreads();
-    }
-    if (tid < RADIX) {
-        const uint32_t toff = scan[tid] - tot;             // first slot of this digit in the tile
-        uint32_t run = toff;
+        uint32_t run = 0;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) {
             const uint32_t c = wcnt[w][tid];
             wcnt[w][tid] = run;
             run += c;
         }
-        gdelta[tid] = digit_base[q * RADIX + tid] + block_hist[(q * nblk + b) * RADIX + tid] - toff;
+        scan[tid] = run;
+        gdelta[tid] = gbase;
+    }
+    __syncthreads();
+    // exclusive scan of the 256 digit totals by ONE wave (4 digits per lane + shuffle scan):
+    // two barriers instead of the sixteen of a workgroup-wide Hillis-Steele scan
+    if (wave == 0) {
+        const uint32_t t0 = scan[4 * lane], t1 = scan[4 * lane + 1], t2 = scan[4 * lane + 2],
+                       t3 = scan[4 * lane + 3];
+        const uint32_t mine = t0 + t1 + t2 + t3;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        const uint32_t ex = inc - mine;
+        const uint32_t toff[4] = {ex, ex + t0, ex + t0 + t1, ex + t0 + t1 + t2};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dgt = 4 * lane + k;
+            scan[dgt] = toff[k];        // now: first slot of the digit in the tile
+            gdelta[dgt] -= toff[k];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -181,7 +205,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(
         const bool valid = (sub0 + r * 64 + lane) < n;
         if (!valid) continue;
         const uint32_t d = (key[r] >> shift) & 255u;
-        const uint32_t lp = wcnt[wave][d] + pos[r];
+        const uint32_t lp = scan[d] + wcnt[wave][d] + pos[r];
         skey[lp] = key[r];
         sval[lp] = val[r];
     }
