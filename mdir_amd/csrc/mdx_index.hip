@@ -72,7 +72,7 @@ template <int QT>
 static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
                             int KB, int nq_valid, hipStream_t s)
 {
-    auto kern = scores_lc_kernel<QT, LC_R, LC_KC, LC_NSTAGE>;
+    auto kern = scores_lc_kernel<QT, LC_R, LC_KC, LC_NSTAGE, 2>;   // 2 = non-temporal database stream
     constexpr int lds = LC_NSTAGE * (QT + 4 * LC_R) * LC_KC * 1024;
     static bool configured = false;     // per instantiation; benign if two threads race
     if (!configured) {

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
 // then read it; the slot of stage c-1 is refilled right after B_c (every consumer has
 // finished chunk c-1 by then).  Accumulation order per output is unchanged (k ascending).
 // ===========================================================================
-template <int QT, int R, int KC, int NSTAGE>
+template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0>
 __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
                                                            float *__restrict__ out, int64_t n, int KB,
@@ -277,10 +277,18 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
         auto issue = [&](int c) {
             f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
 #pragma unroll
-            for (int t = 0; t < PER_LOADER; ++t)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src[t] + (int64_t)c * KC * 64),
-                    (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, 0);
+            for (int t = 0; t < PER_LOADER; ++t) {
+                // query tiles (re-read by every workgroup) keep the default cache policy; the
+                // database stream may be marked non-temporal (DB_AUX = 2)
+                if (DB_AUX != 0 && (lw + t * LW) >= QTILES)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src[t] + (int64_t)c * KC * 64),
+                        (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, DB_AUX);
+                else
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src[t] + (int64_t)c * KC * 64),
+                        (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, 0);
+            }
         };
 #pragma unroll
         for (int c = 0; c < NSTAGE - 1; ++c)

@@ -52,15 +52,11 @@ int main()
             if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
             return ms / 10;
         };
-        for (int rep = 0; rep < 2; ++rep)
-        printf("floor(noDB,noQ) %.3f | v1 NW8 R1 NS3: %.3f | LC R2 KC4 NST3: %.3f | LC R4 KC2 NST3: %.3f | LC R2 KC2 NST3 %.3f | LC R2 KC2 NST4 %.3f | LC R1 KC2 NST4 %.3f | LC R1 KC4 NST3 %.3f | LC R2 KC1 NST5 %.3f\n",
-               run<3, 1, false, true, 3, 2, false, 8, 4>(db, q, out, n, RT, KB, 10),
-               run<0, 1, false, true, 3, 2, false, 8, 4>(db, q, out, n, RT, KB, 10),
-               lc(scores_lc_kernel<5, 2, 4, 3>, 2, 4, 3, 5),
-               lc(scores_lc_kernel<5, 4, 2, 3>, 4, 2, 3, 5),
-               lc(scores_lc_kernel<5, 2, 2, 3>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 2, 2, 4>, 2, 2, 4, 5),
-               lc(scores_lc_kernel<5, 1, 2, 4>, 1, 2, 4, 5), lc(scores_lc_kernel<5, 1, 4, 3>, 1, 4, 3, 5),
-               lc(scores_lc_kernel<5, 2, 1, 5>, 2, 1, 5, 5));
+        for (int rep = 0; rep < 3; ++rep)
+        printf("LC R2 KC2 NST3 aux0 %.3f | aux2(nt) %.3f | aux1 %.3f | aux3 %.3f || R4 KC2 NST3 aux0 %.3f aux2 %.3f\n",
+               lc(scores_lc_kernel<5, 2, 2, 3, 0>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 2, 2, 3, 2>, 2, 2, 3, 5),
+               lc(scores_lc_kernel<5, 2, 2, 3, 1>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 2, 2, 3, 3>, 2, 2, 3, 5),
+               lc(scores_lc_kernel<5, 4, 2, 3, 0>, 4, 2, 3, 5), lc(scores_lc_kernel<5, 4, 2, 3, 2>, 4, 2, 3, 5));
     }
     return 0;
 }
