@@ -31,34 +31,50 @@ __device__ __forceinline__ uint32_t load_key(const float *scores, const uint32_t
     return first ? desc_key(scores[i]) : keys[i];
 }
 
-// per-tile digit histogram -> block_hist[q][b][digit]
+// per-tile digit histogram -> block_hist[q][b][digit].  One workgroup takes HIST_TILES
+// consecutive tiles: all their loads are issued before the first LDS atomic, so that a
+// short-lived workgroup still keeps enough bytes in flight.
+#ifndef MDX_HIST_TILES
+#define MDX_HIST_TILES 1
+#endif
+constexpr int HIST_TILES = MDX_HIST_TILES;
+
 template <bool FIRST>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__restrict__ scores,
-                                                        const uint32_t *__restrict__ keys,
-                                                        int64_t n, int nblk, int shift,
-                                                        uint32_t *__restrict__ block_hist)
+                                                                 const uint32_t *__restrict__ keys,
+                                                                 int64_t n, int nblk, int shift,
+                                                                 uint32_t *__restrict__ block_hist)
 {
-    __shared__ uint32_t h[SORT_WAVES][RADIX];
+    __shared__ uint32_t h[HIST_TILES][SORT_WAVES / 2][RADIX];
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int64_t q = blockIdx.y, b = blockIdx.x;
-    for (int e = tid; e < SORT_WAVES * RADIX; e += SORT_THREADS) (&h[0][0])[e] = 0;
-    __syncthreads();
+    const int64_t q = blockIdx.y, b0 = (int64_t)blockIdx.x * HIST_TILES;
+    for (int e = tid; e < HIST_TILES * (SORT_WAVES / 2) * RADIX; e += SORT_THREADS) (&h[0][0][0])[e] = 0;
     const int64_t base = q * n;
-    const int64_t t0 = b * SORT_TILE;
+    uint32_t k[HIST_TILES][SORT_ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int64_t i = t0 + r * SORT_THREADS + tid;
-        if (i < n) {
-            const uint32_t k = load_key(scores, keys, base + i, FIRST);
-            atomicAdd(&h[wave][(k >> shift) & 255u], 1u);
+    for (int t = 0; t < HIST_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = (b0 + t) * SORT_TILE + r * SORT_THREADS + tid;
+            k[t][r] = i < n ? load_key(scores, keys, base + i, FIRST) : 0u;
         }
-    }
     __syncthreads();
-    if (tid < RADIX) {
-        uint32_t tot = 0;
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) tot += h[w][tid];
-        block_hist[(q * nblk + b) * RADIX + tid] = tot;
+    for (int t = 0; t < HIST_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = (b0 + t) * SORT_TILE + r * SORT_THREADS + tid;
+            if (i < n) atomicAdd(&h[t][wave >> 1][(k[t][r] >> shift) & 255u], 1u);
+        }
+    __syncthreads();
+    for (int e = tid; e < HIST_TILES * RADIX; e += SORT_THREADS) {
+        const int t = e / RADIX, d = e % RADIX;
+        if (b0 + t < nblk) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES / 2; ++w) tot += h[t][w][d];
+            block_hist[(q * nblk + b0 + t) * RADIX + d] = tot;
+        }
     }
 }
 
@@ -348,11 +364,12 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
         const uint32_t *kin = pass == 0 ? nullptr : ws.keys[(pass - 1) & 1];
         const uint32_t *vin = pass == 0 ? nullptr : ws.vals[(pass - 1) & 1];
         uint32_t *kout = ws.keys[pass & 1], *vout = ws.vals[pass & 1];
+        const dim3 hgrid((unsigned)ceil_div(ws.nblk, HIST_TILES), (unsigned)nq);
         if (pass == 0)
-            hipLaunchKernelGGL(sort_hist_kernel<true>, grid, blk, 0, s, scores, kin, n, ws.nblk, shift,
+            hipLaunchKernelGGL(sort_hist_kernel<true>, hgrid, blk, 0, s, scores, kin, n, ws.nblk, shift,
                                ws.block_hist);
         else
-            hipLaunchKernelGGL(sort_hist_kernel<false>, grid, blk, 0, s, scores, kin, n, ws.nblk,
+            hipLaunchKernelGGL(sort_hist_kernel<false>, hgrid, blk, 0, s, scores, kin, n, ws.nblk,
                                shift, ws.block_hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)nq), dim3(256), 0, s, ws.block_hist, ws.nblk,
                            ws.digit_base);
