@@ -242,3 +242,24 @@ def test_full_size_shards_equal_whole(big):
     inv.scatter_(1, rk, torch.arange(n, device=DEV)[None, :].expand(nq, n))
     for qi in range(nq):
         assert bool((cnt[off[qi]:off[qi + 1]] == inv[qi][ids_t[off[qi]:off[qi + 1]]]).all())
+
+
+def test_hard_negative_mining_on_gpu():
+    """f1 (traindataset.py:242-270): pool 20 000 x 300 queries; selections equal the reference's
+    torch.mm + torch.sort + walk restated on the CPU."""
+    from mdir_amd.mining import search_hard_negatives
+    from test_host_api import _reference_mining
+    rng = np.random.default_rng(4)
+    D, P, Q, nimg = 512, 20000, 300, 60000
+    pool = rng.standard_normal((P, D)).astype(np.float32)
+    pool /= np.linalg.norm(pool, axis=1, keepdims=True)
+    qv = pool[rng.choice(P, Q, replace=False)] + 0.05 * rng.standard_normal((Q, D)).astype(np.float32)
+    qv /= np.linalg.norm(qv, axis=1, keepdims=True)
+    idxs2images = rng.permutation(nimg)[:P]
+    clusters = rng.integers(0, 700, nimg).tolist()
+    qidxs = rng.choice(nimg, Q, replace=False).tolist()
+    qvecs, poolvecs = np.ascontiguousarray(qv.T), np.ascontiguousarray(pool.T)
+    got, gd = search_hard_negatives(dev(qvecs), dev(poolvecs), idxs2images, clusters, qidxs, 5)
+    want, wd = _reference_mining(torch.from_numpy(qvecs), torch.from_numpy(poolvecs), idxs2images, clusters, qidxs, 5)
+    assert got == want
+    np.testing.assert_allclose(gd, wd, rtol=1e-4)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 from PIL import Image
 
-import fake_ops
+import fake_ops  # noqa: F401 (tests dir is on sys.path via conftest)
 from conftest import GOLDEN
 from oracle import oracle as O
 
@@ -394,3 +394,44 @@ def test_checkpoint_roundtrip_and_validate_tree(fops, tmp_path, monkeypatch):
         metadata["eval"]["roxford5k/validation/score_avg:map_medium"], abs=1e-12)
     with pytest.raises(AssertionError):
         stages.validate({"network": {}, "validation": {}}, (), device="cpu")
+
+
+# ------------------------------------------------------------------ f1: hard-negative mining
+
+def _reference_mining(qvecs, poolvecs, idxs2images, clusters, qidxs, nnum):
+    """The statement sequence of traindataset.py:242-270 restated with torch on CPU."""
+    scores = torch.mm(poolvecs.t(), qvecs)
+    scores, ranks = torch.sort(scores, dim=0, descending=True)
+    nidxs_all, nd = [], []
+    for q in range(len(qidxs)):
+        seen, nidxs, r = [clusters[qidxs[q]]], [], 0
+        while len(nidxs) < nnum:
+            potential = int(idxs2images[ranks[r, q]])
+            if clusters[potential] not in seen:
+                nidxs.append(potential)
+                seen.append(clusters[potential])
+                nd.append(float(torch.pow(qvecs[:, q] - poolvecs[:, ranks[r, q]] + 1e-6, 2).sum(dim=0).sqrt()))
+            r += 1
+        nidxs_all.append(nidxs)
+    return nidxs_all, nd
+
+
+def test_hard_negative_search_matches_reference_statements(fops):
+    from mdir_amd.mining import search_hard_negatives
+    rng = np.random.default_rng(9)
+    D, P, Q, nimg = 32, 400, 11, 1000
+    pool = rng.standard_normal((P, D)).astype(np.float32)
+    pool /= np.linalg.norm(pool, axis=1, keepdims=True)
+    qv = pool[rng.choice(P, Q, replace=False)] + 0.1 * rng.standard_normal((Q, D)).astype(np.float32)
+    qv /= np.linalg.norm(qv, axis=1, keepdims=True)
+    idxs2images = rng.permutation(nimg)[:P]
+    clusters = rng.integers(0, 40, nimg).tolist()            # few clusters -> many skipped candidates
+    qidxs = rng.choice(nimg, Q, replace=False).tolist()
+    qvecs, poolvecs = torch.from_numpy(np.ascontiguousarray(qv.T)), torch.from_numpy(np.ascontiguousarray(pool.T))
+    for nnum, prefix in ((5, None), (3, 4), (0, None)):     # prefix 4 forces the doubling path
+        got, gd = search_hard_negatives(qvecs, poolvecs, idxs2images, clusters, qidxs, nnum, prefix=prefix)
+        want, wd = _reference_mining(qvecs, poolvecs, idxs2images, clusters, qidxs, nnum)
+        assert got == want
+        np.testing.assert_allclose(gd, wd, rtol=1e-5)
+    with pytest.raises(IndexError):
+        search_hard_negatives(qvecs, poolvecs, idxs2images, [0] * nimg, qidxs, 2)
