@@ -74,11 +74,8 @@ static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_
 {
     auto kern = scores_lc_kernel<QT, LC_R, LC_KC, LC_NSTAGE, 2>;   // 2 = non-temporal database stream
     constexpr int lds = LC_NSTAGE * (QT + 4 * LC_R) * LC_KC * 1024;
-    static bool configured = false;     // per instantiation; benign if two threads race
-    if (!configured) {
-        MDX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
-    }
+    // > 64 KiB of dynamic LDS needs the opt-in; per device, so set on every launch (host-side, cheap)
+    MDX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int64_t blocks = ceil_div(RT, (int64_t)4 * LC_R);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, db, qt, out, n, KB, nq_valid);
     return MDX_OK;

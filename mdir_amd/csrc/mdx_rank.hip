@@ -78,16 +78,34 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__
     }
 }
 
-// per query: exclusive prefix over tiles for each digit (in place) + digit bases
-__global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ block_hist, int nblk,
-                                                        uint32_t *__restrict__ digit_base)
+// per query: exclusive prefix over tiles for each digit (in place) + digit bases.
+// 1024 threads = 4 groups x 256 digits; group g scans a quarter of the tiles (sum pass,
+// then prefix pass -- block_hist is L2-resident), so the serial chain is nblk/4 long.
+constexpr int SCAN_GROUPS = 4;
+
+__global__ __launch_bounds__(256 * SCAN_GROUPS) void sort_scan_kernel(uint32_t *__restrict__ block_hist,
+                                                                      int nblk,
+                                                                      uint32_t *__restrict__ digit_base)
 {
+    __shared__ uint32_t part[SCAN_GROUPS][RADIX];
     __shared__ uint32_t s[RADIX];
-    const int d = threadIdx.x;
+    const int d = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const int per = (nblk + SCAN_GROUPS - 1) / SCAN_GROUPS;
+    const int b0 = g * per, b1 = (b0 + per) < nblk ? (b0 + per) : nblk;
     uint32_t *p = block_hist + (int64_t)blockIdx.x * nblk * RADIX + d;
-    uint32_t run = 0;
-    int b = 0;
-    for (; b + 8 <= nblk; b += 8) {
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += p[(int64_t)b * RADIX];
+    part[g][d] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_GROUPS; ++k) {
+        const uint32_t v = part[k][d];
+        if (k < g) run += v;
+        total += v;
+    }
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
         uint32_t c[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) c[u] = p[(int64_t)(b + u) * RADIX];
@@ -97,20 +115,21 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ b
             run += c[u];
         }
     }
-    for (; b < nblk; ++b) {
+    for (; b < b1; ++b) {
         const uint32_t c = p[(int64_t)b * RADIX];
         p[(int64_t)b * RADIX] = run;
         run += c;
     }
-    s[d] = run;
+    // exclusive scan of the digit totals (group 0 only)
+    if (g == 0) s[d] = total;
     __syncthreads();
     for (int off = 1; off < RADIX; off <<= 1) {
-        const uint32_t v = d >= off ? s[d - off] : 0u;
+        const uint32_t v = (g == 0 && d >= off) ? s[d - off] : 0u;
         __syncthreads();
-        s[d] += v;
+        if (g == 0) s[d] += v;
         __syncthreads();
     }
-    digit_base[(int64_t)blockIdx.x * RADIX + d] = s[d] - run;
+    if (g == 0) digit_base[(int64_t)blockIdx.x * RADIX + d] = s[d] - total;
 }
 
 // stable scatter of one tile.  Element order inside a query = (tile, wave, round,
@@ -371,7 +390,7 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
         else
             hipLaunchKernelGGL(sort_hist_kernel<false>, hgrid, blk, 0, s, scores, kin, n, ws.nblk,
                                shift, ws.block_hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)nq), dim3(256), 0, s, ws.block_hist, ws.nblk,
+        hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)nq), dim3(256 * SCAN_GROUPS), 0, s, ws.block_hist, ws.nblk,
                            ws.digit_base);
         if (pass == 0)
             hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, blk, 0, s, scores, kin, vin,
