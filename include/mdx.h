@@ -46,6 +46,12 @@ typedef enum mdx_layout {
 
 /* Global pooling kinds (cirtorch/networks/imageretrievalnet.py:32-37; rmac is out
  * of scope). */
+/* Storage type of a shard.  MDX_F32 is the exact path (k-ordered fp32 fma chain).  MDX_F16
+ * stores descriptors (and the queries of a call) as IEEE fp16 and multiplies them on the
+ * fp16 MFMA with fp32 accumulation (BASELINE.json configs[4]); scores then carry fp16 input
+ * rounding (~1e-3 relative) -- a separate, looser parity contract (tests/test_gpu_f16.py). */
+typedef enum mdx_storage { MDX_F32 = 0, MDX_F16 = 1 } mdx_storage;
+
 typedef enum mdx_pool_kind { MDX_POOL_GEM = 0, MDX_POOL_MAC = 1, MDX_POOL_SPOC = 2 } mdx_pool_kind;
 
 int mdx_abi_version(void);
@@ -92,6 +98,9 @@ typedef struct mdx_index mdx_index;
  * if the build fails. */
 int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
                      int64_t row_offset, void *stream);
+/* Same with an explicit storage type (mdx_storage).  `src` is fp32 in both cases. */
+int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
+                        int64_t row_offset, int storage, void *stream);
 int mdx_index_destroy(mdx_index *index);
 /* n, d, row_offset and device bytes held. */
 int mdx_index_info(const mdx_index *index, int64_t *n, int64_t *d, int64_t *row_offset,

@@ -14,6 +14,8 @@ CSRC = os.path.join(_HERE, "csrc")
 
 MDX_DIM_MAJOR, MDX_ROW_MAJOR = 0, 1
 MDX_POOL_GEM, MDX_POOL_MAC, MDX_POOL_SPOC = 0, 1, 2
+MDX_F32, MDX_F16 = 0, 1
+STORAGE = {"f32": MDX_F32, "f16": MDX_F16}
 POOL_KINDS = {"gem": MDX_POOL_GEM, "mac": MDX_POOL_MAC, "spoc": MDX_POOL_SPOC}
 
 
@@ -48,6 +50,7 @@ def _declare(lib):
         "mdx_l2n_rows": (i32, [p, i64, i64, p, f32, p]),
         "mdx_ms_aggregate": (i32, [pp, i32, i64, f32, p, p]),
         "mdx_index_create": (i32, [pp, p, i64, i64, i32, i64, p]),
+        "mdx_index_create_ex": (i32, [pp, p, i64, i64, i32, i64, i32, p]),
         "mdx_index_destroy": (i32, [p]),
         "mdx_index_info": (i32, [p, pi64, pi64, pi64, pi64]),
         "mdx_scores_workspace": (i64, [i64, i64]),
@@ -66,7 +69,7 @@ def _declare(lib):
 
 
 EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
-           "mdx_index_create", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
+           "mdx_index_create", "mdx_index_create_ex", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
            "mdx_scores", "mdx_rank_workspace", "mdx_rank_full", "mdx_topk", "mdx_rank_of",
            "mdx_gather_scores", "mdx_rank_count")
 

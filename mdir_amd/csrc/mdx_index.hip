@@ -28,6 +28,36 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// fp16 variant of the re-tiling: tile = 16 rows x 32 k, lane (g,j) holds (row j, k 32kb+8g+e), e = 0..7,
+// converted from the fp32 source with round-to-nearest-even.
+__global__ __launch_bounds__(256) void retile_f16_kernel(const float *__restrict__ src, int64_t rs,
+                                                         int64_t ks, int64_t n, int64_t d,
+                                                         const float *__restrict__ center,
+                                                         f32x4 *__restrict__ tiles, int64_t RT,
+                                                         int64_t KB, int kb_fast)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (tile >= RT * KB) return;
+    int64_t rt, kb;
+    if (kb_fast) { rt = tile / KB; kb = tile % KB; }
+    else         { kb = tile / RT; rt = tile % RT; }
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t row = rt * TILE_ROWS + j;
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t k = kb * 32 + 8 * g + e;
+        float x = 0.0f;
+        if (row < n && k < d) {
+            x = src[row * rs + k * ks];
+            if (center) x -= center[k];
+        }
+        v[e] = (_Float16)x;
+    }
+    tiles[(rt * KB + kb) * 64 + lane] = __builtin_bit_cast(f32x4, v);
+}
+
 // ---------------------------------------------------------------------------
 // re-tiling: any strided [rows, k] fp32 matrix -> fragment-order tiles
 //   element (row, k) is read from src[row*rs + k*ks]; rows >= n and k >= d read 0.
@@ -68,16 +98,17 @@ __global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ s
 // tiles per consumer, chunks of 32 k, ring of 3 stages ((QT+8)*6 KiB of LDS).
 constexpr int LC_R = 2, LC_KC = 2, LC_NSTAGE = 3;
 
-template <int QT>
+template <int QT, typename MM = MmaF32>
 static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
                             int KB, int nq_valid, hipStream_t s)
 {
-    auto kern = scores_lc_kernel<QT, LC_R, LC_KC, LC_NSTAGE, 2>;   // 2 = non-temporal database stream
+    auto kern = scores_lc_kernel<QT, LC_R, LC_KC, LC_NSTAGE, 2, false, MM>;   // 2 = non-temporal database stream
     constexpr int lds = LC_NSTAGE * (QT + 4 * LC_R) * LC_KC * 1024;
     // > 64 KiB of dynamic LDS needs the opt-in; per device, so set on every launch (host-side, cheap)
     MDX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int64_t blocks = ceil_div(RT, (int64_t)4 * LC_R);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, db, qt, out, n, KB, nq_valid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
+                       (unsigned long long *)nullptr);
     return MDX_OK;
 }
 
@@ -92,26 +123,28 @@ static int launch_scores_small(const f32x4 *db, const f32x4 *qt, float *out, int
     return MDX_OK;
 }
 
+// mode 0: fp32 small shard, 1: fp32 loader/consumer, 2: fp16 loader/consumer
 template <int QT>
-static int launch_qt(bool small, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
+static int launch_qt(int mode, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
                      int KB, int nq_valid, hipStream_t s)
 {
-    return small ? launch_scores_small<QT, 4>(db, q, out, n, RT, KB, nq_valid, s)
-                 : launch_scores_lc<QT>(db, q, out, n, RT, KB, nq_valid, s);
+    if (mode == 0) return launch_scores_small<QT, 4>(db, q, out, n, RT, KB, nq_valid, s);
+    if (mode == 1) return launch_scores_lc<QT, MmaF32>(db, q, out, n, RT, KB, nq_valid, s);
+    return launch_scores_lc<QT, MmaF16>(db, q, out, n, RT, KB, nq_valid, s);
 }
 
-static int dispatch_qt(int qt, bool small, const f32x4 *db, const f32x4 *q, float *out, int64_t n,
+static int dispatch_qt(int qt, int mode, const f32x4 *db, const f32x4 *q, float *out, int64_t n,
                        int64_t RT, int KB, int nq_valid, hipStream_t s)
 {
     switch (qt) {
-        case 1: return launch_qt<1>(small, db, q, out, n, RT, KB, nq_valid, s);
-        case 2: return launch_qt<2>(small, db, q, out, n, RT, KB, nq_valid, s);
-        case 3: return launch_qt<3>(small, db, q, out, n, RT, KB, nq_valid, s);
-        case 4: return launch_qt<4>(small, db, q, out, n, RT, KB, nq_valid, s);
-        case 5: return launch_qt<5>(small, db, q, out, n, RT, KB, nq_valid, s);
-        case 6: return launch_qt<6>(small, db, q, out, n, RT, KB, nq_valid, s);
-        case 7: return launch_qt<7>(small, db, q, out, n, RT, KB, nq_valid, s);
-        default: return launch_qt<8>(small, db, q, out, n, RT, KB, nq_valid, s);
+        case 1: return launch_qt<1>(mode, db, q, out, n, RT, KB, nq_valid, s);
+        case 2: return launch_qt<2>(mode, db, q, out, n, RT, KB, nq_valid, s);
+        case 3: return launch_qt<3>(mode, db, q, out, n, RT, KB, nq_valid, s);
+        case 4: return launch_qt<4>(mode, db, q, out, n, RT, KB, nq_valid, s);
+        case 5: return launch_qt<5>(mode, db, q, out, n, RT, KB, nq_valid, s);
+        case 6: return launch_qt<6>(mode, db, q, out, n, RT, KB, nq_valid, s);
+        case 7: return launch_qt<7>(mode, db, q, out, n, RT, KB, nq_valid, s);
+        default: return launch_qt<8>(mode, db, q, out, n, RT, KB, nq_valid, s);
     }
 }
 
@@ -123,6 +156,7 @@ struct mdx_index {
     f32x4 *tiles;
     int64_t n, d, d_pad, RT, RT_pad, KB, row_offset;
     int64_t bytes;
+    int storage;        // MDX_F32 / MDX_F16
 };
 
 extern "C" {
@@ -131,14 +165,18 @@ int mdx_abi_version(void) { return MDX_ABI_VERSION; }
 const char *mdx_last_error(void) { return mdx::g_err; }
 
 static int retile(const float *src, int64_t n, int64_t d, int layout, const float *center,
-                  f32x4 *tiles, int64_t RT, int64_t KB, hipStream_t s)
+                  f32x4 *tiles, int64_t RT, int64_t KB, hipStream_t s, int storage = MDX_F32)
 {
     const int64_t rs = layout == MDX_DIM_MAJOR ? 1 : d;
     const int64_t ks = layout == MDX_DIM_MAJOR ? n : 1;
     const int64_t blocks = ceil_div(RT * KB, (int64_t)WAVES);
     MDX_CHECK_ARG(blocks < (1ll << 31), "matrix too large to re-tile in one launch");
-    hipLaunchKernelGGL(retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, rs, ks, n, d,
-                       center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1);
+    if (storage == MDX_F16)
+        hipLaunchKernelGGL(retile_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, rs, ks, n, d,
+                           center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1);
+    else
+        hipLaunchKernelGGL(retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, rs, ks, n, d,
+                           center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1);
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
@@ -146,7 +184,14 @@ static int retile(const float *src, int64_t n, int64_t d, int layout, const floa
 int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
                      int64_t row_offset, void *stream)
 {
+    return mdx_index_create_ex(out, src, n, d, layout, row_offset, MDX_F32, stream);
+}
+
+int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
+                        int64_t row_offset, int storage, void *stream)
+{
     MDX_CHECK_ARG(out && src, "mdx_index_create: NULL pointer");
+    MDX_CHECK_ARG(storage == MDX_F32 || storage == MDX_F16, "mdx_index_create: storage %d", storage);
     MDX_CHECK_ARG(n > 0 && d > 0, "mdx_index_create: n=%lld d=%lld must be positive",
                   (long long)n, (long long)d);
     MDX_CHECK_ARG(layout == MDX_DIM_MAJOR || layout == MDX_ROW_MAJOR, "mdx_index_create: layout %d",
@@ -154,8 +199,9 @@ int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, in
     mdx_index *ix = new mdx_index();
     ix->n = n;
     ix->d = d;
-    ix->d_pad = round_up(d, TILE_K * KBC);
-    ix->KB = ix->d_pad / TILE_K;
+    ix->storage = storage;
+    ix->d_pad = round_up(d, 64);                                  // 4 fp32 or 2 fp16 k-blocks
+    ix->KB = ix->d_pad / (storage == MDX_F16 ? 32 : TILE_K);
     ix->RT = ceil_div(n, TILE_ROWS);
     ix->RT_pad = round_up(ix->RT, 8);  // every wave of every workgroup has a tile to read
     ix->row_offset = row_offset;
@@ -168,7 +214,7 @@ int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, in
         return MDX_ERR_NOMEM;
     }
     hipStream_t s = (hipStream_t)stream;
-    int rc = retile(src, n, d, layout, nullptr, ix->tiles, ix->RT_pad, ix->KB, s);
+    int rc = retile(src, n, d, layout, nullptr, ix->tiles, ix->RT_pad, ix->KB, s, storage);
     if (rc != MDX_OK) {
         hipStreamSynchronize(s);
         hipFree(ix->tiles);
@@ -205,7 +251,7 @@ int mdx_index_info(const mdx_index *ix, int64_t *n, int64_t *d, int64_t *row_off
 int64_t mdx_scores_workspace(int64_t nq, int64_t d)
 {
     if (nq <= 0 || d <= 0) return 0;
-    return round_up(nq, TILE_ROWS) * round_up(d, TILE_K * KBC) * 4;
+    return round_up(nq, TILE_ROWS) * round_up(d, 64) * 4;   // fp32 tiles; an fp16 shard uses half of it
 }
 
 int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayout,
@@ -225,7 +271,7 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
     hipStream_t s = (hipStream_t)stream;
     f32x4 *qtiles = (f32x4 *)workspace;
     const int64_t QT_total = ceil_div(nq, TILE_ROWS);
-    int rc = retile(queries, nq, ix->d, qlayout, center, qtiles, QT_total, ix->KB, s);
+    int rc = retile(queries, nq, ix->d, qlayout, center, qtiles, QT_total, ix->KB, s, ix->storage);
     if (rc != MDX_OK) return rc;
 
     // Small shards (fewer than ~2 workgroups of 128 rows per CU): 64-row workgroups of the
@@ -237,7 +283,8 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
         const int nq_valid = (int)((nq - q0) < qt * TILE_ROWS ? (nq - q0) : qt * TILE_ROWS);
         const f32x4 *qp = qtiles + qt0 * ix->KB * 64;
         float *op = scores + q0 * ix->n;
-        rc = dispatch_qt(qt, small, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        const int mode = ix->storage == MDX_F16 ? 2 : (small ? 0 : 1);
+        rc = dispatch_qt(qt, mode, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
         if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK();
     }

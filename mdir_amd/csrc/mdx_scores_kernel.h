@@ -216,6 +216,29 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
 }
 
 
+// Element type of a shard.  A tile is always 64 lanes x 16 B; what the 16 bytes are and which
+// MFMA consumes them is the only difference between the fp32 (exact chain) and the fp16
+// (BASELINE.json configs[4]: "fp16 descriptors on CDNA4 fp16 MFMA") paths.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct MmaF32 {                 // v_mfma_f32_16x16x4_f32 x4: lane (g,j) element t = (row j, k 4t+g)
+    static constexpr int KELEMS = 16;   // k per tile
+    static constexpr int STEPS = 4;
+    static __device__ __forceinline__ f32x4 step(int t, const f32x4 &a, const f32x4 &b, const f32x4 &c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], c, 0, 0, 0);
+    }
+};
+
+struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e = (row j, k 8g+e), fp32 accumulate
+    static constexpr int KELEMS = 32;
+    static constexpr int STEPS = 1;
+    static __device__ __forceinline__ f32x4 step(int, const f32x4 &a, const f32x4 &b, const f32x4 &c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
 // ===========================================================================
 // Loader / consumer form of the similarity kernel.
 //
@@ -234,11 +257,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void scores_kernel(const f32x4 *__res
 // then read it; the slot of stage c-1 is refilled right after B_c (every consumer has
 // finished chunk c-1 by then).  Accumulation order per output is unchanged (k ascending).
 // ===========================================================================
-template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0>
+template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32>
 __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
                                                            float *__restrict__ out, int64_t n, int KB,
-                                                           int nq_valid)
+                                                           int nq_valid, unsigned long long *dbg = nullptr)
 {
     constexpr int CW = 4;                           // consumer waves
     constexpr int LW = 4;                           // loader waves
@@ -312,9 +335,12 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
 #pragma unroll
         for (int q = 0; q < QT; ++q) acc[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    unsigned long long t_wait = 0, t_work = 0, ts0 = 0, ts1 = 0;      // STAMPS: diagnostic build only
+    if (STAMPS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory");
     for (int c = 0; c < nchunks; ++c) {
         __builtin_amdgcn_s_barrier();                                       // B_c
         __builtin_amdgcn_sched_barrier(0);
+        if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); t_wait += ts1 - ts0; ts0 = ts1; }
         const f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
         const f32x4 *qs = slot + lane;
         const f32x4 *bs = slot + (QTILES + wave * R * KC) * 64 + lane;
@@ -326,16 +352,17 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
 #pragma unroll
             for (int r = 0; r < R; ++r) b[r] = bs[(r * KC + kb) * 64];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < MM::STEPS; ++t)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int q = 0; q < QT; ++q)
-                        acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][t], b[r][t], acc[r][q], 0, 0, 0);
+                    for (int q = 0; q < QT; ++q) acc[r][q] = MM::step(t, a[q], b[r], acc[r][q]);
         }
         // all LDS reads of this stage are consumed by the MFMAs above before the next barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (STAMPS) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); t_work += ts1 - ts0; ts0 = ts1; }
     }
+    if (STAMPS && dbg && lane == 0) { dbg[((int64_t)blockIdx.x * CW + wave) * 2] = t_wait; dbg[((int64_t)blockIdx.x * CW + wave) * 2 + 1] = t_work; }
 
     // Epilogue: the ring is free now (loaders have left, consumers are past their last read);
     // transpose the accumulators through LDS so that every query row of the workgroup's

@@ -28,11 +28,13 @@ def main():
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--images", type=int, default=30)
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find mode)")
     args = ap.parse_args()
     from mdir_amd import ops
     from mdir_amd.networks import init_network
     from mdir_amd.wrapper import initialize_wrappers
     dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     torch.manual_seed(3)
     net = init_network({"architecture": args.arch, "pooling": "gem", "whitening": False, "pretrained": False})
     net.meta["in_channels"], net.meta["out_channels"] = 3, net.meta["outputdim"]
@@ -46,6 +48,8 @@ def main():
     chain = initialize_wrappers({"0_cirwhiten": {"whitening": wh, "dimensions": None},
                                  "1_cirmultiscale": {"scales": True}}, dev)
     imgs = [torch.randn(1, 3, 768, 1024, device=dev) for _ in range(4)]
+    if args.channels_last:
+        imgs = [i.contiguous(memory_format=torch.channels_last) for i in imgs]
     vecs = torch.empty(args.images, D, device=dev)
     P32 = torch.tensor(wh["P"], dtype=torch.float32, device=dev)
     m32 = torch.tensor(wh["m"], dtype=torch.float32, device=dev)

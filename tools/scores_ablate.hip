@@ -43,20 +43,30 @@ int main()
             hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             const int64_t blocks = (RT + 4 * R_ - 1) / (4 * R_);
             hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70);
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70, (unsigned long long *)nullptr);
             hipEventRecord(a);
-            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70);
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70, (unsigned long long *)nullptr);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
             return ms / 10;
         };
-        for (int rep = 0; rep < 3; ++rep)
-        printf("LC R2 KC2 NST3 aux0 %.3f | aux2(nt) %.3f | aux1 %.3f | aux3 %.3f || R4 KC2 NST3 aux0 %.3f aux2 %.3f\n",
-               lc(scores_lc_kernel<5, 2, 2, 3, 0>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 2, 2, 3, 2>, 2, 2, 3, 5),
-               lc(scores_lc_kernel<5, 2, 2, 3, 1>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 2, 2, 3, 3>, 2, 2, 3, 5),
-               lc(scores_lc_kernel<5, 4, 2, 3, 0>, 4, 2, 3, 5), lc(scores_lc_kernel<5, 4, 2, 3, 2>, 4, 2, 3, 5));
+        {
+            auto kern = scores_lc_kernel<5, 2, 2, 3, 2, true>;
+            const size_t lds = (size_t)3 * (5 + 8) * 2 * 1024;
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const int64_t blocks = (RT + 7) / 8;
+            unsigned long long *dbg; hipMalloc(&dbg, blocks * 4 * 2 * 8); hipMemset(dbg, 0, blocks * 4 * 2 * 8);
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70, dbg);
+            hipDeviceSynchronize();
+            std::vector<unsigned long long> hd(blocks * 8);
+            hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
+            double w = 0, k = 0; for (int64_t i = 0; i < blocks * 4; ++i) { w += hd[2 * i]; k += hd[2 * i + 1]; }
+            printf("LC consumer stamps per wave: barrier-wait %.0f cycles, work %.0f cycles (64 chunks; ideal MFMA 163840) -> wait share %.1f%%\n",
+                   w / (blocks * 4), k / (blocks * 4), 100 * w / (w + k));
+            printf("LC R2 KC2 NST3 nt: %.3f ms\n", lc(scores_lc_kernel<5, 2, 2, 3, 2>, 2, 2, 3, 5));
+        }
     }
     return 0;
 }
