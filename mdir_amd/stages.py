@@ -34,3 +34,93 @@ def validate(params, data, device=None):
             valtask.validate(network, device, logger)
     events.close_epoch()
     return {"eval": {x: y[0] for x, y in events.metadata.metadata().items()}},
+
+
+def _collate_one(batch):
+    """batch_size 1: an image tensor gets its batch axis, an unreadable image stays ``{}``."""
+    return batch[0] if isinstance(batch[0], dict) else batch[0].unsqueeze(0)
+
+
+class EmbeddingOutput:
+    """``mdir/components/data/output.py:117-139``: collects one descriptor per image as a
+    float64 ``[N,D]`` matrix, NaN rows for unreadable images.  Here the rows are gathered in ONE
+    device buffer and copied to the host once, in ``postprocess``."""
+
+    def __init__(self, data, _data_params, *, bbxs=False):
+        if not bbxs:
+            assert len(data) == 1, len(data)
+        self.images, self.bbxs = data if bbxs else (data[0], None)
+        self.vecs = None
+        self._missing = []
+
+    def preprocess(self):
+        return self.images, self.bbxs
+
+    def add(self, index, input_data, output_data):
+        if input_data is None and output_data is None:
+            self._missing.append(index)
+            return
+        vec = output_data.reshape(-1)
+        if self.vecs is None:
+            self.vecs = torch.zeros((len(self.images), vec.numel()), dtype=torch.float32, device=vec.device)
+        self.vecs[index].copy_(vec, non_blocking=True)
+
+    def postprocess(self):
+        if self.vecs is None:
+            return self.images, []
+        out = self.vecs.cpu().numpy().astype(np.float64)
+        out[self._missing, :] = np.nan
+        return self.images, out
+
+
+OUTPUT_LABELS = {"embedding": EmbeddingOutput}
+
+
+def infer(params, data, device=None):
+    """``infer`` stage -- ``mdir/stages/infer.py:18-64`` for the ``embedding`` output (SURVEY.md
+    section 8 row f2): a list of images -> ``(metadata, images, float64 [N,D])``.
+
+    ``params = {"network": {path, runtime}, "data": {"test": {"dataset": {"name": "CirImageList",
+    "image_dir", "image_size"}, ["transforms", "mean_std"]}}, "output": {"inference": {"name":
+    "embedding", ["bbxs"]}}}``; ``data = (images,)`` or ``(images, bbxs)``."""
+    import copy
+    import time
+    from .datasets import ImagesFromList, initialize_transforms
+    from .scenario import path_join
+    from .validation import get_dataset_params
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("mdir_amd.stages.infer needs an MI355X (ROCm) device")
+        device = torch.device("cuda")
+    np.random.seed(0)
+    torch.manual_seed(0)
+
+    out_params = copy.deepcopy(params["output"]["inference"])
+    out_params.pop("async", None)                      # the single end-of-run copy makes the saver thread moot
+    network = load_network(params["network"], device).eval()
+    data_params = get_dataset_params(params["data"]["test"], network.network_params.runtime.get("data", {}))
+    output = OUTPUT_LABELS[out_params.pop("name")](data, copy.deepcopy(data_params), **out_params)
+    images, bbxs = output.preprocess()
+    if not images:
+        return ({"status": "skipped"},) + output.postprocess()
+
+    ds = copy.deepcopy(data_params["dataset"])
+    assert ds.pop("name") == "CirImageList", "only image-list datasets are on the inference path"
+    image_dir = ds.pop("image_dir")
+    transform = initialize_transforms(data_params["transforms"], data_params["mean_std"])
+    dataset = ImagesFromList(root="", images=[path_join(image_dir, x) for x in images], imsize=ds.pop("image_size"),
+                             bbxs=bbxs, transform=transform, **ds)
+    import os
+    loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, pin_memory=True,
+                                         num_workers=int(os.environ.get("MDIR_AMD_WORKERS", "6")),
+                                         collate_fn=_collate_one)
+    t0 = time.time()
+    with torch.no_grad():
+        for i, indata in enumerate(loader):
+            if isinstance(indata, dict) and indata == {}:
+                output.add(i, None, None)
+            else:
+                output.add(i, indata, network(indata.to(device, non_blocking=True)))
+    total = time.time() - t0
+    metadata = {"stats": {"total_time": int(total), "avg_time": total / len(loader)}}
+    return (metadata,) + output.postprocess()

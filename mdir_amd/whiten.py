@@ -25,3 +25,74 @@ def whitenapply(X, m, P, dimensions=None, device="cuda"):
     shard = ops.DescriptorIndex(Pd, "ND")
     y = ops.l2n_rows_(shard.scores(Xd, "DN", center=md), eps=1e-6)      # [N, d]
     return y.t().contiguous().cpu().numpy().astype(out_dtype, copy=False)
+
+
+# ---------------------------------------------------------------------------
+# learning: the D x D products run on the GPU through the same
+# similarity kernel (rows of the left operand are the "database", rows of the right one the
+# "queries"); the small dense factorisations stay on the host, as in the reference.
+# ---------------------------------------------------------------------------
+
+def _as_dev(a, device):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=torch.device(device))
+
+
+def gram(A, device="cuda"):
+    """``A @ A.T`` for ``A [D,n]`` (fp32, k-ordered chain): the ``np.dot(df, df.T)`` of
+    ``whiten.py:42,46`` and the ``np.dot(Xc, Xc.T)`` of ``:22``."""
+    Ad = _as_dev(A, device)
+    shard = ops.DescriptorIndex(Ad, "ND")                       # D "database rows" of length n
+    out = shard.scores(Ad, "ND").cpu().numpy()                  # [D,D], symmetric by construction
+    shard.close()
+    return out
+
+
+def project(P, X, m, device="cuda"):
+    """``np.dot(P, X - m)`` for ``X [D,N]``: returns ``[D_out, N]`` (``whiten.py:45``)."""
+    shard = ops.DescriptorIndex(_as_dev(P, device), "ND")
+    y = shard.scores(_as_dev(X, device), "DN", center=_as_dev(np.asarray(m).reshape(-1), device))    # [N, D_out]
+    shard.close()
+    return np.ascontiguousarray(y.cpu().numpy().T)
+
+
+def cholesky(S):
+    """Cholesky factor, adding 1e-10, 1e-9, ... to the diagonal until S is positive definite
+    (``whiten.py:55-70``)."""
+    alpha = 0
+    while True:
+        try:
+            return np.linalg.cholesky(S + alpha * np.eye(*S.shape))
+        except np.linalg.LinAlgError:
+            alpha = 1e-10 if alpha == 0 else alpha * 10
+            print(">>>> whiten.py::cholesky: Matrix is not positive definite, adding {:.0e} on the diagonal".format(alpha))
+
+
+def pcawhitenlearn(X, shrink=None, device="cuda"):
+    """PCA whitening without annotations (``whiten.py:14-35``): returns ``(m, P)``."""
+    N = X.shape[1]
+    m = X.mean(axis=1, keepdims=True)
+    Xcov = gram(X - m, device)
+    Xcov = (Xcov + Xcov.T) / (2 * N)
+    eigval, eigvec = np.linalg.eig(Xcov)
+    order = eigval.argsort()[::-1]
+    eigval, eigvec = eigval[order], eigvec[:, order]
+    if shrink:
+        b = eigval[shrink - 1]
+        eigval = (1 - b) * eigval + b
+    P = np.dot(np.linalg.inv(np.sqrt(np.diag(eigval))), eigvec.T)
+    return m, P
+
+
+def whitenlearn(X, qidxs, pidxs, device="cuda"):
+    """Learned whitening from matching pairs (``whiten.py:37-53``): returns ``(m, P)``."""
+    m = X[:, qidxs].mean(axis=1, keepdims=True)
+    df = X[:, qidxs] - X[:, pidxs]
+    S = gram(df, device) / df.shape[1]
+    P = np.linalg.inv(cholesky(S))
+    df = project(P, X, m, device)
+    D = gram(df, device)
+    eigval, eigvec = np.linalg.eig(D)
+    order = eigval.argsort()[::-1]
+    eigvec = eigvec[:, order]
+    P = np.dot(eigvec.T, P)
+    return m, P

@@ -263,3 +263,48 @@ def test_hard_negative_mining_on_gpu():
     want, wd = _reference_mining(torch.from_numpy(qvecs), torch.from_numpy(poolvecs), idxs2images, clusters, qidxs, 5)
     assert got == want
     np.testing.assert_allclose(gd, wd, rtol=1e-4)
+
+
+def test_infer_and_whitening_learning_on_gpu(tmp_path):
+    """f2 + f3 on the device: infer stage -> float64 embeddings (NaN row for a missing file);
+    whitenlearn on them whitens the matching-pair differences; gram is the exact k-chain."""
+    from mdir_amd import stages
+    from mdir_amd.network import CirNetwork, SingleNetwork
+    from mdir_amd.networks import init_network
+    from mdir_amd.whiten import gram, whitenlearn
+    from test_host_api import _write_images
+    rng = np.random.default_rng(3)
+    names = ["im%02d" % i for i in range(12)]
+    _write_images(str(tmp_path / "imgs"), names, rng, size=(224, 160))
+    torch.manual_seed(0)
+    model_params = {"architecture": "cirnet", "cir_architecture": "alexnet", "local_whitening": False,
+                    "pooling": "gem", "regional": False, "whitening": False, "pretrained": True}
+    model = init_network({"architecture": "alexnet", "pretrained": False})
+    model.meta["in_channels"], model.meta["out_channels"] = 3, 256
+    runtime = {"wrappers": "cirmultiscale:True", "data": {"transforms": "pil2np | totensor | normalize"}}
+    net = CirNetwork(model, SingleNetwork.NetworkParams(model_params, runtime), "cpu", frozen=True)
+    ckpt = str(tmp_path / "net.pth")
+    torch.save(net.state_dict()["net"], ckpt)
+    images = [n + ".jpg" for n in names[:5]] + ["missing.jpg"] + [n + ".jpg" for n in names[5:]]
+    params = {"network": {"path": ckpt, "runtime": {}},
+              "data": {"test": {"dataset": {"name": "CirImageList", "image_dir": str(tmp_path / "imgs"),
+                                            "image_size": 224, "ignore_errors": True}}},
+              "output": {"inference": {"name": "embedding"}}}
+    import os
+    os.environ["MDIR_AMD_WORKERS"] = "2"
+    meta, imgs_out, vecs = stages.infer(params, (images,))
+    assert vecs.shape == (13, 256) and vecs.dtype == np.float64 and np.isnan(vecs[5]).all()
+    good = np.delete(vecs, 5, axis=0)
+    np.testing.assert_allclose(np.linalg.norm(good, axis=1), 1.0, atol=1e-5)
+
+    rng = np.random.default_rng(0)
+    D, N, npairs = 64, 3000, 1000
+    basis = np.linalg.qr(rng.standard_normal((D, D)))[0] * np.geomspace(3.0, 0.2, D)
+    X = (basis @ rng.standard_normal((D, N))).astype(np.float32)
+    X /= np.linalg.norm(X, axis=0, keepdims=True)
+    qidxs, pidxs = rng.choice(N, npairs, replace=False), rng.choice(N, npairs, replace=False)
+    A = np.ascontiguousarray(X[:, :777])
+    np.testing.assert_array_equal(gram(A), OC.gemm_nt_chain(A, A))
+    m, P = whitenlearn(X, qidxs, pidxs)
+    dfw = P @ (X[:, qidxs] - X[:, pidxs])
+    np.testing.assert_allclose(dfw @ dfw.T / npairs, np.eye(D), atol=5e-3)

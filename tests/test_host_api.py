@@ -435,3 +435,90 @@ def test_hard_negative_search_matches_reference_statements(fops):
         np.testing.assert_allclose(gd, wd, rtol=1e-5)
     with pytest.raises(IndexError):
         search_hard_negatives(qvecs, poolvecs, idxs2images, [0] * nimg, qidxs, 2)
+
+
+# ------------------------------------------------------------------ f2: infer stage / EmbeddingOutput
+
+def test_infer_stage_embedding_output(fops, tmp_path, monkeypatch):
+    """infer.py:18-64 with the embedding output: float64 [N,D], NaN row for an unreadable image,
+    rows equal to extract_vectors of the same network."""
+    from mdir_amd import stages
+    from mdir_amd.network import CirNetwork, SingleNetwork
+    from mdir_amd.networks import extract_vectors, init_network
+    from mdir_amd.datasets import initialize_transforms
+    rng = np.random.default_rng(3)
+    names = ["a", "b", "c"]
+    _write_images(str(tmp_path / "imgs"), names, rng, size=(224, 160))
+    torch.manual_seed(0)
+    model_params = {"architecture": "cirnet", "cir_architecture": "alexnet", "local_whitening": False,
+                    "pooling": "gem", "regional": False, "whitening": False, "pretrained": True}
+    model = init_network({"architecture": "alexnet", "pretrained": False})
+    model.meta["in_channels"], model.meta["out_channels"] = 3, 256
+    runtime = {"wrappers": "cirmultiscale:True", "data": {"transforms": "pil2np | totensor | normalize"}}
+    net = CirNetwork(model, SingleNetwork.NetworkParams(model_params, runtime), "cpu", frozen=True)
+    ckpt = str(tmp_path / "net.pth")
+    torch.save(net.state_dict()["net"], ckpt)
+    images = ["a.jpg", "missing.jpg", "b.jpg", "c.jpg"]
+    params = {"network": {"path": ckpt, "runtime": {}},
+              "data": {"test": {"dataset": {"name": "CirImageList", "image_dir": str(tmp_path / "imgs"),
+                                            "image_size": 224, "ignore_errors": True}}},
+              "output": {"inference": {"name": "embedding"}}}
+    meta, imgs_out, vecs = stages.infer(copy.deepcopy(params), (images,), device="cpu")
+    assert imgs_out == images and vecs.dtype == np.float64 and vecs.shape == (4, 256)
+    assert np.isnan(vecs[1]).all() and not np.isnan(vecs[[0, 2, 3]]).any()
+    assert set(meta["stats"]) == {"total_time", "avg_time"}
+    tr = initialize_transforms("pil2np | totensor | normalize", net.network_params.runtime["data"]["mean_std"])
+    with torch.no_grad():
+        want = extract_vectors(net.eval(), [str(tmp_path / "imgs" / x) for x in ("a.jpg", "b.jpg", "c.jpg")], 224, tr,
+                               device="cpu")
+    np.testing.assert_allclose(vecs[[0, 2, 3]], want.numpy().T.astype(np.float64), rtol=0, atol=1e-7)
+    # nothing to do -> skipped
+    meta, imgs_out, vecs = stages.infer(copy.deepcopy(params), ([],), device="cpu")
+    assert meta == {"status": "skipped"} and vecs == []
+
+
+# ------------------------------------------------------------------ f3: whitening learning
+
+def _reference_whitenlearn(X, qidxs, pidxs):
+    """whiten.py:37-53 restated with numpy only."""
+    m = X[:, qidxs].mean(axis=1, keepdims=True)
+    df = X[:, qidxs] - X[:, pidxs]
+    S = np.dot(df, df.T) / df.shape[1]
+    P = np.linalg.inv(np.linalg.cholesky(S))
+    df = np.dot(P, X - m)
+    D = np.dot(df, df.T)
+    eigval, eigvec = np.linalg.eig(D)
+    eigvec = eigvec[:, eigval.argsort()[::-1]]
+    return m, np.dot(eigvec.T, P)
+
+
+def test_whitening_learning(fops):
+    from mdir_amd.whiten import cholesky, gram, pcawhitenlearn, project, whitenapply, whitenlearn
+    rng = np.random.default_rng(0)
+    D, N, npairs = 24, 400, 150
+    basis = np.linalg.qr(rng.standard_normal((D, D)))[0] * np.geomspace(3.0, 0.2, D)
+    X = (basis @ rng.standard_normal((D, N))).astype(np.float32)
+    X /= np.linalg.norm(X, axis=0, keepdims=True)
+    qidxs, pidxs = rng.choice(N, npairs, replace=False), rng.choice(N, npairs, replace=False)
+    A = X[:, :50]
+    np.testing.assert_allclose(gram(A, "cpu"), A @ A.T, rtol=1e-5, atol=1e-6)
+    Pm, mm = rng.standard_normal((D, D)).astype(np.float32), rng.standard_normal((D, 1)).astype(np.float32)
+    np.testing.assert_allclose(project(Pm, X, mm, "cpu"), Pm @ (X - mm), rtol=1e-4, atol=1e-5)
+    m, P = whitenlearn(X, qidxs, pidxs, device="cpu")
+    mr, Pr = _reference_whitenlearn(X, qidxs, pidxs)
+    np.testing.assert_allclose(m, mr, rtol=1e-6)
+    sign = np.sign(np.sum(P * Pr, axis=1, keepdims=True))       # eigenvectors are defined up to sign
+    np.testing.assert_allclose(P * sign, Pr, rtol=2e-2, atol=2e-3)
+    # the learned projection whitens the pair differences (their covariance becomes the identity)
+    dfw = P @ (X[:, qidxs] - X[:, pidxs])
+    np.testing.assert_allclose(dfw @ dfw.T / npairs, np.eye(D), atol=5e-3)
+    # and retrieval with it agrees with retrieval with the reference's P
+    a = whitenapply(X, m, P.astype(np.float32), device="cpu")
+    b = whitenapply(X, mr, Pr.astype(np.float32), device="cpu")
+    np.testing.assert_allclose(a.T @ a, b.T @ b, atol=2e-3)
+    m2, P2 = pcawhitenlearn(X, device="cpu")
+    Xw = P2 @ (X - m2)
+    np.testing.assert_allclose(Xw @ Xw.T / N, np.eye(D), atol=5e-3)
+    S = np.ones((3, 3))                                          # singular: needs the diagonal bump
+    L = cholesky(S)
+    assert np.allclose(L @ L.T, S, atol=1e-6)
