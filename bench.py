@@ -205,7 +205,7 @@ def main():
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
         if tf:
             traffic = json.load(open(tf[-1])).get("scores_kernel_hbm_bytes_per_launch")
-        roofline = {"kernel": "mdx::scores_kernel<QT=5> (fp32 MFMA 16x16x4, 8 waves/workgroup)", "bound": "mfma",
+        roofline = {"kernel": "mdx::scores_lc_kernel<QT=5,R=2> (fp32 MFMA 16x16x4; 4 MFMA + 4 LDS-DMA loader waves)", "bound": "mfma",
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops, "algorithmic_bytes": algo_bytes,

@@ -18,6 +18,8 @@
 
 namespace mdx {
 
+constexpr int WAVES = 4;        // waves (= tiles) per workgroup of the re-tiling kernels
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char *fmt, ...)
@@ -94,43 +96,37 @@ __global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ s
     tiles[(rt * KB + kb) * 64 + lane] = v;
 }
 
-// Large shards: loader/consumer kernel (4 MFMA waves + 4 LDS-DMA loader waves), R = 2 row
-// tiles per consumer, chunks of 32 k, ring of 3 stages ((QT+8)*6 KiB of LDS).
-constexpr int LC_R = 2, LC_KC = 2, LC_NSTAGE = 3;
+// Loader/consumer kernel (4 MFMA waves + 4 LDS-DMA loader waves), chunks of 2 tiles along k,
+// ring of 3 stages.  R = 2 row tiles per consumer (128-row workgroups, (QT+8)*6 KiB of LDS)
+// for shards of >= 32 768 rows; R = 1 (64-row workgroups) below, so that small shards still
+// spread over the CUs -- measured crossover, tools/scores_ablate.hip.
+constexpr int LC_KC = 2, LC_NSTAGE = 3;
 
-template <int QT, typename MM = MmaF32>
+template <int QT, int R, typename MM>
 static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
                             int KB, int nq_valid, hipStream_t s)
 {
-    auto kern = scores_lc_kernel<QT, LC_R, LC_KC, LC_NSTAGE, 2, false, MM>;   // 2 = non-temporal database stream
-    constexpr int lds = LC_NSTAGE * (QT + 4 * LC_R) * LC_KC * 1024;
+    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM>;   // 2 = non-temporal database stream
+    constexpr int lds = LC_NSTAGE * (QT + 4 * R) * LC_KC * 1024;
     // > 64 KiB of dynamic LDS needs the opt-in; per device, so set on every launch (host-side, cheap)
     MDX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    const int64_t blocks = ceil_div(RT, (int64_t)4 * LC_R);
+    const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
                        (unsigned long long *)nullptr);
     return MDX_OK;
 }
 
-// Small shards: NW-wave workgroups of the register-streaming kernel, one row tile per wave.
-template <int QT, int NW>
-static int launch_scores_small(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
-                               int KB, int nq_valid, hipStream_t s)
-{
-    const int64_t blocks = ceil_div(RT, (int64_t)NW);
-    hipLaunchKernelGGL((scores_kernel<QT, 1, 0, false, true, 3, 2, false, NW>), dim3((unsigned)blocks),
-                       dim3(NW * 64), 0, s, db, qt, out, n, KB, nq_valid, (int64_t)0, nullptr);
-    return MDX_OK;
-}
-
-// mode 0: fp32 small shard, 1: fp32 loader/consumer, 2: fp16 loader/consumer
+// mode bit0: R = 2 (else 1), bit1: fp16 shard
 template <int QT>
 static int launch_qt(int mode, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
                      int KB, int nq_valid, hipStream_t s)
 {
-    if (mode == 0) return launch_scores_small<QT, 4>(db, q, out, n, RT, KB, nq_valid, s);
-    if (mode == 1) return launch_scores_lc<QT, MmaF32>(db, q, out, n, RT, KB, nq_valid, s);
-    return launch_scores_lc<QT, MmaF16>(db, q, out, n, RT, KB, nq_valid, s);
+    switch (mode) {
+        case 0: return launch_scores_lc<QT, 1, MmaF32>(db, q, out, n, RT, KB, nq_valid, s);
+        case 1: return launch_scores_lc<QT, 2, MmaF32>(db, q, out, n, RT, KB, nq_valid, s);
+        case 2: return launch_scores_lc<QT, 1, MmaF16>(db, q, out, n, RT, KB, nq_valid, s);
+        default: return launch_scores_lc<QT, 2, MmaF16>(db, q, out, n, RT, KB, nq_valid, s);
+    }
 }
 
 static int dispatch_qt(int qt, int mode, const f32x4 *db, const f32x4 *q, float *out, int64_t n,
@@ -274,16 +270,14 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
     int rc = retile(queries, nq, ix->d, qlayout, center, qtiles, QT_total, ix->KB, s, ix->storage);
     if (rc != MDX_OK) return rc;
 
-    // Small shards (fewer than ~2 workgroups of 128 rows per CU): 64-row workgroups of the
-    // register-streaming kernel so that more CUs get work.
-    const bool small = ix->RT < 256 * 8 * 2;
+    const bool small = ix->RT < 2048;                 // < 32 768 rows: 64-row workgroups
     for (int64_t qt0 = 0; qt0 < QT_total; qt0 += MAX_QT) {
         const int qt = (int)((QT_total - qt0) < MAX_QT ? (QT_total - qt0) : MAX_QT);
         const int64_t q0 = qt0 * TILE_ROWS;
         const int nq_valid = (int)((nq - q0) < qt * TILE_ROWS ? (nq - q0) : qt * TILE_ROWS);
         const f32x4 *qp = qtiles + qt0 * ix->KB * 64;
         float *op = scores + q0 * ix->n;
-        const int mode = ix->storage == MDX_F16 ? 2 : (small ? 0 : 1);
+        const int mode = (small ? 0 : 1) | (ix->storage == MDX_F16 ? 2 : 0);
         rc = dispatch_qt(qt, mode, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
         if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK();

@@ -1,9 +1,11 @@
 // Timing-only ablations of the similarity kernel (results are wrong for ABL != 0).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdir_amd/csrc tools/scores_ablate.hip -o tools/scores_ablate
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdir_amd/csrc -I tools tools/scores_ablate.hip -o tools/scores_ablate
 #include <stdarg.h>
 #include <vector>
 #include <math.h>
+#include <stdlib.h>
 #include "mdx_scores_kernel.h"
+#include "scores_v1_kernel.h"
 namespace mdx { void set_error(const char *, ...) {} }
 using namespace mdx;
 
@@ -20,9 +22,9 @@ static float run(const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t
     return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int64_t n = 1004993, d = 2048; const int KB = d / 16;
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 1004993, d = 2048; const int KB = d / 16;
     const int64_t RT = (n + 15) / 16, RTp = (RT + 7) / 8 * 8;
     f32x4 *db, *q; float *out;
     hipMalloc(&db, (RTp + 256) * KB * 1024); hipMalloc(&q, 5 * KB * 1024); hipMalloc(&out, 70 * n * 4);
@@ -52,21 +54,11 @@ int main()
             if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
             return ms / 10;
         };
-        {
-            auto kern = scores_lc_kernel<5, 2, 2, 3, 2, true>;
-            const size_t lds = (size_t)3 * (5 + 8) * 2 * 1024;
-            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            const int64_t blocks = (RT + 7) / 8;
-            unsigned long long *dbg; hipMalloc(&dbg, blocks * 4 * 2 * 8); hipMemset(dbg, 0, blocks * 4 * 2 * 8);
-            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70, dbg);
-            hipDeviceSynchronize();
-            std::vector<unsigned long long> hd(blocks * 8);
-            hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
-            double w = 0, k = 0; for (int64_t i = 0; i < blocks * 4; ++i) { w += hd[2 * i]; k += hd[2 * i + 1]; }
-            printf("LC consumer stamps per wave: barrier-wait %.0f cycles, work %.0f cycles (64 chunks; ideal MFMA 163840) -> wait share %.1f%%\n",
-                   w / (blocks * 4), k / (blocks * 4), 100 * w / (w + k));
-            printf("LC R2 KC2 NST3 nt: %.3f ms\n", lc(scores_lc_kernel<5, 2, 2, 3, 2>, 2, 2, 3, 5));
-        }
+        for (int rep = 0; rep < 3; ++rep)
+        printf("n=%lld: LC R2 KC2 NST3 %.4f | R1 KC2 NST3 %.4f | R1 KC2 NST4 %.4f | R1 KC4 NST3 %.4f | v1 NW4 R1 %.4f | v1 NW8 R1 %.4f ms\n", (long long)n,
+               lc(scores_lc_kernel<5, 2, 2, 3, 2>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 1, 2, 3, 2>, 1, 2, 3, 5),
+               lc(scores_lc_kernel<5, 1, 2, 4, 2>, 1, 2, 4, 5), lc(scores_lc_kernel<5, 1, 4, 3, 2>, 1, 4, 3, 5),
+               run<0, 1, false, true, 3, 2, false, 4, 4>(db, q, out, n, RT, KB, 10), run<0, 1, false, true, 3, 2, false, 8, 4>(db, q, out, n, RT, KB, 10));
     }
     return 0;
 }
