@@ -47,7 +47,11 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__
 {
     __shared__ uint32_t h[HIST_TILES][SORT_WAVES / 2][RADIX];
     const int tid = threadIdx.x, wave = tid >> 6;
+#ifdef MDX_HIST_REVERSE
+    const int64_t q = blockIdx.y, b0 = ((int64_t)gridDim.x - 1 - blockIdx.x) * HIST_TILES;   // newest data first
+#else
     const int64_t q = blockIdx.y, b0 = (int64_t)blockIdx.x * HIST_TILES;
+#endif
     for (int e = tid; e < HIST_TILES * (SORT_WAVES / 2) * RADIX; e += SORT_THREADS) (&h[0][0][0])[e] = 0;
     const int64_t base = q * n;
     uint32_t k[HIST_TILES][SORT_ITEMS];
@@ -151,7 +155,11 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : SORT_WAVES / 
     __shared__ uint32_t skey[SORT_TILE];
     __shared__ uint32_t sval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef MDX_SORT_FORWARD
+    const int64_t q = (int64_t)gridDim.y - 1 - blockIdx.y;
+#else
     const int64_t q = blockIdx.y;
+#endif
     // Neighbouring tiles end their digit runs in the same cache lines.  Workgroups are dealt
     // round-robin over the 8 XCDs (speed only, never correctness), so give each XCD a
     // contiguous range of tiles: partial lines then meet in one L2 instead of two.
@@ -161,6 +169,9 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : SORT_WAVES / 
         const int qn = nblk / 8, rn = nblk % 8, x = (int)(blockIdx.x % 8), k = (int)(blockIdx.x / 8);
         b = (x < rn ? (int64_t)x * (qn + 1) : (int64_t)rn * (qn + 1) + (int64_t)(x - rn) * qn) + k;
     }
+#endif
+#ifndef MDX_SORT_FORWARD
+    b = (int64_t)nblk - 1 - b;      // the histogram pass just streamed the keys forward: the tail is still in the Infinity Cache
 #endif
     for (int e = tid; e < SORT_WAVES * RADIX; e += SORT_THREADS) (&wcnt[0][0])[e] = 0;
     __syncthreads();
