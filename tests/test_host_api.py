@@ -484,7 +484,14 @@ def _reference_whitenlearn(X, qidxs, pidxs):
     m = X[:, qidxs].mean(axis=1, keepdims=True)
     df = X[:, qidxs] - X[:, pidxs]
     S = np.dot(df, df.T) / df.shape[1]
-    P = np.linalg.inv(np.linalg.cholesky(S))
+    alpha = 0                                              # whiten.py:55-70: bump the diagonal until PD
+    while True:
+        try:
+            L = np.linalg.cholesky(S + alpha * np.eye(*S.shape))
+            break
+        except np.linalg.LinAlgError:
+            alpha = 1e-10 if alpha == 0 else alpha * 10
+    P = np.linalg.inv(L)
     df = np.dot(P, X - m)
     D = np.dot(df, df.T)
     eigval, eigvec = np.linalg.eig(D)
