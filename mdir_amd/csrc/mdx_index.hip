@@ -212,8 +212,8 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
     hipStream_t s = (hipStream_t)stream;
     int rc = retile(src, n, d, layout, nullptr, ix->tiles, ix->RT_pad, ix->KB, s, storage);
     if (rc != MDX_OK) {
-        hipStreamSynchronize(s);
-        hipFree(ix->tiles);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(ix->tiles);
         delete ix;
         return rc;
     }

@@ -189,3 +189,25 @@ def test_errors_are_loud(ops):
         ix.scores(torch.zeros(9, 3, device=DEV), "DN")
     with pytest.raises(IndexError):
         ops.rank_of(torch.zeros(1, 10, device=DEV), [[10]])
+
+
+def test_scores_race_screen(ops):
+    """The loader/consumer ring under repetition and uneven load: random shapes, four launches each
+    with other work on a second stream, every score bit-exact (tools/stress_scores.py is the long form)."""
+    rng = np.random.default_rng(123)
+    bg = torch.cuda.Stream()
+    junk = torch.randn(2048, 2048, device=DEV)
+    for it in range(10):
+        n = int(rng.integers(1, 90000)) if it % 2 else int(rng.integers(40000, 120000))
+        d = int(rng.choice([32, 100, 512, 2048]))
+        nq = int(rng.integers(1, 140))
+        db = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+        q = (rng.standard_normal((nq, d)) / np.sqrt(d)).astype(np.float32)
+        want = OC.gemm_nt_chain(q, db)
+        ix = ops.DescriptorIndex(dev(db), "ND")
+        qd = dev(q)
+        for rep in range(4):
+            with torch.cuda.stream(bg):
+                _ = junk @ junk
+            np.testing.assert_array_equal(ix.scores(qd, "ND").cpu().numpy(), want)
+        ix.close()

@@ -1,0 +1,41 @@
+"""Race screen for the loader/consumer similarity kernel: many random shapes, repeated launches,
+every score compared bit for bit with the fmaf-chain oracle (a ring-protocol bug shows up as rare
+wrong tiles that come and go with shape and load)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from mdir_amd import ops
+from oracle import chain as OC
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+bad = 0
+t0 = time.time()
+# a background stream of work on another HIP stream makes timing uneven
+bg = torch.cuda.Stream()
+junk = torch.randn(4096, 4096, device="cuda")
+for it in range(iters):
+    n = int(rng.integers(1, 90000)) if it % 3 else int(rng.integers(60000, 140000))
+    d = int(rng.choice([32, 64, 100, 256, 512, 1000, 2048]))
+    nq = int(rng.integers(1, 140))
+    storage = "f16" if it % 5 == 4 else "f32"
+    db = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    q = (rng.standard_normal((nq, d)) / np.sqrt(d)).astype(np.float32)
+    ix = ops.DescriptorIndex(torch.from_numpy(db).cuda(), "ND", storage=storage)
+    qd = torch.from_numpy(q).cuda()
+    if storage == "f32":
+        want = OC.gemm_nt_chain(q, db)
+    else:
+        want = (q.astype(np.float16).astype(np.float64) @ db.astype(np.float16).astype(np.float64).T)
+    for rep in range(4):
+        with torch.cuda.stream(bg):
+            junk2 = junk @ junk if rep % 2 else None
+        got = ix.scores(qd, "ND").cpu().numpy()
+        ok = np.array_equal(got, want) if storage == "f32" else np.allclose(got, want, rtol=0, atol=2e-6)
+        if not ok:
+            bad += 1
+            w = np.argwhere(got != want) if storage == "f32" else np.argwhere(np.abs(got - want) > 2e-6)
+            print("MISMATCH it=%d rep=%d n=%d d=%d nq=%d %s: %d wrong, first %s" % (it, rep, n, d, nq, storage, len(w), w[:3].tolist()))
+    ix.close()
+print("stress done: %d iterations x4, %d mismatching launches, %.1f s" % (iters, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
