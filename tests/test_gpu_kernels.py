@@ -211,3 +211,33 @@ def test_scores_race_screen(ops):
                 _ = junk @ junk
             np.testing.assert_array_equal(ix.scores(qd, "ND").cpu().numpy(), want)
         ix.close()
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "ascending", "descending", "two_values", "all_nan", "few_distinct", "denormals"])
+def test_rank_full_degenerate_distributions(ops, kind):
+    """Histograms with one huge bin, already-sorted input, ties everywhere: still the exact stable order."""
+    rng = np.random.default_rng(1)
+    n, nq = 50000, 3
+    if kind == "all_equal":
+        sc = np.full((nq, n), 0.25, dtype=np.float32)
+    elif kind == "ascending":
+        sc = np.tile(np.linspace(-1, 1, n, dtype=np.float32), (nq, 1))
+    elif kind == "descending":
+        sc = np.tile(np.linspace(1, -1, n, dtype=np.float32), (nq, 1))
+    elif kind == "two_values":
+        sc = rng.choice(np.array([-0.5, 0.5], dtype=np.float32), size=(nq, n))
+    elif kind == "all_nan":
+        sc = np.full((nq, n), np.nan, dtype=np.float32)
+    elif kind == "few_distinct":
+        sc = rng.choice(rng.standard_normal(37).astype(np.float32), size=(nq, n))
+    else:
+        sc = (rng.standard_normal((nq, n)) * 1e-41).astype(np.float32)      # subnormal scores, both signs, zeros
+        sc[:, ::7] = 0.0
+        sc[:, 3::11] = -0.0
+    want = OC.rank_full(sc)
+    got = ops.rank_full(dev(sc)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    if kind in ("all_equal", "all_nan"):
+        np.testing.assert_array_equal(got[0], np.arange(n))
+    ids, _ = ops.topk(dev(sc), 257)
+    np.testing.assert_array_equal(ids.cpu().numpy(), want[:, :257])
