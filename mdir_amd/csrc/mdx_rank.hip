@@ -420,6 +420,272 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
     return MDX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Row-wise top-k by radix SELECT (k << n): instead of sorting a million scores per query to
+// keep the first k, find the k-th key digit by digit from the top (one histogram pass per level,
+// normally ONE level: the best scores sit in the sparse tail of the distribution), compact
+// the candidates (keys below the threshold prefix, then keys equal to it) in id order, and
+// sort only those.  Exact, same tie rule as mdx_rank_full.
+// ---------------------------------------------------------------------------
+struct SelState { uint32_t prefix, mask, k_rem, resolved; };
+
+constexpr int SEL_CAP = 4096;   // slack: a level is final once (#equal-prefix keys) <= k_rem + SEL_CAP
+
+__global__ __launch_bounds__(SORT_THREADS) void select_hist_kernel(const float *__restrict__ scores, int64_t n,
+                                                                   int nblk, int shift,
+                                                                   const SelState *__restrict__ st,
+                                                                   uint32_t *__restrict__ block_hist)
+{
+    __shared__ uint32_t h[SORT_WAVES / 2][RADIX];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t q = blockIdx.y;
+    const SelState s = st[q];
+    if (s.resolved) return;         // later levels of an already decided query: nothing to do
+    // workgroups stride over the tiles, so that the (usual) early exit above costs few launches
+    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        for (int e = tid; e < (SORT_WAVES / 2) * RADIX; e += SORT_THREADS) (&h[0][0])[e] = 0;
+        uint32_t k[SORT_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = b * SORT_TILE + r * SORT_THREADS + tid;
+            k[r] = i < n ? desc_key(scores[q * n + i]) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = b * SORT_TILE + r * SORT_THREADS + tid;
+            if (i < n && (k[r] & s.mask) == s.prefix) atomicAdd(&h[wave >> 1][(k[r] >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES / 2; ++w) tot += h[w][tid];
+            block_hist[(q * nblk + b) * RADIX + tid] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// per query: the digit at which the cumulative count (best keys first) reaches k_rem; per-tile
+// counts of the two candidate classes (strictly below the new prefix / equal to it).
+// 1024 threads: 4 groups x 256 digits for the totals, 16 waves for the per-tile class counts.
+__global__ __launch_bounds__(1024) void select_step_kernel(const uint32_t *__restrict__ block_hist, int nblk,
+                                                           int shift, SelState *__restrict__ st,
+                                                           uint32_t *__restrict__ tile_less,
+                                                           uint32_t *__restrict__ tile_eq)
+{
+    __shared__ uint32_t part[4][RADIX];
+    __shared__ uint32_t cum[RADIX];
+    __shared__ uint32_t dstar_s;
+    const int tid = threadIdx.x, d = tid & 255, g = tid >> 8;
+    const int64_t q = blockIdx.x;
+    SelState s = st[q];
+    if (s.resolved) return;
+    const uint32_t *bh = block_hist + q * nblk * RADIX;
+    const int per = (nblk + 3) / 4, b0 = g * per, b1 = (b0 + per) < nblk ? (b0 + per) : nblk;
+    uint32_t tot = 0;
+    for (int b = b0; b < b1; ++b) tot += bh[(int64_t)b * RADIX + d];
+    part[g][d] = tot;
+    __syncthreads();
+    if (g == 0) cum[d] = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+    __syncthreads();
+    for (int off = 1; off < RADIX; off <<= 1) {
+        const uint32_t v = (g == 0 && d >= off) ? cum[d - off] : 0u;
+        __syncthreads();
+        if (g == 0) cum[d] += v;
+        __syncthreads();
+    }
+    // k_rem >= 1 and the matching keys number at least k_rem, so exactly one digit crosses
+    if (g == 0 && cum[d] >= s.k_rem && (d == 0 || cum[d - 1] < s.k_rem)) dstar_s = d;
+    __syncthreads();
+    const uint32_t ds = dstar_s;
+    const uint32_t c_eq = ds == 0 ? cum[0] : cum[ds] - cum[ds - 1];
+    const uint32_t c_less = cum[ds] - c_eq;
+    // one wave per tile: lane l sums digits 4l..4l+3 (one coalesced KiB), shuffle-reduce
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int b = wv; b < nblk; b += 16) {
+        const uint4 c = *(const uint4 *)(bh + (int64_t)b * RADIX + 4 * lane);
+        const uint32_t e0 = 4 * lane;
+        uint32_t less = (e0 < ds ? c.x : 0u) + (e0 + 1 < ds ? c.y : 0u) + (e0 + 2 < ds ? c.z : 0u) + (e0 + 3 < ds ? c.w : 0u);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) less += __shfl_xor(less, o, 64);
+        if (lane == 0) {
+            tile_less[q * nblk + b] += less;
+            tile_eq[q * nblk + b] = bh[(int64_t)b * RADIX + ds];
+        }
+    }
+    if (tid == 0) {
+        s.prefix |= ds << shift;
+        s.mask |= 255u << shift;
+        s.k_rem -= c_less;
+        s.resolved = (shift == 0 || c_eq <= s.k_rem + SEL_CAP) ? 1u : 0u;
+        st[q] = s;
+    }
+}
+
+// per query: exclusive offsets of every tile's two candidate blocks (all "less" first, then "equal")
+__global__ __launch_bounds__(256) void select_offsets_kernel(uint32_t *__restrict__ tile_less,
+                                                             uint32_t *__restrict__ tile_eq, int nblk)
+{
+    __shared__ uint32_t sa[256], sb[256];
+    __shared__ uint32_t carry_a, carry_b;
+    const int t = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    uint32_t *la = tile_less + q * nblk, *lb = tile_eq + q * nblk;
+    if (t == 0) { carry_a = 0; carry_b = 0; }
+    __syncthreads();
+    // pass 1: totals of "less" (the "equal" block starts after all of them)
+    uint32_t part = 0;
+    for (int b = t; b < nblk; b += 256) part += la[b];
+    sa[t] = part;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (t < off) sa[t] += sa[t + off]; __syncthreads(); }
+    const uint32_t total_less = sa[0];
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += 256) {
+        const int b = b0 + t;
+        const uint32_t va = b < nblk ? la[b] : 0u, vb = b < nblk ? lb[b] : 0u;
+        sa[t] = va; sb[t] = vb;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t xa = t >= off ? sa[t - off] : 0u, xb = t >= off ? sb[t - off] : 0u;
+            __syncthreads();
+            sa[t] += xa; sb[t] += xb;
+            __syncthreads();
+        }
+        if (b < nblk) { la[b] = carry_a + sa[t] - va; lb[b] = total_less + carry_b + sb[t] - vb; }
+        __syncthreads();
+        if (t == 255) { carry_a += sa[255]; carry_b += sb[255]; }
+        __syncthreads();
+    }
+}
+
+// ordered compaction of the candidates of one tile: (score, id) at their block offsets, id order kept
+__global__ __launch_bounds__(SORT_THREADS) void select_scatter_kernel(const float *__restrict__ scores, int64_t n,
+                                                                      int nblk, const SelState *__restrict__ st,
+                                                                      const uint32_t *__restrict__ off_less,
+                                                                      const uint32_t *__restrict__ off_eq,
+                                                                      uint32_t cap_total,
+                                                                      float *__restrict__ cand_scores,
+                                                                      uint32_t *__restrict__ cand_ids)
+{
+    __shared__ uint32_t wl[SORT_WAVES], we[SORT_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.y, b = blockIdx.x;
+    const SelState s = st[q];
+    const int64_t sub0 = b * SORT_TILE + wave * SUB_TILE;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    float v[SORT_ITEMS];
+    uint32_t pl[SORT_ITEMS], pe[SORT_ITEMS];        // position inside the wave's less / equal sequence (or ~0)
+    uint32_t nl = 0, ne = 0;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t i = sub0 + r * 64 + lane;
+        v[r] = i < n ? scores[q * n + i] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t i = sub0 + r * 64 + lane;
+        const uint32_t km = desc_key(v[r]) & s.mask;
+        const bool is_l = i < n && km < s.prefix, is_e = i < n && km == s.prefix;
+        const uint64_t ml = __ballot(is_l), me = __ballot(is_e);
+        pl[r] = is_l ? nl + __popcll(ml & lt_mask) : 0xFFFFFFFFu;
+        pe[r] = is_e ? ne + __popcll(me & lt_mask) : 0xFFFFFFFFu;
+        nl += __popcll(ml);
+        ne += __popcll(me);
+    }
+    if (lane == 0) { wl[wave] = nl; we[wave] = ne; }
+    __syncthreads();
+    uint32_t bl = off_less[q * nblk + b], be = off_eq[q * nblk + b];
+    for (int w = 0; w < wave; ++w) { bl += wl[w]; be += we[w]; }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t pos = pl[r] != 0xFFFFFFFFu ? bl + pl[r] : (pe[r] != 0xFFFFFFFFu ? be + pe[r] : 0xFFFFFFFFu);
+        if (pos < cap_total) {
+            cand_scores[q * cap_total + pos] = v[r];
+            cand_ids[q * cap_total + pos] = (uint32_t)(sub0 + r * 64 + lane);
+        }
+    }
+}
+
+__global__ void select_init_kernel(SelState *st, int64_t nq, uint32_t k)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) st[q] = SelState{0u, 0u, k, 0u};
+}
+
+__global__ void select_gather_kernel(const int64_t *__restrict__ local, const float *__restrict__ cand_scores,
+                                     const uint32_t *__restrict__ cand_ids, int64_t nq, int64_t k,
+                                     uint32_t cap_total, int64_t id_offset, int64_t *__restrict__ top_ids,
+                                     float *__restrict__ top_scores)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * k) return;
+    const int64_t q = t / k, j = local[t];
+    if (top_ids) top_ids[t] = (int64_t)cand_ids[q * cap_total + j] + id_offset;
+    if (top_scores) top_scores[t] = cand_scores[q * cap_total + j];
+}
+
+// workspace carve-up of the select path (lives inside a workspace sized by mdx_rank_workspace(n, nq))
+struct SelWs {
+    uint32_t *block_hist, *tile_less, *tile_eq, *cand_ids;
+    SelState *state;
+    float *cand_scores;
+    int64_t *local;
+    char *sort_ws;
+    int64_t sort_ws_bytes;
+};
+
+static int64_t carve_select(SelWs *ws, char *base, int64_t n, int64_t nq, int64_t k)
+{
+    const int64_t nblk = ceil_div(n, SORT_TILE), ct = k + SEL_CAP;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { char *p = base ? base + off : nullptr; off += round_up(bytes, 256); return p; };
+    char *p;
+    p = take(nq * nblk * RADIX * 4); if (ws) ws->block_hist = (uint32_t *)p;
+    p = take(nq * nblk * 4);         if (ws) ws->tile_less = (uint32_t *)p;
+    p = take(nq * nblk * 4);         if (ws) ws->tile_eq = (uint32_t *)p;
+    p = take(nq * sizeof(SelState)); if (ws) ws->state = (SelState *)p;
+    p = take(nq * ct * 4);           if (ws) ws->cand_scores = (float *)p;
+    p = take(nq * ct * 4);           if (ws) ws->cand_ids = (uint32_t *)p;
+    p = take(nq * k * 8);            if (ws) ws->local = (int64_t *)p;
+    const int64_t sw = carve(nullptr, nullptr, ct, nq);
+    p = take(sw);                    if (ws) { ws->sort_ws = p; ws->sort_ws_bytes = sw; }
+    return off;
+}
+
+static int topk_select(const float *scores, int64_t n, int64_t nq, int64_t k, int64_t id_offset,
+                       int64_t *top_ids, float *top_scores, void *workspace, hipStream_t s)
+{
+    SelWs ws;
+    carve_select(&ws, (char *)workspace, n, nq, k);
+    const int nblk = (int)ceil_div(n, SORT_TILE);
+    const uint32_t ct = (uint32_t)(k + SEL_CAP);
+    const dim3 grid((unsigned)nblk, (unsigned)nq), blk(SORT_THREADS);
+    hipLaunchKernelGGL(select_init_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, s, ws.state, nq, (uint32_t)k);
+    MDX_HIP(hipMemsetAsync(ws.tile_less, 0, (size_t)nq * nblk * 4, s));
+    MDX_HIP(hipMemsetAsync(ws.cand_scores, 0xFF, (size_t)nq * ct * 4, s));      // NaN padding sorts last
+    MDX_HIP(hipMemsetAsync(ws.cand_ids, 0, (size_t)nq * ct * 4, s));
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        // level 1 always runs: one workgroup per tile; later levels usually exit at once: fewer workgroups
+        const dim3 hgrid((unsigned)((shift == 24 || nblk < 512) ? nblk : 512), (unsigned)nq);
+        hipLaunchKernelGGL(select_hist_kernel, hgrid, blk, 0, s, scores, n, nblk, shift, ws.state, ws.block_hist);
+        hipLaunchKernelGGL(select_step_kernel, dim3((unsigned)nq), dim3(1024), 0, s, ws.block_hist, nblk, shift,
+                           ws.state, ws.tile_less, ws.tile_eq);
+    }
+    hipLaunchKernelGGL(select_offsets_kernel, dim3((unsigned)nq), dim3(256), 0, s, ws.tile_less, ws.tile_eq, nblk);
+    hipLaunchKernelGGL(select_scatter_kernel, grid, blk, 0, s, scores, n, nblk, ws.state, ws.tile_less, ws.tile_eq,
+                       ct, ws.cand_scores, ws.cand_ids);
+    MDX_LAUNCH_CHECK();
+    int rc = rank_impl(ws.cand_scores, ct, nq, 0, ws.local, nullptr, k, ws.sort_ws, ws.sort_ws_bytes, s, "mdx_topk");
+    if (rc != MDX_OK) return rc;
+    hipLaunchKernelGGL(select_gather_kernel, dim3((unsigned)ceil_div(nq * k, 256)), dim3(256), 0, s, ws.local,
+                       ws.cand_scores, ws.cand_ids, nq, k, ct, id_offset, top_ids, top_scores);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
 }  // namespace mdx
 
 using namespace mdx;
@@ -447,6 +713,15 @@ int mdx_topk(const float *scores, int64_t n, int64_t nq, int64_t k, int64_t id_o
     MDX_CHECK_ARG(k > 0 && k <= n, "mdx_topk: k=%lld out of range (n=%lld)", (long long)k,
                   (long long)n);
     MDX_CHECK_ARG(top_ids || top_scores, "mdx_topk: both outputs NULL");
+    MDX_CHECK_ARG(scores && n > 0 && nq > 0 && n < (1ll << 32) && nq < 65536, "mdx_topk: bad sizes");
+    const int64_t need = carve(nullptr, nullptr, n, nq);
+    if (!workspace || workspace_bytes < need) {
+        set_error("mdx_topk: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+        return MDX_ERR_WORKSPACE;
+    }
+    // k << n: radix select + sort of the candidates; otherwise the full ranking, trimmed in its last pass
+    if (4 * (k + SEL_CAP) <= n && carve_select(nullptr, nullptr, n, nq, k) <= workspace_bytes)
+        return topk_select(scores, n, nq, k, id_offset, top_ids, top_scores, workspace, (hipStream_t)stream);
     return rank_impl(scores, n, nq, id_offset, top_ids, top_scores, k, workspace, workspace_bytes,
                      (hipStream_t)stream, "mdx_topk");
 }

@@ -241,3 +241,25 @@ def test_rank_full_degenerate_distributions(ops, kind):
         np.testing.assert_array_equal(got[0], np.arange(n))
     ids, _ = ops.topk(dev(sc), 257)
     np.testing.assert_array_equal(ids.cpu().numpy(), want[:, :257])
+
+
+@pytest.mark.parametrize("n,nq,k,kind", [(200000, 5, 100, "gauss"), (70000, 3, 1, "gauss"), (65536, 4, 1000, "ties"),
+                                         (100000, 2, 50, "allequal"), (300000, 3, 257, "concentrated"),
+                                         (50000, 2, 10, "nan"), (20000, 6, 100, "gauss"), (1000, 3, 10, "gauss"),
+                                         (40000, 2, 5000, "gauss")])
+def test_topk_radix_select(ops, n, nq, k, kind):
+    """mdx_topk (radix select for k << n, trimmed full sort otherwise) = first k of the oracle ranking."""
+    rng = np.random.default_rng(n + k)
+    sc = (rng.standard_normal((nq, n)) * 0.022).astype(np.float32)
+    if kind == "ties":
+        sc = (np.round(sc * 50) / 50).astype(np.float32)
+    if kind == "allequal":
+        sc[:] = 0.125
+    if kind == "concentrated":
+        sc = (0.3 + rng.standard_normal((nq, n)) * 1e-4).astype(np.float32)
+    if kind == "nan":
+        sc[:, ::3] = np.nan
+    want = OC.rank_full(sc)[:, :k]
+    ids, vals = ops.topk(dev(sc), k, id_offset=7)
+    np.testing.assert_array_equal(ids.cpu().numpy(), want + 7)
+    np.testing.assert_array_equal(vals.cpu().numpy(), np.take_along_axis(sc, want, axis=1))
