@@ -147,3 +147,87 @@ class ShardedIndex:
         if self.world > 1:
             self._all_reduce_sum(cnt)
         return cnt, offsets
+
+
+# ---------------------------------------------------------------------------
+# Extraction is embarrassingly parallel over images: rank g extracts the contiguous slice of
+# database images that is going to be ITS shard anyway, so descriptors never move between
+# GPUs; only the (few) query descriptors are exchanged.
+# ---------------------------------------------------------------------------
+
+def extract_shard(net, images, image_size, transform, device, group=None, **kwargs):
+    """Descriptors ``[n_local, D]`` (device) of this rank's slice ``images[lo:hi]`` plus ``(lo, hi)``."""
+    from .networks import extract_vectors_device
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(len(images), world, rank)
+    vecs = extract_vectors_device(net, images[lo:hi], image_size, transform, device=device, **kwargs)
+    return vecs, (lo, hi)
+
+
+def gather_query_vectors(local_q, nq_total, group=None):
+    """All ranks' slices of the query descriptors -> the full ``[Q, D]`` on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_q
+    staged = dist.get_backend(group) == "gloo" and local_q.is_cuda
+    d = local_q.shape[1]
+    pieces = []
+    for r in range(world):
+        lo, hi = shard_bounds(nq_total, world, r)
+        pieces.append(torch.empty((hi - lo, d), dtype=local_q.dtype, device="cpu" if staged else local_q.device))
+    mine = local_q.cpu() if staged else local_q.contiguous()
+    if _even(pieces):
+        dist.all_gather(pieces, mine, group=group)
+    else:
+        _all_gather_uneven(pieces, mine, group)
+    return torch.cat(pieces, dim=0).to(local_q.device)
+
+
+def _even(pieces):
+    return len({p.shape[0] for p in pieces}) == 1
+
+
+def _all_gather_uneven(pieces, mine, group):
+    """Slices differ by at most one row: broadcast each rank's piece (tiny tensors)."""
+    rank = dist.get_rank(group)
+    for r, p in enumerate(pieces):
+        if r == rank:
+            p.copy_(mine)
+        dist.broadcast(p, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+
+
+def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, transform, device,
+                          group=None, backend=None, **kwargs):
+    """Distributed form of ``CirDatasetAp.__call__`` (cirscore.py:49-71): every rank extracts its
+    slice of the database (which stays resident as its shard) and its slice of the queries, query
+    descriptors are all-gathered, similarities are computed against the local shard, and mAP comes
+    from the sort-free position counts.  Returns the same ``(averages, per_query)`` on every rank."""
+    from .evaluate import _evaluate, map_from_positions
+    import numpy as np
+    vecs, _ = extract_shard(net, images, image_size, transform, device, group, **kwargs)
+    if images == qimages and set(bbxs) == {None}:
+        qlocal = vecs            # the query set IS the database (cirscore.py:56-57): slices coincide
+    else:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        qlo, qhi = shard_bounds(len(qimages), world, rank)
+        from .networks import extract_vectors_device
+        qlocal = extract_vectors_device(net, qimages[qlo:qhi], image_size, transform, device=device,
+                                        bbxs=bbxs[qlo:qhi] if bbxs else None, **kwargs) if qhi > qlo else \
+            torch.empty((0, vecs.shape[1]), dtype=torch.float32, device=vecs.device)
+    qvecs = gather_query_vectors(qlocal, len(qimages), group)
+    index = ShardedIndex(vecs, "ND", len(images), group=group, backend=backend)
+    s_local = index.local_scores(qvecs.contiguous(), "ND")
+
+    def one_map(g, kappas):
+        oks = [np.asarray(x["ok"], dtype=np.int64).reshape(-1) for x in g]
+        junks = [np.asarray(x["junk"], dtype=np.int64).reshape(-1) if "junk" in x and len(o) else
+                 np.empty(0, dtype=np.int64) for x, o in zip(g, oks)]
+        pos, off = index.positions(s_local, [np.concatenate([o, j]) for o, j in zip(oks, junks)])
+        pos = pos.cpu().numpy()
+        pl = [pos[off[q]:off[q] + len(oks[q])] for q in range(len(g))]
+        jl = [pos[off[q] + len(oks[q]):off[q + 1]] for q in range(len(g))]
+        return map_from_positions(pl, jl, [len(o) for o in oks], kappas)
+
+    return _evaluate(dataset, gnd, [1, 5, 10], one_map)

@@ -77,7 +77,37 @@ def rank_of(scores, id_lists):
             torch.from_numpy(np.concatenate(sc).astype(np.float32) if sc else np.empty(0, np.float32)), off)
 
 
+def gather_scores(scores, ids_t, off_t):
+    s, off, ids = scores.detach().numpy(), off_t.numpy(), ids_t.numpy()
+    out = np.empty(len(ids), dtype=np.float32)
+    for q in range(len(off) - 1):
+        out[off[q]:off[q + 1]] = s[q][ids[off[q]:off[q + 1]]]
+    return torch.from_numpy(out)
+
+
+def rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, off_t):
+    s, off = scores.detach().numpy(), off_t.numpy()
+    for q in range(len(off) - 1):
+        keys = np.array([OC.desc_key(x) for x in s[q]], dtype=np.uint64)
+        gid = np.arange(s.shape[1]) + id_offset
+        for t in range(off[q], off[q + 1]):
+            rk, ri = OC.desc_key(float(ref_scores[t])), int(ref_ids[t])
+            cnt[t] += int(np.count_nonzero((keys < rk) | ((keys == rk) & (gid < ri))))
+    return cnt
+
+
+NAMES = ("pool_l2n", "l2n_rows_", "ms_aggregate", "DescriptorIndex", "rank_full", "topk", "rank_of",
+         "gather_scores", "rank_count_")
+
+
+def install_globally():
+    """For worker processes of the multi-process tests (no monkeypatch fixture there)."""
+    from mdir_amd import ops
+    for name in NAMES:
+        setattr(ops, name, globals()[name])
+
+
 def install(monkeypatch):
     from mdir_amd import ops
-    for name in ("pool_l2n", "l2n_rows_", "ms_aggregate", "DescriptorIndex", "rank_full", "topk", "rank_of"):
+    for name in NAMES:
         monkeypatch.setattr(ops, name, globals()[name])

@@ -123,3 +123,69 @@ def test_default_backend_is_hip_and_refuses_cpu():
     from mdir_amd.sharded import ShardedIndex
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ShardedIndex(torch.zeros(8, 16), "DN", 16)
+
+
+def _map_worker(rank, world, port, root, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MDIR_AMD_WORKERS="0", CIRTORCH_ROOT=root)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fake_ops
+    fake_ops.install_globally()
+    import pickle
+    from mdir_amd.datasets import configdataset, initialize_transforms
+    from mdir_amd.networks import init_network
+    from mdir_amd.sharded import sharded_retrieval_map
+    torch.manual_seed(0)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False}).eval()
+    net.meta["out_channels"] = 256
+    tr = initialize_transforms("pil2np | totensor | normalize", [net.meta["mean"], net.meta["std"]])
+    res = {}
+    for ds in ("roxford5k", "247tokyo1k"):
+        cfg = configdataset(ds, os.path.join(root, "data", "test"))
+        images = [cfg["im_fname"](cfg, i) for i in range(cfg["n"])]
+        qimages = [cfg["qim_fname"](cfg, i) for i in range(cfg["nq"])]
+        bbxs = [tuple(g["bbx"]) if g.get("bbx") else None for g in cfg["gnd"]]
+        with torch.no_grad():
+            avg, per = sharded_retrieval_map(net, images, qimages, bbxs, cfg["gnd"], ds, 224, tr, "cpu")
+        res[ds] = (avg, {k: np.asarray(v) for k, v in per.items()})
+    with open(os.path.join(out_dir, "map%d.pkl" % rank), "wb") as f:
+        pickle.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_sharded_extraction_and_map_equal_single_process(tmp_path, monkeypatch):
+    """Each rank extracts its slice of the database (= its shard) and of the queries; the sort-free
+    distributed mAP equals the single-process CirDatasetAp on the same data (both protocols,
+    incl. the query == database shortcut of 247tokyo1k)."""
+    import pickle
+    import subprocess
+    import fake_ops
+    root = str(tmp_path / "synth")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_eval.py"), root],
+                          stdout=subprocess.DEVNULL)
+    mp.spawn(_map_worker, args=(2, _free_port(), root, str(tmp_path)), nprocs=2, join=True)
+    got = [pickle.load(open(tmp_path / ("map%d.pkl" % r), "rb")) for r in range(2)]
+    # single process, full ranking route
+    fake_ops.install(monkeypatch)
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    monkeypatch.setenv("CIRTORCH_ROOT", root)
+    from mdir_amd.networks import init_network
+    from mdir_amd.score import initialize_score
+    torch.manual_seed(0)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False}).eval()
+    net.meta["out_channels"] = 256
+    for ds in ("roxford5k", "247tokyo1k"):
+        score = initialize_score({"type": "cirdatasetap", "image_size": 224, "dataset": ds,
+                                  "transforms": "pil2np | totensor | normalize",
+                                  "mean_std": [net.meta["mean"], net.meta["std"]]})
+        rows = []
+        with torch.no_grad():
+            score(net, "cpu", lambda it, size, label, value, dtype: rows.append((label, value)))
+        want_avg = rows[1][1]
+        for r in range(2):
+            avg, per = got[r][ds]
+            assert avg.keys() == want_avg.keys()
+            for k in avg:
+                np.testing.assert_allclose(avg[k], want_avg[k], rtol=0, atol=1e-12)
+        assert got[0][ds][0] == got[1][ds][0]
