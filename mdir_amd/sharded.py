@@ -55,6 +55,27 @@ def query_bounds(nq, world, rank):
     return shard_bounds(nq, world, rank)
 
 
+def exchange_chunks(n_total, world):
+    """How many row chunks every shard is cut into so that the all-to-all of chunk c runs on
+    RCCL's stream while the similarity kernel of chunk c+1 runs on the compute stream.  Chunks
+    below ~250 k rows cost more in kernel efficiency than the hidden transfer gains (measured:
+    tools/shard_model.py), so only big shards (G=2 at 1 M rows) are split.  Same value on every
+    rank (derived from the largest shard)."""
+    import os
+    forced = os.environ.get("MDIR_AMD_EXCHANGE_CHUNKS")
+    if forced:
+        return max(1, int(forced))
+    if world == 1:
+        return 1
+    biggest = shard_bounds(n_total, world, 0)[1]
+    return max(1, min(4, biggest // 250_000))
+
+
+def chunk_bounds(lo, hi, chunks):
+    """Chunk c of rows ``[lo, hi)``: the same near-equal contiguous split as ``shard_bounds``."""
+    return [tuple(lo + x for x in shard_bounds(hi - lo, chunks, c)) for c in range(chunks)]
+
+
 class ShardedIndex:
     def __init__(self, local_vecs, layout, n_total, group=None, backend=None):
         self.group = group
@@ -62,23 +83,25 @@ class ShardedIndex:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_total = int(n_total)
         self.lo, self.hi = shard_bounds(self.n_total, self.world, self.rank)
-        n_local = local_vecs.shape[1] if layout in ("DN", "dim_major") else local_vecs.shape[0]
+        dim_major = layout in ("DN", "dim_major")
+        n_local = local_vecs.shape[1] if dim_major else local_vecs.shape[0]
         if n_local != self.hi - self.lo:
             raise ValueError("rank %d holds %d rows, expected %d" % (self.rank, n_local, self.hi - self.lo))
         self.backend = backend or HipBackend()
-        self.index = self.backend.make_index(local_vecs, layout, self.lo)
         self.device = local_vecs.device
+        self.chunks = exchange_chunks(self.n_total, self.world)
+        self.parts = []                    # (lo, hi, index) per chunk, ascending rows
+        for a, b in chunk_bounds(self.lo, self.hi, self.chunks):
+            if self.chunks == 1:
+                piece = local_vecs
+            else:
+                piece = (local_vecs[:, a - self.lo:b - self.lo] if dim_major else local_vecs[a - self.lo:b - self.lo])
+                piece = piece.contiguous()
+            self.parts.append((a, b, self.backend.make_index(piece, layout, a)))
+        self.index = self.parts[0][2] if self.chunks == 1 else None
         # RCCL moves device buffers directly; under gloo (CPU tests, or several ranks
         # sharing one GPU for a dry run) collectives are staged through host memory.
         self._host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
-
-    def _all_to_all(self, recv, send, out_split, in_split):
-        if self._host_staged:
-            r = torch.empty(recv.shape, dtype=recv.dtype)
-            dist.all_to_all_single(r, send.cpu(), out_split, in_split, group=self.group)
-            recv.copy_(r)
-        else:
-            dist.all_to_all_single(recv, send, out_split, in_split, group=self.group)
 
     def _all_reduce_sum(self, t):
         if self._host_staged:
@@ -91,32 +114,82 @@ class ShardedIndex:
     # ------------------------------------------------------------------ scores
     def local_scores(self, queries, qlayout="DN"):
         """``[Q, n_local]`` similarities against this rank's rows (no communication)."""
-        return self.index.scores(queries, qlayout)
+        if self.chunks == 1:
+            return self.index.scores(queries, qlayout)
+        return torch.cat([ix.scores(queries, qlayout) for _, _, ix in self.parts], dim=1)
 
     # ----------------------------------------------------------- full ranking
+    def _peer_widths(self, c):
+        """Rows of chunk ``c`` on every rank (what each peer sends me per query)."""
+        out = []
+        for r in range(self.world):
+            a, b = chunk_bounds(*shard_bounds(self.n_total, self.world, r), self.chunks)[c]
+            out.append(b - a)
+        return out
+
+    def _start_exchange(self, s_part, widths):
+        """Enqueue the all-to-all that turns "all queries x my rows" into "my queries x every
+        peer's rows" for one chunk.  Returns ``(work, recv, host_recv, keepalive)``; the
+        collective runs on the communicator's own stream, so kernels launched next on the
+        compute stream overlap with it."""
+        nq = s_part.shape[0]
+        qlo, qhi = query_bounds(nq, self.world, self.rank)
+        in_split = [(query_bounds(nq, self.world, r)[1] - query_bounds(nq, self.world, r)[0]) * s_part.shape[1]
+                    for r in range(self.world)]
+        out_split = [(qhi - qlo) * w for w in widths]
+        recv = torch.empty(sum(out_split), dtype=s_part.dtype, device=s_part.device)
+        if self._host_staged:
+            send, host_recv = s_part.reshape(-1).cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            work = dist.all_to_all_single(host_recv, send, out_split, in_split, group=self.group, async_op=True)
+        else:
+            send, host_recv = s_part.reshape(-1), None
+            work = dist.all_to_all_single(recv, send, out_split, in_split, group=self.group, async_op=True)
+        return work, recv, host_recv, send
+
+    def _finish_exchange(self, pending, widths, nq_mine):
+        work, recv, host_recv, _send = pending
+        work.wait()                                   # compute stream waits for the collective
+        if host_recv is not None:
+            recv.copy_(host_recv)
+        blocks, o = [], 0
+        for w in widths:
+            blocks.append(recv[o:o + nq_mine * w].view(nq_mine, w))
+            o += nq_mine * w
+        return blocks
+
     def exchange(self, s_local):
-        """``[Q, n_local]`` on every rank  ->  ``[Q_mine, N]`` on every rank."""
+        """``[Q, n_local]`` on every rank  ->  ``[Q_mine, N]`` on every rank (one all-to-all)."""
         nq = s_local.shape[0]
         if self.world == 1:
             return s_local, (0, nq)
         qlo, qhi = query_bounds(nq, self.world, self.rank)
-        in_split = [(query_bounds(nq, self.world, r)[1] - query_bounds(nq, self.world, r)[0]) * s_local.shape[1]
-                    for r in range(self.world)]
         widths = [shard_bounds(self.n_total, self.world, r)[1] - shard_bounds(self.n_total, self.world, r)[0]
                   for r in range(self.world)]
-        out_split = [(qhi - qlo) * w for w in widths]
-        recv = torch.empty(sum(out_split), dtype=s_local.dtype, device=s_local.device)
-        self._all_to_all(recv, s_local.reshape(-1), out_split, in_split)
-        blocks, o = [], 0
-        for w, sz in zip(widths, out_split):
-            blocks.append(recv[o:o + sz].view(qhi - qlo, w))
-            o += sz
+        blocks = self._finish_exchange(self._start_exchange(s_local, widths), widths, qhi - qlo)
+        return torch.cat(blocks, dim=1), (qlo, qhi)
+
+    def exchanged_scores(self, queries, qlayout="DN"):
+        """Similarities of MY queries against ALL rows: per chunk, similarity kernel then
+        all-to-all, with chunk c's transfer overlapping chunk c+1's kernel."""
+        if self.world == 1:
+            s = self.local_scores(queries, qlayout)
+            return s, (0, s.shape[0])
+        pending, nq = [], None
+        for c, (_, _, ix) in enumerate(self.parts):
+            s_part = ix.scores(queries, qlayout)
+            nq = s_part.shape[0]
+            widths = self._peer_widths(c)
+            pending.append((self._start_exchange(s_part, widths), widths))
+        qlo, qhi = query_bounds(nq, self.world, self.rank)
+        per_chunk = [self._finish_exchange(p, widths, qhi - qlo) for p, widths in pending]
+        # global row order: peer-major, chunk-minor
+        blocks = [per_chunk[c][r] for r in range(self.world) for c in range(self.chunks)]
         return torch.cat(blocks, dim=1), (qlo, qhi)
 
     def rank_queries(self, queries, qlayout="DN"):
         """Exact full ranking, query-partitioned: returns ``(ranks [Q_mine, N] int64
         with GLOBAL ids, scores [Q_mine, N], (qlo, qhi))``."""
-        s_mine, (qlo, qhi) = self.exchange(self.local_scores(queries, qlayout))
+        s_mine, (qlo, qhi) = self.exchanged_scores(queries, qlayout)
         if qhi == qlo:
             return torch.empty((0, self.n_total), dtype=torch.int64, device=self.device), s_mine, (qlo, qhi)
         return self.backend.rank_full(s_mine, 0), s_mine, (qlo, qhi)

@@ -61,10 +61,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, nq, d, out_dir):
+def _worker(rank, world, port, n, nq, d, out_dir, chunks):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if chunks:
+        os.environ["MDIR_AMD_EXCHANGE_CHUNKS"] = str(chunks)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mdir_amd.sharded import ShardedIndex, shard_bounds
     from oracle import oracle as O
@@ -73,6 +75,7 @@ def _worker(rank, world, port, n, nq, d, out_dir):
     vecs[:, 7] = vecs[:, 3]; vecs[:, n - 1] = vecs[:, 3]       # exact ties across shards
     lo, hi = shard_bounds(n, world, rank)
     sh = ShardedIndex(torch.from_numpy(np.ascontiguousarray(vecs[:, lo:hi])), "DN", n, backend=OracleBackend())
+    assert sh.chunks == (chunks or 1) and len(sh.parts) == sh.chunks
     rk, sc, (qlo, qhi) = sh.rank_queries(torch.from_numpy(qvecs), "DN")
     gnd = O.synth_gnd(nq, n, seed=1, easy=3, hard=4, junk=2)
     lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
@@ -83,12 +86,14 @@ def _worker(rank, world, port, n, nq, d, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,nq", [(2, 301, 7), (3, 100, 2)])
-def test_sharded_equals_single_process(tmp_path, world, n, nq):
+@pytest.mark.parametrize("world,n,nq,chunks", [(2, 301, 7, 0), (3, 100, 2, 0), (2, 301, 7, 3), (3, 101, 5, 2)])
+def test_sharded_equals_single_process(tmp_path, world, n, nq, chunks):
+    """chunks > 0: every shard is cut into row chunks whose all-to-alls are in flight together
+    (the overlap pipeline used for big shards)."""
     from oracle import chain as OC
     from oracle import oracle as O
     d = 32
-    mp.spawn(_worker, args=(world, _free_port(), n, nq, d, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, nq, d, str(tmp_path), chunks), nprocs=world, join=True)
     vecs, qvecs, _ = O.synth_ranking_problem(n, nq, d, seed=4)
     vecs[:, 7] = vecs[:, 3]; vecs[:, n - 1] = vecs[:, 3]
     want_sc = OC.scores_chain(vecs, qvecs)
@@ -106,6 +111,16 @@ def test_sharded_equals_single_process(tmp_path, world, n, nq):
         for q in range(nq):
             np.testing.assert_array_equal(g["pos"][g["off"][q]:g["off"][q + 1]], OC.rank_of(want_sc[q], lists[q]))
     assert covered == nq
+
+
+def test_exchange_chunk_policy():
+    from mdir_amd.sharded import chunk_bounds, exchange_chunks
+    assert exchange_chunks(1004993, 1) == 1
+    assert exchange_chunks(1004993, 2) == 2          # 502 k-row shards: transfer hidden behind the second half
+    assert exchange_chunks(1004993, 4) == 1 and exchange_chunks(1004993, 8) == 1
+    assert exchange_chunks(4993, 8) == 1
+    b = chunk_bounds(10, 21, 3)
+    assert b[0][0] == 10 and b[-1][1] == 21 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
 
 
 def test_shard_bounds_cover_everything():
