@@ -39,20 +39,25 @@ __device__ __forceinline__ uint32_t load_key(const float *scores, const uint32_t
 #endif
 constexpr int HIST_TILES = MDX_HIST_TILES;
 
+// LDS sub-histograms are selected by LANE (not by wave): when a digit is concentrated in a few
+// values (the top byte of cosine scores: sign + 7 exponent bits) at most 64/HIST_COPIES lanes of
+// one ds_add hit the same address.  Row stride RADIX+1 keeps the copies in different banks.
+constexpr int HIST_COPIES = 8;
+
 template <bool FIRST>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__restrict__ scores,
                                                                  const uint32_t *__restrict__ keys,
                                                                  int64_t n, int nblk, int shift,
                                                                  uint32_t *__restrict__ block_hist)
 {
-    __shared__ uint32_t h[HIST_TILES][SORT_WAVES / 2][RADIX];
-    const int tid = threadIdx.x, wave = tid >> 6;
+    __shared__ uint32_t h[HIST_TILES][HIST_COPIES][RADIX + 1];
+    const int tid = threadIdx.x, copy = tid & (HIST_COPIES - 1);
 #ifdef MDX_HIST_REVERSE
     const int64_t q = blockIdx.y, b0 = ((int64_t)gridDim.x - 1 - blockIdx.x) * HIST_TILES;   // newest data first
 #else
     const int64_t q = blockIdx.y, b0 = (int64_t)blockIdx.x * HIST_TILES;
 #endif
-    for (int e = tid; e < HIST_TILES * (SORT_WAVES / 2) * RADIX; e += SORT_THREADS) (&h[0][0][0])[e] = 0;
+    for (int e = tid; e < HIST_TILES * HIST_COPIES * (RADIX + 1); e += SORT_THREADS) (&h[0][0][0])[e] = 0;
     const int64_t base = q * n;
     uint32_t k[HIST_TILES][SORT_ITEMS];
 #pragma unroll
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r) {
             const int64_t i = (b0 + t) * SORT_TILE + r * SORT_THREADS + tid;
-            if (i < n) atomicAdd(&h[t][wave >> 1][(k[t][r] >> shift) & 255u], 1u);
+            if (i < n) atomicAdd(&h[t][copy][(k[t][r] >> shift) & 255u], 1u);
         }
     __syncthreads();
     for (int e = tid; e < HIST_TILES * RADIX; e += SORT_THREADS) {
@@ -76,38 +81,38 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__
         if (b0 + t < nblk) {
             uint32_t tot = 0;
 #pragma unroll
-            for (int w = 0; w < SORT_WAVES / 2; ++w) tot += h[t][w][d];
+            for (int w = 0; w < HIST_COPIES; ++w) tot += h[t][w][d];
             block_hist[(q * nblk + b0 + t) * RADIX + d] = tot;
         }
     }
 }
 
-// per query: exclusive prefix over tiles for each digit (in place) + digit bases.
-// 1024 threads = 4 groups x 256 digits; group g scans a quarter of the tiles (sum pass,
-// then prefix pass -- block_hist is L2-resident), so the serial chain is nblk/4 long.
-constexpr int SCAN_GROUPS = 4;
+// per query and per slice of 32 digits: exclusive prefix over tiles for each digit (in place)
+// + the per-query digit totals (the scatter kernel turns them into digit bases in the same
+// single-wave scan it already runs).  1024 threads = 32 groups x 32 digits; group g scans 1/32 of
+// the tiles (sum pass, then prefix pass -- block_hist is L2-resident), so the serial chain is
+// nblk/32 long and 8 workgroups per query run in parallel: this kernel is pure latency, and with
+// one workgroup per query it was a quarter of the sort at small nq.
+constexpr int SCAN_GROUPS = 32, SCAN_DIGITS = 32;
 
-__global__ __launch_bounds__(256 * SCAN_GROUPS) void sort_scan_kernel(uint32_t *__restrict__ block_hist,
-                                                                      int nblk,
-                                                                      uint32_t *__restrict__ digit_base)
+__global__ __launch_bounds__(SCAN_GROUPS * SCAN_DIGITS) void sort_scan_kernel(uint32_t *__restrict__ block_hist,
+                                                                              int nblk,
+                                                                              uint32_t *__restrict__ digit_tot)
 {
-    __shared__ uint32_t part[SCAN_GROUPS][RADIX];
-    __shared__ uint32_t s[RADIX];
-    const int d = threadIdx.x & 255, g = threadIdx.x >> 8;
+    __shared__ uint32_t part[SCAN_GROUPS][SCAN_DIGITS + 1];
+    const int dl = threadIdx.x & (SCAN_DIGITS - 1), g = threadIdx.x / SCAN_DIGITS;
+    const int d = blockIdx.x * SCAN_DIGITS + dl;
+    const int64_t q = blockIdx.y;
     const int per = (nblk + SCAN_GROUPS - 1) / SCAN_GROUPS;
-    const int b0 = g * per, b1 = (b0 + per) < nblk ? (b0 + per) : nblk;
-    uint32_t *p = block_hist + (int64_t)blockIdx.x * nblk * RADIX + d;
+    const int b0 = g * per < nblk ? g * per : nblk, b1 = (b0 + per) < nblk ? (b0 + per) : nblk;
+    uint32_t *p = block_hist + q * nblk * RADIX + d;
     uint32_t sum = 0;
     for (int b = b0; b < b1; ++b) sum += p[(int64_t)b * RADIX];
-    part[g][d] = sum;
+    part[g][dl] = sum;
     __syncthreads();
-    uint32_t run = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_GROUPS; ++k) {
-        const uint32_t v = part[k][d];
-        if (k < g) run += v;
-        total += v;
-    }
+    uint32_t run = 0;
+    for (int k = 0; k < g; ++k) run += part[k][dl];
+    if (g == SCAN_GROUPS - 1) digit_tot[q * RADIX + d] = run + sum;
     int b = b0;
     for (; b + 8 <= b1; b += 8) {
         uint32_t c[8];
@@ -124,16 +129,6 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void sort_scan_kernel(uint32_t *
         p[(int64_t)b * RADIX] = run;
         run += c;
     }
-    // exclusive scan of the digit totals (group 0 only)
-    if (g == 0) s[d] = total;
-    __syncthreads();
-    for (int off = 1; off < RADIX; off <<= 1) {
-        const uint32_t v = (g == 0 && d >= off) ? s[d - off] : 0u;
-        __syncthreads();
-        if (g == 0) s[d] += v;
-        __syncthreads();
-    }
-    if (g == 0) digit_base[(int64_t)blockIdx.x * RADIX + d] = s[d] - total;
 }
 
 // stable scatter of one tile.  Element order inside a query = (tile, wave, round,
@@ -142,13 +137,14 @@ __global__ __launch_bounds__(256 * SCAN_GROUPS) void sort_scan_kernel(uint32_t *
 // tile is then put in digit order in LDS, so that consecutive lanes write
 // consecutive global addresses inside each digit run (coalesced scatter).
 template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : SORT_WAVES / 2)) void sort_scatter_kernel(
+__global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAVES) / 4)) void sort_scatter_kernel(
     const float *__restrict__ scores, const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, int64_t *__restrict__ ranks, float *__restrict__ top_scores,
     int64_t n, int nblk, int shift, const uint32_t *__restrict__ block_hist,
-    const uint32_t *__restrict__ digit_base, int64_t id_offset, int64_t klimit)
+    const uint32_t *__restrict__ digit_tot, int64_t id_offset, int64_t klimit)
 {
+    __shared__ uint32_t dtot[RADIX];        // per-query digit totals -> digit bases (scanned below)
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];     // per-wave digit counts, then tile-local offsets
     __shared__ uint32_t gdelta[RADIX];      // global position of a digit run minus its tile offset
     __shared__ uint32_t scan[RADIX];
@@ -181,6 +177,13 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : SORT_WAVES / 
     const int64_t sub0 = tile0 + wave * SUB_TILE;
     const int tile_n = (int)((n - tile0) < SORT_TILE ? (n - tile0) : SORT_TILE);
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS], pos[SORT_ITEMS];
+    // global start of every digit run of this tile + the query's digit totals: requested first,
+    // parked in LDS once the key loads are in flight (no register held across the ranking)
+    uint32_t gbase = 0, qtot = 0;
+    if (tid < RADIX) {
+        gbase = block_hist[(q * nblk + b) * RADIX + tid];
+        qtot = digit_tot[q * RADIX + tid];
+    }
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int64_t i = sub0 + r * 64 + lane;
@@ -188,8 +191,10 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : SORT_WAVES / 
         key[r] = valid ? load_key(scores, keys_in, base + i, FIRST) : 0xFFFFFFFFu;
         val[r] = FIRST ? (uint32_t)i : (valid ? vals_in[base + i] : 0u);
     }
-    // global start of every digit run of this tile: requested now, needed after the ranking
-    const uint32_t gbase = tid < RADIX ? digit_base[q * RADIX + tid] + block_hist[(q * nblk + b) * RADIX + tid] : 0u;
+    if (tid < RADIX) {
+        gdelta[tid] = gbase;
+        dtot[tid] = qtot;
+    }
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -221,7 +226,6 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : SORT_WAVES / 
             run += c;
         }
         scan[tid] = run;
-        gdelta[tid] = gbase;
     }
     __syncthreads();
     // exclusive scan of the 256 digit totals by ONE wave (4 digits per lane + shuffle scan):
@@ -229,20 +233,23 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : SORT_WAVES / 
     if (wave == 0) {
         const uint32_t t0 = scan[4 * lane], t1 = scan[4 * lane + 1], t2 = scan[4 * lane + 2],
                        t3 = scan[4 * lane + 3];
-        const uint32_t mine = t0 + t1 + t2 + t3;
-        uint32_t inc = mine;
+        const uint32_t g0 = dtot[4 * lane], g1 = dtot[4 * lane + 1], g2 = dtot[4 * lane + 2],
+                       g3 = dtot[4 * lane + 3];
+        const uint32_t mine = t0 + t1 + t2 + t3, gmine = g0 + g1 + g2 + g3;
+        uint32_t inc = mine, ginc = gmine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += v;
+            const uint32_t v = __shfl_up(inc, o, 64), gv = __shfl_up(ginc, o, 64);
+            if (lane >= o) { inc += v; ginc += gv; }
         }
-        const uint32_t ex = inc - mine;
+        const uint32_t ex = inc - mine, gex = ginc - gmine;
         const uint32_t toff[4] = {ex, ex + t0, ex + t0 + t1, ex + t0 + t1 + t2};
+        const uint32_t goff[4] = {gex, gex + g0, gex + g0 + g1, gex + g0 + g1 + g2};   // digit bases of the query
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int dgt = 4 * lane + k;
             scan[dgt] = toff[k];        // now: first slot of the digit in the tile
-            gdelta[dgt] -= toff[k];
+            gdelta[dgt] += goff[k] - toff[k];
         }
     }
     __syncthreads();
@@ -349,7 +356,7 @@ struct RankWs {
     uint32_t *keys[2];
     uint32_t *vals[2];
     uint32_t *block_hist;
-    uint32_t *digit_base;
+    uint32_t *digit_tot;
     int nblk;
 };
 
@@ -366,7 +373,7 @@ static int64_t carve(RankWs *ws, char *base, int64_t n, int64_t nq)
     }
     if (ws) ws->block_hist = (uint32_t *)(base + off);
     off += round_up(nq * nblk * RADIX * 4, 256);
-    if (ws) ws->digit_base = (uint32_t *)(base + off);
+    if (ws) ws->digit_tot = (uint32_t *)(base + off);
     off += round_up(nq * RADIX * 4, 256);
     if (ws) ws->nblk = (int)nblk;
     return off;
@@ -401,20 +408,20 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
         else
             hipLaunchKernelGGL(sort_hist_kernel<false>, hgrid, blk, 0, s, scores, kin, n, ws.nblk,
                                shift, ws.block_hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)nq), dim3(256 * SCAN_GROUPS), 0, s, ws.block_hist, ws.nblk,
-                           ws.digit_base);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX / SCAN_DIGITS, (unsigned)nq), dim3(SCAN_GROUPS * SCAN_DIGITS), 0, s,
+                           ws.block_hist, ws.nblk, ws.digit_tot);
         if (pass == 0)
             hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, blk, 0, s, scores, kin, vin,
                                kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
-                               ws.digit_base, id_offset, klimit);
+                               ws.digit_tot, id_offset, klimit);
         else if (pass < 3)
             hipLaunchKernelGGL((sort_scatter_kernel<false, false>), grid, blk, 0, s, scores, kin, vin,
                                kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
-                               ws.digit_base, id_offset, klimit);
+                               ws.digit_tot, id_offset, klimit);
         else
             hipLaunchKernelGGL((sort_scatter_kernel<false, true>), grid, blk, 0, s, scores, kin, vin,
                                kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
-                               ws.digit_base, id_offset, klimit);
+                               ws.digit_tot, id_offset, klimit);
         MDX_LAUNCH_CHECK();
     }
     return MDX_OK;

@@ -38,7 +38,7 @@ def main():
     full = ops.DescriptorIndex(rows, "ND").scores(q, "ND")
     base = None
     print("%2s %10s %9s %9s %9s %9s %9s %8s" % ("G", "rows/rank", "scores", "reblock", "sort", "a2a(model)", "total", "speedup"))
-    for G in (1, 2, 4, 8):
+    for G in ([int(a) for a in sys.argv[1:]] or (1, 2, 4, 8)):
         lo, hi = shard_bounds(n, G, 0)
         qlo, qhi = shard_bounds(nq, G, 0)
         ix = ops.DescriptorIndex(rows[lo:hi], "ND")
