@@ -47,11 +47,37 @@ def load_scenarios(names):
     return scenario
 
 
+def init_distributed():
+    """``python -m torch.distributed.run --nproc-per-node G eval.py ...``: one process per GPU; the
+    retrieval score then shards extraction and the database over the ranks (mdir_amd/sharded.py)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("MDIR_AMD_DRYRUN_ONE_GPU") == "1":
+        # functional dry run on a 1-GPU box: every rank on cuda:0, collectives staged through gloo
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return dist.get_rank()
+
+
 def main(argv):
     scenario = load_scenarios(argv)
     if not scenario:
         sys.stderr.write("Scenario needs to be specified\n")
         return 1
+    rank = init_distributed()
+    if rank != 0:
+        import contextlib
+        with open(os.devnull, "w") as sink, contextlib.redirect_stdout(sink):
+            stages.validate(scenario, ())
+        return 0
     metadata, = stages.validate(scenario, ())
     for heading, section in metadata.items():
         print("\n%s\n" % heading.capitalize())

@@ -65,6 +65,16 @@ class CirDatasetAp:
 
     def __call__(self, network, device, logger):
         stopwatch = StopWatch()
+        if _world_size() > 1:
+            # one process per GPU (torchrun eval.py ...): every rank extracts its slice of the
+            # database, which stays resident as its shard; same rows go to the logger on every rank
+            from .sharded import sharded_retrieval_map
+            print(">> {}: database + query images, rank {} of {}...".format(self.dataset, *_rank_world()))
+            averages, scores_per_query = sharded_retrieval_map(
+                network, self.images, self.qimages, self.bbxs, self.gnd, self.dataset, self.image_size,
+                self.transforms, device, lap=stopwatch.lap)
+            self._log(logger, stopwatch, averages, scores_per_query)
+            return
         print(">> {}: database images...".format(self.dataset))
         vecs = extract_vectors_device(network, self.images, self.image_size, self.transforms, device=device)
         print(">> {}: query images...".format(self.dataset))
@@ -85,7 +95,10 @@ class CirDatasetAp:
             averages, scores_per_query = compute_map_and_print_from_scores(self.dataset, scores, self.gnd)
         stopwatch.lap("compute_score")
         index.close()
+        self._log(logger, stopwatch, averages, scores_per_query)
 
+    @staticmethod
+    def _log(logger, stopwatch, averages, scores_per_query):
         first_score = scores_per_query[list(scores_per_query.keys())[0]]
         logger(None, len(first_score), "dataset", stopwatch.reset(), "scalar/time")
         logger(None, len(first_score), "score_avg", averages, "scalar/score")
@@ -93,6 +106,17 @@ class CirDatasetAp:
         for i, _ in enumerate(first_score):
             logger(i, len(first_score), "score", {x: scores_per_query[x][i] for x in scores_per_query},
                    "scalar/score")
+
+
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _world_size():
+    return _rank_world()[1]
 
 
 SCORES = {"cirdatasetap": CirDatasetAp}

@@ -271,7 +271,7 @@ def _all_gather_uneven(pieces, mine, group):
 
 
 def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, transform, device,
-                          group=None, backend=None, **kwargs):
+                          group=None, backend=None, lap=None, **kwargs):
     """Distributed form of ``CirDatasetAp.__call__`` (cirscore.py:49-71): every rank extracts its
     slice of the database (which stays resident as its shard) and its slice of the queries, query
     descriptors are all-gathered, similarities are computed against the local shard, and mAP comes
@@ -290,6 +290,8 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
                                         bbxs=bbxs[qlo:qhi] if bbxs else None, **kwargs) if qhi > qlo else \
             torch.empty((0, vecs.shape[1]), dtype=torch.float32, device=vecs.device)
     qvecs = gather_query_vectors(qlocal, len(qimages), group)
+    if lap:
+        lap("extract_descriptors")
     index = ShardedIndex(vecs, "ND", len(images), group=group, backend=backend)
     s_local = index.local_scores(qvecs.contiguous(), "ND")
 
@@ -303,4 +305,7 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
         jl = [pos[off[q] + len(oks[q]):off[q + 1]] for q in range(len(g))]
         return map_from_positions(pl, jl, [len(o) for o in oks], kappas)
 
-    return _evaluate(dataset, gnd, [1, 5, 10], one_map)
+    result = _evaluate(dataset, gnd, [1, 5, 10], one_map)
+    if lap:
+        lap("compute_score")
+    return result

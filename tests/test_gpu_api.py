@@ -310,6 +310,35 @@ def test_infer_and_whitening_learning_on_gpu(tmp_path):
     np.testing.assert_allclose(dfw @ dfw.T / npairs, np.eye(D), atol=5e-3)
 
 
+def test_eval_py_two_processes_print_the_same_numbers(tmp_path):
+    """`torchrun --nproc-per-node 2 eval.py ...` (both ranks on this one GPU, collectives through
+    gloo): sharded extraction + sort-free distributed mAP print what the single process prints."""
+    import socket
+    root = str(tmp_path / "synth")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_eval.py"), root])
+    env = dict(os.environ, CIRTORCH_ROOT=root, MDIR_AMD_WORKERS="0")
+    args = [os.path.join(ROOT, "eval.py"), "eval.yml", os.path.join(root, "eval_synth.yml")]
+
+    def printed(cmd, extra):
+        proc = subprocess.run(cmd, env=dict(env, **extra), text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert proc.returncode == 0, proc.stdout[-3000:]
+        out = {}
+        for line in proc.stdout.splitlines():
+            for label in ("roxford.5k medium", "247tokyo.1k"):
+                if line.strip().startswith(label):
+                    out[label] = float(line.split()[-1])
+        assert set(out) == {"roxford.5k medium", "247tokyo.1k"}, proc.stdout[-3000:]
+        return out
+
+    single = printed([sys.executable] + args, {})
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    double = printed([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                      "--master-addr", "127.0.0.1", "--master-port", str(port)] + args, {"MDIR_AMD_DRYRUN_ONE_GPU": "1"})
+    assert single == double, (single, double)
+
+
 def test_cirtorch_test_cli_end_to_end(tmp_path):
     """`python -m mdir_amd.examples.test` (the upstream cirtorch CLI, second caller of the API):
     multi-scale descriptors, learned whitening (whitenlearn on the fly), both mAP lines equal an

@@ -148,22 +148,22 @@ def _map_worker(rank, world, port, root, out_dir):
     import fake_ops
     fake_ops.install_globally()
     import pickle
-    from mdir_amd.datasets import configdataset, initialize_transforms
     from mdir_amd.networks import init_network
-    from mdir_amd.sharded import sharded_retrieval_map
+    from mdir_amd.score import initialize_score
     torch.manual_seed(0)
     net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False}).eval()
     net.meta["out_channels"] = 256
-    tr = initialize_transforms("pil2np | totensor | normalize", [net.meta["mean"], net.meta["std"]])
     res = {}
     for ds in ("roxford5k", "247tokyo1k"):
-        cfg = configdataset(ds, os.path.join(root, "data", "test"))
-        images = [cfg["im_fname"](cfg, i) for i in range(cfg["n"])]
-        qimages = [cfg["qim_fname"](cfg, i) for i in range(cfg["nq"])]
-        bbxs = [tuple(g["bbx"]) if g.get("bbx") else None for g in cfg["gnd"]]
-        with torch.no_grad():
-            avg, per = sharded_retrieval_map(net, images, qimages, bbxs, cfg["gnd"], ds, 224, tr, "cpu")
-        res[ds] = (avg, {k: np.asarray(v) for k, v in per.items()})
+        score = initialize_score({"type": "cirdatasetap", "image_size": 224, "dataset": ds,
+                                  "transforms": "pil2np | totensor | normalize",
+                                  "mean_std": [net.meta["mean"], net.meta["std"]]})
+        rows = []
+        with torch.no_grad():       # the score object takes the sharded route by itself (world size 2)
+            score(net, "cpu", lambda it, size, label, value, dtype: rows.append((label, value)))
+        assert rows[0][0] == "dataset" and set(rows[0][1]) == {"extract_descriptors", "compute_score", "total_s"}
+        per = {k: np.array([r[1][k] for r in rows[2:]]) for k in rows[2][1]}
+        res[ds] = (rows[1][1], per)
     with open(os.path.join(out_dir, "map%d.pkl" % rank), "wb") as f:
         pickle.dump(res, f)
     dist.destroy_process_group()
@@ -198,9 +198,12 @@ def test_sharded_extraction_and_map_equal_single_process(tmp_path, monkeypatch):
         with torch.no_grad():
             score(net, "cpu", lambda it, size, label, value, dtype: rows.append((label, value)))
         want_avg = rows[1][1]
+        want_per = {k: np.array([r[1][k] for r in rows[2:]]) for k in rows[2][1]}
         for r in range(2):
             avg, per = got[r][ds]
             assert avg.keys() == want_avg.keys()
             for k in avg:
                 np.testing.assert_allclose(avg[k], want_avg[k], rtol=0, atol=1e-12)
+            for k in want_per:
+                np.testing.assert_allclose(per[k], want_per[k], rtol=0, atol=1e-12, equal_nan=True)
         assert got[0][ds][0] == got[1][ds][0]
