@@ -196,8 +196,10 @@ def main():
     # ---- results check + mAP (untimed) --------------------------------------
     extra = {}
     if world == 1:
-        avg_s, _ = compute_map_and_print_from_scores("roxford5k", sc, gnd)           # counting kernel, no sort
-        avg_r, _ = compute_map_and_print("roxford5k", rk.t(), gnd)                   # from the full ranking
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # stdout carries the one JSON line only
+            avg_s, _ = compute_map_and_print_from_scores("roxford5k", sc, gnd)       # counting kernel, no sort
+            avg_r, _ = compute_map_and_print("roxford5k", rk.t(), gnd)               # from the full ranking
         assert avg_s == avg_r, (avg_s, avg_r)
         assert bool((rk[:, 0].cpu() == torch.from_numpy(qid)).all()), "every query must retrieve its source row first"
         extra["map_medium"] = avg_r["map_medium"]
