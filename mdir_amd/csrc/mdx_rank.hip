@@ -195,20 +195,23 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         gdelta[tid] = gbase;
         dtot[tid] = qtot;
     }
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const bool valid = (sub0 + r * 64 + lane) < n;
         const uint32_t d = (key[r] >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
+        // match-any on the 8 digit bits, as two 32-bit halves: per bit one sign-extract (0 / ~0),
+        // one compare (the ballot) and xnor + and per half
+        const uint64_t vmask = __ballot(valid);
+        uint32_t plo = (uint32_t)vmask, phi = (uint32_t)(vmask >> 32);
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
-            const bool one = (d >> bit) & 1u;
-            const uint64_t m = __ballot(valid && one);
-            peers &= one ? m : ~m;
+            const int32_t sel = (int32_t)(d << (31 - bit)) >> 31;       // ~0 where the bit is set
+            const uint64_t m = __ballot(valid && sel != 0);
+            plo &= ~((uint32_t)m ^ (uint32_t)sel);
+            phi &= ~((uint32_t)(m >> 32) ^ (uint32_t)sel);
         }
-        const uint32_t rank = __popcll(peers & lt_mask);
-        const uint32_t cnt = __popcll(peers);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t cnt = __popc(plo) + __popc(phi);
         const uint32_t old = wcnt[wave][d];
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) wcnt[wave][d] = old + cnt;
@@ -582,10 +585,10 @@ __global__ __launch_bounds__(SORT_THREADS) void select_scatter_kernel(const floa
     const int64_t q = blockIdx.y, b = blockIdx.x;
     const SelState s = st[q];
     const int64_t sub0 = b * SORT_TILE + wave * SUB_TILE;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     float v[SORT_ITEMS];
     uint32_t pl[SORT_ITEMS], pe[SORT_ITEMS];        // position inside the wave's less / equal sequence (or ~0)
     uint32_t nl = 0, ne = 0;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int64_t i = sub0 + r * 64 + lane;
