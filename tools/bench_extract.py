@@ -29,11 +29,15 @@ def main():
     ap.add_argument("--images", type=int, default=30)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find mode)")
-    args = ap.parse_args()
+    print(json.dumps(measure(ap.parse_args())))
+
+
+def measure(args):
+    """``args``: namespace with arch / images / channels_last / miopen_find (also called by bench.py)."""
     from mdir_amd import ops
     from mdir_amd.networks import init_network
     from mdir_amd.wrapper import initialize_wrappers
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", torch.cuda.current_device())
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     torch.manual_seed(3)
     net = init_network({"architecture": args.arch, "pooling": "gem", "whitening": False, "pretrained": False})
@@ -106,12 +110,13 @@ def main():
         a, b = tail_mdx().reshape(-1), tail_torch().reshape(-1)
         err = float((a - b).abs().max())
         t_tail, t_tail_torch = timeit(tail_mdx), timeit(tail_torch)
-    print(json.dumps({"metric": "descriptors/sec, %s-GeM, 3 scales of 1024x768 + whitening, 1 GPU" % args.arch,
-                      "value": round(args.images / total, 2), "unit": "descriptors/s",
-                      "ms_per_image": round(1e3 * total / args.images, 3),
-                      "backbone_ms_per_image": round(t_backbone, 3),
-                      "tail_ms_per_image_mdx": round(t_tail, 4), "tail_ms_per_image_torch_ops": round(t_tail_torch, 4),
-                      "tail_max_abs_diff_vs_torch_ops": err, "dtype": "f32", "data": "synthetic"}))
+    return {"metric": "descriptors/sec, %s-GeM, 3 scales of 1024x768 + whitening, 1 GPU" % args.arch,
+            "value": round(args.images / total, 2), "unit": "descriptors/s",
+            "ms_per_image": round(1e3 * total / args.images, 3),
+            "backbone_ms_per_image": round(t_backbone, 3),
+            "tail_ms_per_image_mdx": round(t_tail, 4), "tail_ms_per_image_torch_ops": round(t_tail_torch, 4),
+            "tail_max_abs_diff_vs_torch_ops": err, "dtype": "f32", "data": "synthetic"}
 
 
-main()
+if __name__ == "__main__":
+    main()
