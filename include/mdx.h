@@ -75,6 +75,15 @@ int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float 
  * (imageretrievalnet.py:111-112). */
 int mdx_l2n_rows(float *x, int64_t R, int64_t D, const float *bias, float eps, void *stream);
 
+/* Trunk epilogue, in place on a convolution output x[N,C,H*W] (NCHW, contiguous):
+ *   x = act( (x - mean[c]) * weight[c] / sqrt(var[c] + eps) + bias[c]  (+ residual) ),  act = ReLU or identity
+ * i.e. inference `bn(x)`, `out += identity`, `relu(out)` of a residual block (mdir_amd/backbones.py; the
+ * torchvision Bottleneck/BasicBlock forward kept by cirtorch/networks/imageretrievalnet.py:172-173) as one
+ * pass.  weight / bias / residual may be NULL; mean and var may both be NULL (no normalisation: with only
+ * `bias` given this is the `conv bias + ReLU` of a VGG / AlexNet layer).  mean, var, weight, bias: C floats. */
+int mdx_bn_act(float *x, const float *residual, int64_t N, int64_t C, int64_t HW, const float *mean,
+               const float *var, const float *weight, const float *bias, float eps, int relu, void *stream);
+
 /* Multi-scale aggregation of S per-scale descriptors of one image:
  *   out[k] = v[k] / ||v||,  v[k] = (sum_s vecs[s][k]^msp / S)^(1/msp)     (no eps)
  * Replaces CirMultiscaleAggregation.aggregate_tensor

@@ -7,11 +7,40 @@ reference ``state_dict`` (``features.0.weight``, ``features.4.0.conv1.weight`` .
 loads unchanged.  The convolutions themselves stay on PyTorch-ROCm / MIOpen: the
 backbone is not part of the hand-written hot path (BASELINE.json north_star).
 """
+import os
+
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 
 def _conv3x3(cin, cout, stride=1):
     return nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+
+
+def _bn_act(x, bn, residual=None, relu=True):
+    """``relu(bn(x) + residual)`` on a fresh convolution output.  At inference on the GPU the three
+    full-tensor passes are one in-place kernel (``mdx_bn_act``: a third of the trunk's GPU time and
+    400 of its 1100 launches on ResNet101); training / CPU tensors / autograd keep the module calls."""
+    if (x.is_cuda and not bn.training and not torch.is_grad_enabled() and bn.track_running_stats
+            and x.dtype == torch.float32 and _fused_trunk()):
+        from . import ops
+        res = residual.contiguous() if residual is not None else None
+        return ops.bn_act_(x.contiguous(), bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, res, relu)
+    out = bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out, inplace=True) if relu else out
+
+
+def _fused_trunk():
+    return os.environ.get("MDIR_AMD_FUSED_TRUNK", "1") != "0"
+
+
+def _downsample(mod, x):
+    if isinstance(mod, nn.Sequential) and len(mod) == 2 and isinstance(mod[1], nn.BatchNorm2d):
+        return _bn_act(mod[0](x), mod[1], None, relu=False)
+    return mod(x)
 
 
 class BasicBlock(nn.Module):
@@ -27,10 +56,9 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + idt)
+        idt = x if self.downsample is None else _downsample(self.downsample, x)
+        out = _bn_act(self.conv1(x), self.bn1)
+        return _bn_act(self.conv2(out), self.bn2, idt)
 
 
 class Bottleneck(nn.Module):
@@ -48,11 +76,42 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        idt = x if self.downsample is None else _downsample(self.downsample, x)
+        out = _bn_act(self.conv1(x), self.bn1)
+        out = _bn_act(self.conv2(out), self.bn2)
+        return _bn_act(self.conv3(out), self.bn3, idt)
+
+
+class TrunkSequential(nn.Sequential):
+    """``nn.Sequential`` (same child names, same state dict) whose inference pass on the GPU folds
+    the elementwise modules that follow a convolution into one in-place kernel:
+    ``Conv2d(bias=False) -> BatchNorm2d [-> ReLU]`` (ResNet stem) and ``Conv2d(bias) -> ReLU``
+    (every VGG / AlexNet layer: the bias add and the ReLU are two full-tensor passes otherwise)."""
+
+    def forward(self, x):
+        if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and _fused_trunk()):
+            return super().forward(x)
+        from . import ops
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, nn.Conv2d) and m.padding_mode == "zeros" and not isinstance(m.padding, str):
+                if (m.bias is None and isinstance(nxt, nn.BatchNorm2d) and not nxt.training and nxt.track_running_stats):
+                    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                    x = ops.bn_act_(m(x).contiguous(), nxt.running_mean, nxt.running_var, nxt.weight, nxt.bias, nxt.eps,
+                                    None, relu)
+                    i += 3 if relu else 2
+                    continue
+                if m.bias is not None and isinstance(nxt, nn.ReLU):
+                    y = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+                    x = ops.bn_act_(y.contiguous(), None, None, None, m.bias, 0.0, None, True)
+                    i += 2
+                    continue
+            x = m(x)
+            i += 1
+        return x
 
 
 _RESNET = {"resnet18": (BasicBlock, (2, 2, 2, 2)), "resnet34": (BasicBlock, (3, 4, 6, 3)),

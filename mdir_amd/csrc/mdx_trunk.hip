@@ -1,0 +1,86 @@
+// Trunk epilogue: inference batch-norm + residual add + ReLU of a convolution output in ONE
+// in-place pass.
+//
+// The convolutions of the backbone stay on MIOpen (BASELINE.json north_star), but between them
+// torchvision-style residual blocks (mirrored in mdir_amd/backbones.py; torchvision resnet.py
+// Bottleneck.forward as kept by cirtorch/networks/imageretrievalnet.py:172-173) run three separate
+// full-tensor kernels: batch_norm (read+write), `out += identity` (2 reads + write), relu
+// (read+write).  On ResNet101 at 1024x768 that is 711 launches and a third of the trunk's GPU time,
+// and the trunk is launch-bound on top.  HBM-bound: one read (+ one for the residual) and one write
+// per element.
+#include "mdx_common.h"
+
+namespace mdx {
+
+struct BnArgs {
+    const float *mean, *var, *weight, *bias;
+    float eps;
+};
+
+__device__ __forceinline__ void bn_coeffs(const BnArgs &a, int c, float &mean, float &scale, float &shift)
+{
+    mean = a.mean ? a.mean[c] : 0.0f;
+    const float invstd = a.var ? 1.0f / sqrtf(a.var[c] + a.eps) : 1.0f;
+    scale = a.weight ? invstd * a.weight[c] : invstd;
+    shift = a.bias ? a.bias[c] : 0.0f;
+}
+
+// VEC = 4: planes are a multiple of 4 long and 16-B aligned, so a float4 never straddles channels
+template <int VEC, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_act_kernel(float *__restrict__ x, const float *__restrict__ res,
+                                                     int64_t total_vec, unsigned hw_vec, unsigned C, BnArgs a)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const unsigned c = (unsigned)((uint64_t)i / hw_vec) % C;
+        float mean, scale, shift;
+        bn_coeffs(a, (int)c, mean, scale, shift);
+        if (VEC == 4) {
+            float4 v = ((const float4 *)x)[i];
+            float4 r = RES ? ((const float4 *)res)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x = fmaf(v.x - mean, scale, shift) + r.x;
+            v.y = fmaf(v.y - mean, scale, shift) + r.y;
+            v.z = fmaf(v.z - mean, scale, shift) + r.z;
+            v.w = fmaf(v.w - mean, scale, shift) + r.w;
+            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            ((float4 *)x)[i] = v;
+        } else {
+            float v = fmaf(x[i] - mean, scale, shift) + (RES ? res[i] : 0.0f);
+            x[i] = RELU ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+template <int VEC>
+static void launch_bn_act(float *x, const float *res, int64_t total_vec, unsigned hw_vec, unsigned C, const BnArgs &a,
+                          bool relu, hipStream_t s)
+{
+    const int64_t want = ceil_div(total_vec, (int64_t)256);
+    const unsigned grid = (unsigned)(want < 256 * 16 ? (want > 0 ? want : 1) : 256 * 16);
+    if (res && relu) hipLaunchKernelGGL((bn_act_kernel<VEC, true, true>), dim3(grid), dim3(256), 0, s, x, res, total_vec, hw_vec, C, a);
+    else if (res)    hipLaunchKernelGGL((bn_act_kernel<VEC, true, false>), dim3(grid), dim3(256), 0, s, x, res, total_vec, hw_vec, C, a);
+    else if (relu)   hipLaunchKernelGGL((bn_act_kernel<VEC, false, true>), dim3(grid), dim3(256), 0, s, x, res, total_vec, hw_vec, C, a);
+    else             hipLaunchKernelGGL((bn_act_kernel<VEC, false, false>), dim3(grid), dim3(256), 0, s, x, res, total_vec, hw_vec, C, a);
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+extern "C" int mdx_bn_act(float *x, const float *residual, int64_t N, int64_t C, int64_t HW, const float *mean,
+                          const float *var, const float *weight, const float *bias, float eps, int relu,
+                          void *stream)
+{
+    MDX_CHECK_ARG(x, "mdx_bn_act: NULL x");
+    MDX_CHECK_ARG((mean == nullptr) == (var == nullptr), "mdx_bn_act: mean and var must both be given or both be NULL");
+    MDX_CHECK_ARG(N > 0 && C > 0 && HW > 0, "mdx_bn_act: N=%lld C=%lld HW=%lld must be positive", (long long)N,
+                  (long long)C, (long long)HW);
+    MDX_CHECK_ARG(C < (1ll << 31) && HW < (1ll << 31), "mdx_bn_act: C or HW too large");
+    MDX_CHECK_ARG(eps >= 0.0f, "mdx_bn_act: eps=%g must be >= 0", (double)eps);
+    const BnArgs a{mean, var, weight, bias, eps};
+    const int64_t total = N * C * HW;
+    const bool vec = (HW % 4 == 0) && (((uintptr_t)x & 15) == 0) && (!residual || ((uintptr_t)residual & 15) == 0);
+    if (vec) launch_bn_act<4>(x, residual, total / 4, (unsigned)(HW / 4), (unsigned)C, a, relu != 0, (hipStream_t)stream);
+    else     launch_bn_act<1>(x, residual, total, (unsigned)HW, (unsigned)C, a, relu != 0, (hipStream_t)stream);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}

@@ -22,15 +22,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .backbones import OUTPUT_DIM, build_features
+from .backbones import OUTPUT_DIM, TrunkSequential, build_features
 from .datasets import ImagesFromList, get_data_root
+from .graphs import ShapeGraphs, graphs_enabled
 from .layers import POOLING, L2N, pool_kind
 
 
 class ImageRetrievalNet(nn.Module):
     def __init__(self, features, lwhiten, pool, whiten, meta):
         super().__init__()
-        self.features = nn.Sequential(*features)
+        self.features = TrunkSequential(*features)
         self.lwhiten = lwhiten
         self.pool = pool
         self.whiten = whiten
@@ -172,11 +173,14 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     loader = torch.utils.data.DataLoader(
         ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),
         batch_size=1, shuffle=False, num_workers=num_workers, pin_memory=True)
+    describe = (lambda x: extract_ss(net, x)) if len(ms) == 1 else (lambda x: extract_ms(net, x, ms, msp))
+    if graphs_enabled(device):
+        describe = ShapeGraphs(describe)      # per input shape: eager twice, then one hipGraph replay per image
     with torch.no_grad():
         vecs = None
         for i, input in enumerate(loader):
             input = input.to(device, non_blocking=True)
-            v = extract_ss(net, input) if len(ms) == 1 else extract_ms(net, input, ms, msp)
+            v = describe(input)
             if vecs is None:
                 # width from the first descriptor: a dimension-reducing whitening wrapper
                 # (cirwhiten dimensions=d) yields d < meta['out_channels'], which the

@@ -14,7 +14,13 @@ from ._lib import MDX_DIM_MAJOR, MDX_ROW_MAJOR, POOL_KINDS, check
 _vp = ctypes.c_void_p
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Handle of torch's current HIP stream (launches are enqueued there; nothing synchronises)."""
+    if _raw_stream is not None:           # a few hundred ns instead of building a torch.cuda.Stream object
+        return _vp(_raw_stream(torch.cuda.current_device()))
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
@@ -89,6 +95,36 @@ def ms_aggregate(vecs, msp=1.0):
     check(_lib.lib().mdx_ms_aggregate(ptrs, len(flat), D, float(msp), _vp(out.data_ptr()), _stream()),
           "mdx_ms_aggregate")
     return out
+
+
+def bn_act_(x, running_mean, running_var, weight=None, bias=None, eps=1e-5, residual=None, relu=True):
+    """In place on a convolution output ``x [N,C,H,W]``: inference batch-norm, ``+ residual``, ReLU
+    in one pass (``mdx_bn_act``); returns ``x``.  Called ~100 times per image by a launch-bound trunk,
+    so the checks are kept to what protects the raw pointers."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise ValueError("bn_act_ expects a contiguous fp32 [N,C,H,W] CUDA/ROCm tensor (no CPU fallback)")
+    n, c, h, w = x.shape
+    ptrs = []
+    for name, t in (("running_mean", running_mean), ("running_var", running_var), ("weight", weight), ("bias", bias)):
+        if t is None:
+            ptrs.append(None)
+            continue
+        if t.numel() != c or t.dtype != torch.float32 or t.device != x.device or not t.is_contiguous():
+            raise ValueError("%s must be %d contiguous fp32 values on %s" % (name, c, x.device))
+        ptrs.append(t.data_ptr())
+    if (ptrs[0] is None) != (ptrs[1] is None):
+        raise ValueError("running_mean and running_var must both be given or both be None")
+    rp = None
+    if residual is not None:
+        if residual.shape != x.shape or residual.dtype != torch.float32 or residual.device != x.device \
+                or not residual.is_contiguous():
+            raise ValueError("residual must be contiguous fp32 and shaped like x")
+        rp = residual.data_ptr()
+    if x.numel() == 0:
+        return x
+    check(_lib.lib().mdx_bn_act(x.data_ptr(), rp, n, c, h * w, ptrs[0], ptrs[1], ptrs[2], ptrs[3], float(eps),
+                                1 if relu else 0, _stream()), "mdx_bn_act")
+    return x
 
 
 # ----------------------------------------------------------------------- index

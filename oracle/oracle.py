@@ -88,6 +88,23 @@ def forward_tail(feat, p=3.0, eps=1e-6, whiten_w=None, whiten_b=None, pooling="g
 MS_SCALES = (1.0, 1.0 / np.sqrt(2.0), 0.5)  # mdir/components/data/wrapper.py:93
 
 
+def bn_act(x, mean, var, weight=None, bias=None, eps=1e-5, residual=None, relu=True):
+    """Inference batch-norm + residual add + ReLU of a residual block on ``x [N,C,H,W]``:
+    ``relu(bn(x) + identity)`` -- torch.nn.BatchNorm2d in eval mode,
+    ``(x - running_mean) / sqrt(running_var + eps) * weight + bias``, as used by the torchvision
+    ResNet blocks the reference keeps as ``features`` (cirtorch/networks/imageretrievalnet.py:172-173).
+    float64 inside, so it is a reference for fp32 implementations in either operation order."""
+    shape = (1, -1, 1, 1)
+    y = (x.astype(np.float64) - mean.astype(np.float64).reshape(shape)) / np.sqrt(var.astype(np.float64).reshape(shape) + eps)
+    if weight is not None:
+        y = y * weight.astype(np.float64).reshape(shape)
+    if bias is not None:
+        y = y + bias.astype(np.float64).reshape(shape)
+    if residual is not None:
+        y = y + residual.astype(np.float64)
+    return (np.maximum(y, 0.0) if relu else y).astype(F32)
+
+
 def ms_aggregate(vecs, msp=1.0):
     """Aggregate ``S`` per-scale descriptors ``[S,D] -> [D]``.
 

@@ -310,6 +310,42 @@ def test_infer_and_whitening_learning_on_gpu(tmp_path):
     np.testing.assert_allclose(dfw @ dfw.T / npairs, np.eye(D), atol=5e-3)
 
 
+def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
+    """extract_vectors_device replays one hipGraph per input shape from the third image of that shape
+    on; descriptors equal the eager run of the same images (two shapes, multi-scale + whitening chain
+    and plain cirtorch multi-scale)."""
+    from PIL import Image
+    from mdir_amd import networks
+    from mdir_amd.datasets import initialize_transforms
+    from mdir_amd.graphs import ShapeGraphs
+    from mdir_amd.networks import extract_vectors_device, init_network
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(9):
+        size = (160, 120) if i % 3 else (120, 160)
+        p = str(tmp_path / ("im%d.png" % i))
+        Image.fromarray(rng.integers(0, 255, (size[1], size[0], 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    torch.manual_seed(1)
+    net = init_network({"architecture": "resnet18", "pooling": "gem", "whitening": False, "pretrained": False}).to(DEV).eval()
+    tr = initialize_transforms("pil2np | totensor | normalize", [net.meta["mean"], net.meta["std"]])
+    ms = [1, 2 ** -0.5, 0.5]
+    made = []
+    orig = ShapeGraphs.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(self)
+    monkeypatch.setattr(ShapeGraphs, "__init__", spy)
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    graphed = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
+    assert len(made) == 1 and made[0].replays == 9 - 2 * 2 and len(made[0].graphs) == 2 and not made[0].refused
+    monkeypatch.setenv("MDIR_AMD_GRAPHS", "0")
+    eager = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
+    assert len(made) == 1
+    np.testing.assert_allclose(graphed.cpu().numpy(), eager.cpu().numpy(), rtol=0, atol=1e-6)
+
+
 def test_eval_py_two_processes_print_the_same_numbers(tmp_path):
     """`torchrun --nproc-per-node 2 eval.py ...` (both ranks on this one GPU, collectives through
     gloo): sharded extraction + sort-free distributed mAP print what the single process prints."""

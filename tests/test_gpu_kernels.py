@@ -137,6 +137,72 @@ def test_pool_batch_and_zero_map(ops):
     assert not np.isnan(got).any()
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 48, 64), (2, 256, 17, 23), (1, 2048, 23, 17), (3, 5, 1, 1), (1, 7, 3, 5)])
+def test_bn_act_vs_oracle_and_torch(ops, shape):
+    """Fused trunk epilogue: every combination of residual / relu / affine, aligned and odd planes,
+    against the float64 oracle and against torch's own batch_norm + add + relu on the same device."""
+    rng = np.random.default_rng(11)
+    n, c, h, w = shape
+    x = rng.standard_normal(shape).astype(np.float32) * 2
+    res = rng.standard_normal(shape).astype(np.float32)
+    mean, var = rng.standard_normal(c).astype(np.float32), rng.uniform(0.2, 3.0, c).astype(np.float32)
+    wt, bs = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    for use_res in (False, True):
+        for relu in (False, True):
+            for affine in (True, False):
+                got = ops.bn_act_(dev(x.copy()), dev(mean), dev(var), dev(wt) if affine else None, dev(bs) if affine else None,
+                                  1e-5, dev(res) if use_res else None, relu)
+                want = O.bn_act(x, mean, var, wt if affine else None, bs if affine else None, 1e-5, res if use_res else None, relu)
+                np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+                t = torch.nn.functional.batch_norm(dev(x), dev(mean), dev(var), dev(wt) if affine else None,
+                                                   dev(bs) if affine else None, False, 0.0, 1e-5)
+                if use_res:
+                    t = t + dev(res)
+                if relu:
+                    t = torch.relu(t)
+                np.testing.assert_allclose(got.cpu().numpy(), t.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    with pytest.raises(ValueError):
+        ops.bn_act_(dev(x), dev(mean[:-1]) if c > 1 else dev(np.zeros(2, np.float32)), dev(var))
+
+
+def test_fused_trunk_equals_module_calls(ops, monkeypatch):
+    """ResNet blocks with the fused epilogue == the same blocks through torch's bn / add / relu kernels."""
+    from mdir_amd.backbones import build_features
+    torch.manual_seed(5)
+    from mdir_amd.backbones import TrunkSequential
+    feats = TrunkSequential(*build_features("resnet50")).eval()
+    for m in feats.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):       # non-trivial running statistics
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.2); m.bias.data.normal_(0, 0.1)
+    feats = feats.to(DEV)
+    x = torch.randn(1, 3, 203, 157, device=DEV)
+    with torch.no_grad():
+        fused = feats(x)
+        monkeypatch.setenv("MDIR_AMD_FUSED_TRUNK", "0")
+        plain = feats(x)
+    assert fused.shape == plain.shape
+    scale = float(plain.abs().max())
+    assert float((fused - plain).abs().max()) <= 2e-5 * scale, (float((fused - plain).abs().max()), scale)
+    # autograd keeps the module path (no in-place HIP kernel under grad)
+    monkeypatch.delenv("MDIR_AMD_FUSED_TRUNK")
+    y = feats(x.requires_grad_(True))
+    y.mean().backward()
+    assert x.grad is not None
+    # VGG / AlexNet layers: conv bias + ReLU folded
+    vgg = TrunkSequential(*build_features("vgg16")).eval().to(DEV)
+    x = torch.randn(2, 3, 97, 131, device=DEV)
+    with torch.no_grad():
+        fused = vgg(x)
+        monkeypatch.setenv("MDIR_AMD_FUSED_TRUNK", "0")
+        plain = vgg(x)
+    assert float((fused - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
+    # bias-only form of the kernel is exactly x + b
+    b = torch.randn(7, device=DEV)
+    t = torch.randn(1, 7, 5, 3, device=DEV)
+    np.testing.assert_array_equal(ops.bn_act_(t.clone(), None, None, None, b, 0.0, None, False).cpu().numpy(),
+                                  (t + b.view(1, -1, 1, 1)).cpu().numpy())
+
+
 def test_l2n_rows_golden(ops, golden):
     g = golden("g2_l2n.npz")
     got = ops.l2n_rows_(dev(g["x"].copy())).cpu().numpy()
