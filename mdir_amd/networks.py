@@ -160,6 +160,26 @@ def extract_ms(net, input, ms, msp):
     return ops.ms_aggregate(per_scale, msp)
 
 
+def _same_shape_order(images, bbxs):
+    """Indices of ``images`` ordered so that images of equal raw size (hence equal network input
+    shape) are consecutive: every hipGraph is then captured once and replayed for its whole group
+    instead of being evicted and re-captured.  Sizes come from the file headers (no decode); an
+    unreadable header keeps its place in a group of its own (the loader reports the error)."""
+    from PIL import Image
+    keys = []
+    for i, path in enumerate(images):
+        box = bbxs[i] if bbxs else None
+        if box:
+            keys.append((int(box[2] - box[0]), int(box[3] - box[1])))
+            continue
+        try:
+            with Image.open(path) as handle:
+                keys.append(tuple(handle.size))
+        except Exception:
+            keys.append((-1, i))
+    return sorted(range(len(images)), key=lambda i: (keys[i], i))
+
+
 def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1], msp=1, print_freq=10,
                            device=None, num_workers=None):
     """Like :func:`extract_vectors` but the result stays on the GPU as ``[N,D]``
@@ -170,15 +190,17 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     net.eval()
     if num_workers is None:
         num_workers = int(os.environ.get("MDIR_AMD_WORKERS", "6"))
-    loader = torch.utils.data.DataLoader(
-        ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),
-        batch_size=1, shuffle=False, num_workers=num_workers, pin_memory=True)
     describe = (lambda x: extract_ss(net, x)) if len(ms) == 1 else (lambda x: extract_ms(net, x, ms, msp))
+    order = list(range(len(images)))
     if graphs_enabled(device):
         describe = ShapeGraphs(describe)      # per input shape: eager twice, then one hipGraph replay per image
+        order = _same_shape_order(images, bbxs)
+    loader = torch.utils.data.DataLoader(
+        ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),
+        batch_size=1, shuffle=False, sampler=order, num_workers=num_workers, pin_memory=True)
     with torch.no_grad():
         vecs = None
-        for i, input in enumerate(loader):
+        for done, (i, input) in enumerate(zip(order, loader)):
             input = input.to(device, non_blocking=True)
             v = describe(input)
             if vecs is None:
@@ -186,9 +208,9 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
                 # (cirwhiten dimensions=d) yields d < meta['out_channels'], which the
                 # reference's fixed-size buffer (imageretrievalnet.py:291) cannot hold
                 vecs = torch.empty(len(images), v.numel(), dtype=torch.float32, device=device)
-            vecs[i].copy_(v.reshape(-1), non_blocking=True)
-            if (i + 1) % print_freq == 0 or (i + 1) == len(images):
-                print("\r>>>> {}/{} done...".format(i + 1, len(images)), end="")
+            vecs[i].copy_(v.reshape(-1), non_blocking=True)      # row = position in the caller's list
+            if (done + 1) % print_freq == 0 or (done + 1) == len(images):
+                print("\r>>>> {}/{} done...".format(done + 1, len(images)), end="")
         print("")
     return vecs
 

@@ -338,6 +338,8 @@ def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
         made.append(self)
     monkeypatch.setattr(ShapeGraphs, "__init__", spy)
     monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    from mdir_amd.networks import _same_shape_order
+    assert _same_shape_order(paths, None) == [0, 3, 6, 1, 2, 4, 5, 7, 8]       # equal sizes made consecutive
     graphed = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
     assert len(made) == 1 and made[0].replays == 9 - 2 * 2 and len(made[0].graphs) == 2 and not made[0].refused
     monkeypatch.setenv("MDIR_AMD_GRAPHS", "0")
