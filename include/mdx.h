@@ -84,6 +84,13 @@ int mdx_l2n_rows(float *x, int64_t R, int64_t D, const float *bias, float eps, v
 int mdx_bn_act(float *x, const float *residual, int64_t N, int64_t C, int64_t HW, const float *mean,
                const float *var, const float *weight, const float *bias, float eps, int relu, void *stream);
 
+/* Input conversion: uint8 images [B,H,W,C] (C = 1 or 3, interleaved) -> fp32 [B,C,H,W] with
+ *   out = (u / 255 - mean[c]) / std[c]            (fp32, IEEE divisions, this operation order)
+ * = the `pil2np | totensor | normalize` transform chain of the scenarios (mdir/components/data/transform/
+ * core_transforms.py:33-63) moved behind the host-to-device copy.  mean, std: HOST arrays of C floats. */
+int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W, int C, const float *mean,
+                  const float *std, float *out, void *stream);
+
 /* Multi-scale aggregation of S per-scale descriptors of one image:
  *   out[k] = v[k] / ||v||,  v[k] = (sum_s vecs[s][k]^msp / S)^(1/msp)     (no eps)
  * Replaces CirMultiscaleAggregation.aggregate_tensor

@@ -84,3 +84,50 @@ extern "C" int mdx_bn_act(float *x, const float *residual, int64_t N, int64_t C,
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Input conversion on the device: uint8 HWC image -> normalised fp32 CHW tensor, i.e. the
+// `pil2np | totensor | normalize` chain of the eval scenarios (mdir/components/data/transform/
+// core_transforms.py:33-63; cirtorch's ToTensor + Normalize) with its exact fp32 operation order
+// ((u / 255 - mean) / std, IEEE divisions), so the loader workers ship 1 byte per value instead of 4.
+// ---------------------------------------------------------------------------
+namespace mdx {
+
+struct NormArgs { float mean[4], std[4]; };
+
+template <int C>
+__global__ __launch_bounds__(256) void u8_to_chw_kernel(const uint8_t *__restrict__ src, float *__restrict__ dst,
+                                                        int64_t pixels_per_image, int64_t total_pixels, NormArgs a)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_pixels; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / pixels_per_image, p = i - b * pixels_per_image;
+        const uint8_t *s = src + i * C;
+        float *d = dst + b * C * pixels_per_image + p;
+#pragma unroll
+        for (int c = 0; c < C; ++c) d[c * pixels_per_image] = ((float)s[c] / 255.0f - a.mean[c]) / a.std[c];
+    }
+}
+
+}  // namespace mdx
+
+extern "C" int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W, int C, const float *mean,
+                             const float *std, float *out, void *stream)
+{
+    MDX_CHECK_ARG(hwc && out && mean && std, "mdx_u8_to_chw: NULL pointer");
+    MDX_CHECK_ARG(B > 0 && H > 0 && W > 0, "mdx_u8_to_chw: B=%lld H=%lld W=%lld must be positive", (long long)B,
+                  (long long)H, (long long)W);
+    MDX_CHECK_ARG(C == 1 || C == 3, "mdx_u8_to_chw: C=%d (1 or 3 channels)", C);
+    NormArgs a{};
+    for (int c = 0; c < C; ++c) {
+        MDX_CHECK_ARG(std[c] != 0.0f, "mdx_u8_to_chw: std[%d] is zero", c);
+        a.mean[c] = mean[c];
+        a.std[c] = std[c];
+    }
+    const int64_t px = H * W, total = B * px;
+    const int64_t want = ceil_div(total, (int64_t)256);
+    const unsigned grid = (unsigned)(want < 256 * 16 ? want : 256 * 16);
+    if (C == 3) hipLaunchKernelGGL((u8_to_chw_kernel<3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, hwc, out, px, total, a);
+    else        hipLaunchKernelGGL((u8_to_chw_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, hwc, out, px, total, a);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}

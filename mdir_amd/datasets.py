@@ -158,6 +158,26 @@ class Compose:
             pics = t(*pics)
         return pics[0] if len(pics) == 1 else pics
 
+    def device_tail(self):
+        """``(mean, std)`` when the whole chain is the PIL -> normalised CHW tensor conversion
+        (``pil2np | totensor | normalize`` of the scenarios, or cirtorch's ``ToTensor, Normalize``):
+        extraction then ships uint8 pixels and does this arithmetic on the GPU (``mdx_u8_to_chw``,
+        same fp32 operation order).  ``None`` for any other chain."""
+        t = list(self.transforms)
+        if len(t) == 3 and isinstance(t[0], Pil2Numpy):
+            t = t[1:]
+        if len(t) == 2 and isinstance(t[0], ToTensor) and isinstance(t[1], Normalize) and len(t[1].mean) == 3 \
+                and t[1].strict_shape:
+            return list(t[1].mean), list(t[1].std)
+        return None
+
+
+class ToUint8HWC:
+    """Loader-side half of the split conversion: PIL -> uint8 ``[H,W,3]`` tensor (no arithmetic)."""
+
+    def __call__(self, pic):
+        return torch.from_numpy(np.array(pic.convert("RGB")))
+
 
 TRANSFORMS = {"totensor": ToTensor, "normalize": Normalize, "pil2np": Pil2Numpy}
 

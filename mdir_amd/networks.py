@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .backbones import OUTPUT_DIM, TrunkSequential, build_features
-from .datasets import ImagesFromList, get_data_root
+from .datasets import ImagesFromList, ToUint8HWC, get_data_root
 from .graphs import ShapeGraphs, graphs_enabled
 from .layers import POOLING, L2N, pool_kind
 
@@ -160,6 +160,10 @@ def extract_ms(net, input, ms, msp):
     return ops.ms_aggregate(per_scale, msp)
 
 
+def _gpu_preprocess(device):
+    return torch.device(device).type == "cuda" and os.environ.get("MDIR_AMD_GPU_PREPROCESS", "1") != "0"
+
+
 def _same_shape_order(images, bbxs):
     """Indices of ``images`` ordered so that images of equal raw size (hence equal network input
     shape) are consecutive: every hipGraph is then captured once and replayed for its whole group
@@ -191,6 +195,12 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     if num_workers is None:
         num_workers = int(os.environ.get("MDIR_AMD_WORKERS", "6"))
     describe = (lambda x: extract_ss(net, x)) if len(ms) == 1 else (lambda x: extract_ms(net, x, ms, msp))
+    tail = transform.device_tail() if hasattr(transform, "device_tail") and _gpu_preprocess(device) else None
+    if tail is not None:
+        # workers ship uint8 pixels (a quarter of the bytes through shared memory, the pinned copy
+        # and PCIe, and no float arithmetic on the host); /255, -mean, /std happen on the GPU
+        transform, from_tensor = ToUint8HWC(), describe
+        describe = lambda u8: from_tensor(ops.u8_to_chw(u8, tail[0], tail[1]))
     order = list(range(len(images)))
     if graphs_enabled(device):
         describe = ShapeGraphs(describe)      # per input shape: eager twice, then one hipGraph replay per image

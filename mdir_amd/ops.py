@@ -97,6 +97,23 @@ def ms_aggregate(vecs, msp=1.0):
     return out
 
 
+def u8_to_chw(images, mean, std):
+    """uint8 ``[B,H,W,C]`` device images -> normalised fp32 ``[B,C,H,W]`` (``mdx_u8_to_chw``):
+    ``(u / 255 - mean) / std``, the scenarios' ``pil2np | totensor | normalize``."""
+    if not (images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.is_contiguous()):
+        raise ValueError("u8_to_chw expects a contiguous uint8 [B,H,W,C] CUDA/ROCm tensor (no CPU fallback)")
+    b, h, w, c = images.shape
+    if len(mean) != c or len(std) != c:
+        raise ValueError("mean / std need %d values" % c)
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=images.device)
+    if images.numel() == 0:
+        return out
+    arr = ctypes.c_float * c
+    check(_lib.lib().mdx_u8_to_chw(images.data_ptr(), b, h, w, c, arr(*[float(v) for v in mean]),
+                                   arr(*[float(v) for v in std]), out.data_ptr(), _stream()), "mdx_u8_to_chw")
+    return out
+
+
 def bn_act_(x, running_mean, running_var, weight=None, bias=None, eps=1e-5, residual=None, relu=True):
     """In place on a convolution output ``x [N,C,H,W]``: inference batch-norm, ``+ residual``, ReLU
     in one pass (``mdx_bn_act``); returns ``x``.  Called ~100 times per image by a launch-bound trunk,

@@ -346,6 +346,16 @@ def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
     eager = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
     assert len(made) == 1
     np.testing.assert_allclose(graphed.cpu().numpy(), eager.cpu().numpy(), rtol=0, atol=1e-6)
+    # GPU-side `pil2np | totensor | normalize` (uint8 through the loader) == the host transform chain
+    assert tr.device_tail() is not None
+    monkeypatch.setenv("MDIR_AMD_GPU_PREPROCESS", "0")
+    host = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
+    np.testing.assert_allclose(host.cpu().numpy(), eager.cpu().numpy(), rtol=0, atol=1e-6)   # MIOpen is not run-to-run bit-stable
+    from mdir_amd import ops
+    from mdir_amd.datasets import ToUint8HWC
+    pic = Image.open(paths[0])
+    got = ops.u8_to_chw(ToUint8HWC()(pic)[None].to(DEV), *tr.device_tail())
+    np.testing.assert_array_equal(got.cpu().numpy()[0], tr(pic).numpy())                 # bit-identical arithmetic
 
 
 def test_eval_py_two_processes_print_the_same_numbers(tmp_path):
