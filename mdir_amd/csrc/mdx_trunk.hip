@@ -25,41 +25,67 @@ __device__ __forceinline__ void bn_coeffs(const BnArgs &a, int c, float &mean, f
     shift = a.bias ? a.bias[c] : 0.0f;
 }
 
-// VEC = 4: planes are a multiple of 4 long and 16-B aligned, so a float4 never straddles channels
+// One workgroup = a run of one (image, channel) plane, so the four per-channel statistics are
+// scalar loads and no thread divides anything.  VEC = 4: planes are a multiple of 4 long and 16-B
+// aligned (float4 accesses); VEC = 1 covers odd plane sizes.  Each thread takes UNR elements, all
+// loads issued before the first store.
+constexpr int BN_UNR = 4;
+
 template <int VEC, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_act_kernel(float *__restrict__ x, const float *__restrict__ res,
-                                                     int64_t total_vec, unsigned hw_vec, unsigned C, BnArgs a)
+                                                     int64_t plane0, unsigned hw_vec, unsigned C, BnArgs a)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
-        const unsigned c = (unsigned)((uint64_t)i / hw_vec) % C;
-        float mean, scale, shift;
-        bn_coeffs(a, (int)c, mean, scale, shift);
-        if (VEC == 4) {
-            float4 v = ((const float4 *)x)[i];
-            float4 r = RES ? ((const float4 *)res)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            v.x = fmaf(v.x - mean, scale, shift) + r.x;
-            v.y = fmaf(v.y - mean, scale, shift) + r.y;
-            v.z = fmaf(v.z - mean, scale, shift) + r.z;
-            v.w = fmaf(v.w - mean, scale, shift) + r.w;
-            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            ((float4 *)x)[i] = v;
-        } else {
-            float v = fmaf(x[i] - mean, scale, shift) + (RES ? res[i] : 0.0f);
-            x[i] = RELU ? fmaxf(v, 0.f) : v;
+    const int64_t plane = plane0 + blockIdx.y;
+    float mean, scale, shift;
+    bn_coeffs(a, (int)(plane % C), mean, scale, shift);
+    const int64_t base = plane * hw_vec;
+    const unsigned i0 = blockIdx.x * (256 * BN_UNR) + threadIdx.x;
+    if (VEC == 4) {
+        float4 v[BN_UNR], r[BN_UNR];
+#pragma unroll
+        for (int u = 0; u < BN_UNR; ++u) {
+            const unsigned i = i0 + u * 256;
+            if (i < hw_vec) {
+                v[u] = ((const float4 *)x)[base + i];
+                if (RES) r[u] = ((const float4 *)res)[base + i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BN_UNR; ++u) {
+            const unsigned i = i0 + u * 256;
+            if (i >= hw_vec) continue;
+            float4 o;
+            o.x = fmaf(v[u].x - mean, scale, shift) + (RES ? r[u].x : 0.f);
+            o.y = fmaf(v[u].y - mean, scale, shift) + (RES ? r[u].y : 0.f);
+            o.z = fmaf(v[u].z - mean, scale, shift) + (RES ? r[u].z : 0.f);
+            o.w = fmaf(v[u].w - mean, scale, shift) + (RES ? r[u].w : 0.f);
+            if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            ((float4 *)x)[base + i] = o;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < BN_UNR; ++u) {
+            const unsigned i = i0 + u * 256;
+            if (i >= hw_vec) continue;
+            const float o = fmaf(x[base + i] - mean, scale, shift) + (RES ? res[base + i] : 0.0f);
+            x[base + i] = RELU ? fmaxf(o, 0.f) : o;
         }
     }
 }
 
 template <int VEC>
-static void launch_bn_act(float *x, const float *res, int64_t total_vec, unsigned hw_vec, unsigned C, const BnArgs &a,
+static void launch_bn_act(float *x, const float *res, int64_t planes, unsigned hw_vec, unsigned C, const BnArgs &a,
                           bool relu, hipStream_t s)
 {
-    const int64_t want = ceil_div(total_vec, (int64_t)256);
-    const unsigned grid = (unsigned)(want < 256 * 16 ? (want > 0 ? want : 1) : 256 * 16);
-    if (res && relu) hipLaunchKernelGGL((bn_act_kernel<VEC, true, true>), dim3(grid), dim3(256), 0, s, x, res, total_vec, hw_vec, C, a);
-    else if (res)    hipLaunchKernelGGL((bn_act_kernel<VEC, true, false>), dim3(grid), dim3(256), 0, s, x, res, total_vec, hw_vec, C, a);
-    else if (relu)   hipLaunchKernelGGL((bn_act_kernel<VEC, false, true>), dim3(grid), dim3(256), 0, s, x, res, total_vec, hw_vec, C, a);
-    else             hipLaunchKernelGGL((bn_act_kernel<VEC, false, false>), dim3(grid), dim3(256), 0, s, x, res, total_vec, hw_vec, C, a);
+    const unsigned gx = (unsigned)ceil_div((int64_t)hw_vec, (int64_t)(256 * BN_UNR));
+    for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+        const unsigned gy = (unsigned)((planes - p0) < 65535 ? (planes - p0) : 65535);
+        const dim3 grid(gx, gy);
+        if (res && relu) hipLaunchKernelGGL((bn_act_kernel<VEC, true, true>), grid, dim3(256), 0, s, x, res, p0, hw_vec, C, a);
+        else if (res)    hipLaunchKernelGGL((bn_act_kernel<VEC, true, false>), grid, dim3(256), 0, s, x, res, p0, hw_vec, C, a);
+        else if (relu)   hipLaunchKernelGGL((bn_act_kernel<VEC, false, true>), grid, dim3(256), 0, s, x, res, p0, hw_vec, C, a);
+        else             hipLaunchKernelGGL((bn_act_kernel<VEC, false, false>), grid, dim3(256), 0, s, x, res, p0, hw_vec, C, a);
+    }
 }
 
 }  // namespace mdx
@@ -77,10 +103,9 @@ extern "C" int mdx_bn_act(float *x, const float *residual, int64_t N, int64_t C,
     MDX_CHECK_ARG(C < (1ll << 31) && HW < (1ll << 31), "mdx_bn_act: C or HW too large");
     MDX_CHECK_ARG(eps >= 0.0f, "mdx_bn_act: eps=%g must be >= 0", (double)eps);
     const BnArgs a{mean, var, weight, bias, eps};
-    const int64_t total = N * C * HW;
     const bool vec = (HW % 4 == 0) && (((uintptr_t)x & 15) == 0) && (!residual || ((uintptr_t)residual & 15) == 0);
-    if (vec) launch_bn_act<4>(x, residual, total / 4, (unsigned)(HW / 4), (unsigned)C, a, relu != 0, (hipStream_t)stream);
-    else     launch_bn_act<1>(x, residual, total, (unsigned)HW, (unsigned)C, a, relu != 0, (hipStream_t)stream);
+    if (vec) launch_bn_act<4>(x, residual, N * C, (unsigned)(HW / 4), (unsigned)C, a, relu != 0, (hipStream_t)stream);
+    else     launch_bn_act<1>(x, residual, N * C, (unsigned)HW, (unsigned)C, a, relu != 0, (hipStream_t)stream);
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
