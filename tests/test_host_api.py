@@ -529,3 +529,128 @@ def test_whitening_learning(fops):
     S = np.ones((3, 3))                                          # singular: needs the diagonal bump
     L = cholesky(S)
     assert np.allclose(L @ L.T, S, atol=1e-6)
+
+
+# ------------------------------------------------------------------ f2/f3: stage wrappers
+
+def test_whitening_stages(fops):
+    """mdir/stages/whiten.py: whiten / learn_lw_whitening / learn_pca_whitening / paste_pca_normalize
+    keep the (params, data) -> (metadata, ...) protocol and the reference's arithmetic."""
+    from mdir_amd import stage_whiten as S
+    rng = np.random.default_rng(1)
+    D, N, npairs = 16, 300, 120
+    basis = np.linalg.qr(rng.standard_normal((D, D)))[0] * np.geomspace(2.0, 0.3, D)
+    values = (basis @ rng.standard_normal((D, N))).T.astype(np.float32)           # [N,D] as the stages carry them
+    values /= np.linalg.norm(values, axis=1, keepdims=True)
+    names = ["img%03d" % i for i in range(N)]
+    q = [names[i] for i in rng.choice(N, npairs, replace=False)]
+    p = [names[i] for i in rng.choice(N, npairs, replace=False)]
+    meta, Lw = S.learn_lw_whitening({}, (names, values, q, p), device="cpu")
+    assert meta["stats"] == {"failed_times": 0, "vectors_used": 1.0, "vectors_total": npairs}
+    assert set(meta) == {"stats", "timings", "resource_usage"} and "whitening_learn" in meta["timings"]
+    idx = {x: i for i, x in enumerate(names)}
+    mr, Pr = _reference_whitenlearn(values.astype(np.float64).T, np.array([idx[x] for x in q]), np.array([idx[x] for x in p]))
+    np.testing.assert_allclose(Lw["m"], mr, rtol=1e-6)
+    sign = np.sign(np.sum(Lw["P"] * Pr, axis=1, keepdims=True))
+    np.testing.assert_allclose(Lw["P"] * sign, Pr, rtol=2e-2, atol=2e-3)
+    # apply stage: [N,D] in, [N,d] out, unit rows, names passed through
+    meta, names_out, wh = S.whiten({"dimensions": 8}, (Lw, names, values), device="cpu")
+    assert names_out is names and wh.shape == (N, 8) and "whitening_apply" in meta["timings"]
+    X = (Lw["P"][:8] @ (values.T.astype(np.float64) - Lw["m"]))
+    np.testing.assert_allclose(wh, (X / (np.linalg.norm(X, axis=0, keepdims=True) + 1e-6)).T, rtol=1e-4, atol=1e-5)
+    with pytest.raises(AssertionError):
+        S.whiten({"dimensions": 8, "bogus": 1}, (Lw, names, values), device="cpu")
+    # pca
+    meta, pca = S.learn_pca_whitening({"shrink": None}, (values,), device="cpu")
+    Xw = pca["P"] @ (values.T.astype(np.float64) - pca["m"])
+    np.testing.assert_allclose(Xw @ Xw.T / N, np.eye(D), atol=5e-3)
+    # paste + pca + normalise: numpy restatement of whiten.py:90-118
+    a, b = values[:, :10].astype(np.float64), values[:, 10:].astype(np.float64)
+    meta, pasted = S.paste_pca_normalize({"dimensions": 5}, (a.copy(), b.copy()), device="cpu")
+    v = np.concatenate([a, b], axis=1)
+    v = v - np.mean(v)
+    ev, evec = np.linalg.eig(v.T.dot(v))
+    keep = evec[:, np.argsort(ev)[-5:]]
+    want = v.dot(keep.dot(keep.T))
+    want = want / np.linalg.norm(want, axis=1, keepdims=True)
+    np.testing.assert_allclose(pasted, want, rtol=1e-3, atol=1e-4)
+    assert "pca_compute" in meta["timings"]
+    meta, plain = S.paste_pca_normalize({"dimensions": None}, (a, b), device="cpu")
+    assert meta == {} and np.allclose(np.linalg.norm(plain, axis=1), 1.0)
+    assert S.paste_pca_normalize({"dimensions": None}, (np.empty((0,)),), device="cpu")[1].shape == (0,)
+
+
+def test_cirtorch_format_stages(fops, tmp_path, monkeypatch):
+    """mdir/stages/cirtorch_format/test.py: embed / learn_whitening / load_whitening /
+    convert_contained_net on an upstream-format checkpoint."""
+    from mdir_amd import cirtorch_format as C
+    from mdir_amd.datasets import Compose, Normalize, ToTensor
+    from mdir_amd.network import load_network
+    from mdir_amd.networks import extract_vectors, init_network
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    rng = np.random.default_rng(5)
+    root = tmp_path / "data"
+    monkeypatch.setenv("CIRTORCH_ROOT", str(tmp_path))
+    # a whitening training set in the upstream layout: train/<name>/ims/<c[-2:]>/<c[-4:-2]>/<c[-6:-4]>/<cid>
+    name = "retrieval-SfM-30k"
+    cids = ["%032x" % int(x) for x in rng.integers(1, 2 ** 62, 12)]
+    for cid in cids:
+        path = C.cid2filename(cid, str(root / "train" / name / "ims"))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        from PIL import Image
+        Image.fromarray(rng.integers(0, 255, (200, 240, 3), dtype=np.uint8)).save(path, format="JPEG")
+    db = {"cids": cids, "qidxs": [0, 1, 2, 3, 4, 5], "pidxs": [6, 7, 8, 9, 10, 11]}
+    with open(root / "train" / name / (name + "-whiten.pkl"), "wb") as f:
+        pickle.dump(db, f)
+    # upstream checkpoint with a stored whitening
+    torch.manual_seed(2)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False})
+    stored = {"m": rng.standard_normal((256, 1)), "P": rng.standard_normal((256, 256))}
+    meta = {"architecture": "alexnet", "pooling": "gem", "whitening": False, "mean": net.meta["mean"], "std": net.meta["std"],
+            "outputdim": 256, "local_whitening": False, "regional": False,
+            "Lw": {name: {"ms": stored, "ss": {"m": stored["m"] + 1, "P": stored["P"]}}}}
+    ckpt = str(tmp_path / "upstream.pth")
+    torch.save({"meta": meta, "state_dict": net.state_dict()}, ckpt)
+
+    # load_whitening: both return styles, alias names
+    out = C.load_whitening({"net": ckpt, "whitening": "sfm30k", "multiscale": True}, ())
+    assert out[0] == {} and out[1] is not None and np.array_equal(out[1]["m"], stored["m"])
+    wdir = str(tmp_path / "wh")
+    assert C.load_whitening({"net": ckpt, "whitening": name, "multiscale": False, "whitening_dir": wdir, "image_size": 192}, ()) == ({},)
+    assert os.path.isfile(os.path.join(wdir, "%s_None_192_False.lw.pkl" % name))
+
+    # learn_whitening writes <whitening>_None_<size>_<multiscale>.lw.pkl and embed consumes it
+    meta_l, = C.learn_whitening({"net": ckpt, "whitening": "sfm30k", "whitening_dir": wdir, "image_size": 192,
+                                 "multiscale": True}, (), device="cpu")
+    assert set(meta_l) == {"whitening_learn"}
+    with open(os.path.join(wdir, "%s_None_192_True.lw.pkl" % name), "rb") as f:
+        Lw = pickle.load(f)
+    assert Lw["P"].shape == (256, 256) and Lw["m"].shape == (256, 1)
+    imgs = [os.path.relpath(C.cid2filename(c, "ims"), "ims") for c in cids[:4]]
+    imgdir = str(root / "train" / name / "ims")
+    res = C.embed({"net": ckpt, "imgdir": imgdir, "whitening": name, "whitening_dir": wdir, "image_size": 192,
+                   "multiscale": True}, (imgs,), device="cpu")
+    assert res[0] == {} and res[1] == imgs and res[2].shape == (4, 256) and res[3].shape == (4, 256)
+    tr = Compose([ToTensor(), Normalize(net.meta["mean"], net.meta["std"])])
+    with torch.no_grad():
+        want = extract_vectors(net.eval(), [os.path.join(imgdir, x) for x in imgs], 192, tr,
+                               ms=[1, 2 ** -0.5, 0.5], msp=float(net.pool.p), device="cpu").numpy()
+    np.testing.assert_allclose(res[2], want.T, rtol=0, atol=1e-6)
+    X = Lw["P"] @ (want.astype(np.float64) - Lw["m"])
+    np.testing.assert_allclose(res[3], (X / (np.linalg.norm(X, axis=0, keepdims=True) + 1e-6)).T, rtol=1e-3, atol=1e-4)
+    assert C.embed({"net": ckpt, "imgdir": imgdir}, ([],)) == ({"status": "skipped"}, [], [])
+    assert C.embed({"net": ckpt, "imgdir": imgdir, "whitening_dir": wdir}, ([],)) == ({"status": "skipped"}, [], [], [])
+
+    # convert_contained_net -> a CirNetwork checkpoint that load_network reads
+    converted = str(tmp_path / "conv" / "net.pth")
+    assert C.convert_contained_net({"source": ckpt, "net": converted}, ()) == ({},)
+    state = torch.load(converted, weights_only=False)
+    assert state["type"] == "CirNetwork" and state["network_params"]["model"]["cir_architecture"] == "alexnet"
+    assert state["network_params"]["runtime"]["data"]["transforms"] == "pil2np | totensor | normalize"
+    loaded = load_network({"path": converted, "runtime": {}}, "cpu")
+    for k, v in net.state_dict().items():
+        assert torch.equal(loaded.model.state_dict()[k], v)
+    broken = str(tmp_path / "broken.pth")
+    torch.save({"meta": dict(meta, surprise=1), "state_dict": net.state_dict()}, broken)
+    with pytest.raises(AssertionError):
+        C.convert_contained_net({"source": broken, "net": converted}, ())
