@@ -110,9 +110,8 @@ NETWORKS = {"SingleNetwork": SingleNetwork, "CirNetwork": CirNetwork}
 
 def load_checkpoint(path):
     """``Checkpoints.load_network`` for a single file (mdir/learning/checkpoints.py:145-155)."""
-    if path.startswith("http://") or path.startswith("https://"):
-        raise RuntimeError("no network on this path: download '%s' first and pass the local file" % path)
-    checkpoint = torch.load(path, map_location="cpu", weights_only=False)
+    from .scenario import open_resource
+    checkpoint = torch.load(open_resource(path), map_location="cpu", weights_only=False)
     assert "net" not in checkpoint.get("_networks_included", {})
     return {"net": checkpoint, **checkpoint.pop("_networks_included", {})}
 

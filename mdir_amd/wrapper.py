@@ -20,13 +20,10 @@ from . import ops
 
 
 def load_path(path):
-    """Pickle from a local path (mdir/tools/utils.py:44-51; URLs need a network the
-    MI355X boxes do not have, so they are refused loudly)."""
+    """Pickle from a local path or a (mirrored, hash-checked) URL: mdir/tools/utils.py:44-51."""
     assert path.endswith(".pkl"), "Cannot load anything else than pickle at the moment"
-    if path.startswith("http://") or path.startswith("https://"):
-        raise RuntimeError("no network on this path: download '%s' first and pass the local file" % path)
-    with open(path, "rb") as handle:
-        return pickle.load(handle)
+    from .scenario import open_resource
+    return pickle.load(open_resource(path))
 
 
 class Compose(object):

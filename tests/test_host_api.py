@@ -654,3 +654,39 @@ def test_cirtorch_format_stages(fops, tmp_path, monkeypatch):
     torch.save({"meta": dict(meta, surprise=1), "state_dict": net.state_dict()}, broken)
     with pytest.raises(AssertionError):
         C.convert_contained_net({"source": broken, "net": converted}, ())
+
+
+def test_url_resources_are_mirrored_and_hash_checked(tmp_path, monkeypatch):
+    """mdir/tools/utils.py:27-51: `...-<sha256 prefix>.<ext>` names are verified; URLs resolve from a
+    local mirror directory on boxes without a network."""
+    import hashlib
+    from mdir_amd.scenario import open_resource, validate_hash
+    from mdir_amd.wrapper import load_path
+    payload = pickle.dumps({"m": np.zeros((2, 1)), "P": np.eye(2)})
+    good = hashlib.sha256(payload).hexdigest()[:8]
+    validate_hash(payload, "http://x/y/lw-%s.pkl" % good)
+    validate_hash(payload, "http://x/y/plain.pkl")                     # no hash in the name: nothing to check
+    with pytest.raises(ValueError, match="not consistent with stored hash"):
+        validate_hash(payload, "http://x/y/lw-%s.pkl" % ("0" * 8))
+    mirror = tmp_path / "models"
+    mirror.mkdir()
+    (mirror / ("lw-%s.pkl" % good)).write_bytes(payload)
+    (mirror / "lw-00000000.pkl").write_bytes(payload)
+    monkeypatch.setenv("MDIR_AMD_MODELS", str(mirror))
+    got = load_path("http://example.invalid/models/lw-%s.pkl" % good)
+    assert np.array_equal(got["P"], np.eye(2))
+    with pytest.raises(ValueError):
+        load_path("http://example.invalid/models/lw-00000000.pkl")
+    with pytest.raises(RuntimeError, match="MDIR_AMD_MODELS"):
+        open_resource("http://example.invalid/models/absent-12345678.pkl")
+    # the reference's three shortcut scenarios parse and overlay onto eval.yml
+    import importlib
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    ev = importlib.import_module("eval")
+    for shortcut in ("test", "clahe", "composition"):
+        sc = ev.load_scenarios([shortcut])
+        assert sc["network"]["path"].startswith("http://cmp.felk.cvut.cz/daynightretrieval/download/models/")
+        assert set(sc["network"]["runtime"]["wrappers"]["eval"]) == {"0_cirwhiten", "1_cirmultiscale"}
+        assert set(sc["validation"]) >= {"roxford5k", "rparis6k", "247tokyo1k"}
