@@ -6,7 +6,7 @@ from mdir_amd import ops
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1004993
-    nq, d = 70, 2048
+    nq, d = (int(sys.argv[2]) if len(sys.argv) > 2 else 70), 2048
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev); g.manual_seed(0)
     vecs = torch.empty((d, n), dtype=torch.float32, device=dev)
