@@ -137,7 +137,8 @@ def test_pool_batch_and_zero_map(ops):
     assert not np.isnan(got).any()
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 48, 64), (2, 256, 17, 23), (1, 2048, 23, 17), (3, 5, 1, 1), (1, 7, 3, 5)])
+@pytest.mark.parametrize("shape", [(1, 64, 48, 64), (2, 256, 17, 23), (1, 2048, 23, 17), (3, 5, 1, 1), (1, 7, 3, 5),
+                                   (1, 64, 384, 512), (1, 2048, 24, 32)])
 def test_bn_act_vs_oracle_and_torch(ops, shape):
     """Fused trunk epilogue: every combination of residual / relu / affine, aligned and odd planes,
     against the float64 oracle and against torch's own batch_norm + add + relu on the same device."""
@@ -163,6 +164,21 @@ def test_bn_act_vs_oracle_and_torch(ops, shape):
                 np.testing.assert_allclose(got.cpu().numpy(), t.cpu().numpy(), rtol=2e-6, atol=2e-6)
     with pytest.raises(ValueError):
         ops.bn_act_(dev(x), dev(mean[:-1]) if c > 1 else dev(np.zeros(2, np.float32)), dev(var))
+
+
+def test_u8_to_chw_matches_host_chain(ops):
+    """mdx_u8_to_chw == `pil2np | totensor | normalize` bit for bit (RGB and single channel, odd sizes, batch)."""
+    rng = np.random.default_rng(2)
+    for shape, mean, std in (((2, 37, 53, 3), [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]), ((1, 5, 3, 1), [0.5], [0.25]),
+                             ((1, 768, 1024, 3), [0.1, 0.2, 0.3], [1.0, 0.5, 2.0])):
+        u8 = rng.integers(0, 256, shape, dtype=np.uint8)
+        got = ops.u8_to_chw(dev(u8), mean, std).cpu().numpy()
+        want = ((u8.astype(np.float32) / np.float32(255.0)) - np.array(mean, np.float32)) / np.array(std, np.float32)
+        np.testing.assert_array_equal(got, want.transpose(0, 3, 1, 2))
+    with pytest.raises(ValueError):
+        ops.u8_to_chw(dev(u8), [0.0], [1.0])
+    with pytest.raises(ValueError):
+        ops.u8_to_chw(dev(np.zeros((1, 2, 2, 3), np.uint8)), [0, 0, 0], [1, 0, 1])       # zero std
 
 
 def test_fused_trunk_equals_module_calls(ops, monkeypatch):

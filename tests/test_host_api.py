@@ -690,3 +690,36 @@ def test_url_resources_are_mirrored_and_hash_checked(tmp_path, monkeypatch):
         assert sc["network"]["path"].startswith("http://cmp.felk.cvut.cz/daynightretrieval/download/models/")
         assert set(sc["network"]["runtime"]["wrappers"]["eval"]) == {"0_cirwhiten", "1_cirmultiscale"}
         assert set(sc["validation"]) >= {"roxford5k", "rparis6k", "247tokyo1k"}
+
+
+def test_device_tail_detection_and_shape_order(tmp_path):
+    """Only the exact PIL -> normalised tensor conversions are moved behind the H2D copy; any other
+    chain stays on the host.  Equal-sized images are visited consecutively."""
+    from mdir_amd.datasets import Compose, Normalize, Pil2Numpy, ToTensor, ToUint8HWC, initialize_transforms
+    from mdir_amd.networks import _same_shape_order
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    assert initialize_transforms("pil2np | totensor | normalize", [mean, std]).device_tail() == (mean, std)
+    assert Compose([ToTensor(), Normalize(mean, std)]).device_tail() == (mean, std)
+    assert Compose([ToTensor()]).device_tail() is None
+    assert Compose([Pil2Numpy(), ToTensor()]).device_tail() is None
+    assert Compose([ToTensor(), Normalize(mean, std), ToTensor()]).device_tail() is None
+    assert Compose([ToTensor(), Normalize(mean[:1], std[:1])]).device_tail() is None          # not RGB
+    assert Compose([ToTensor(), Normalize(mean, std, strict_shape=False)]).device_tail() is None
+    rng = np.random.default_rng(0)
+    pic = Image.fromarray(rng.integers(0, 255, (5, 7, 3), dtype=np.uint8))
+    u8 = ToUint8HWC()(pic)
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (5, 7, 3)
+    # the split conversion restated on the CPU equals the host chain bit for bit
+    want = initialize_transforms("pil2np | totensor | normalize", [mean, std])(pic)
+    got = ((u8.float() / 255.0).permute(2, 0, 1) - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+    assert torch.equal(got, want)
+    paths = []
+    for i, size in enumerate([(8, 6), (6, 8), (8, 6), (9, 9), (6, 8)]):
+        p = str(tmp_path / ("s%d.png" % i))
+        Image.fromarray(rng.integers(0, 255, (size[1], size[0], 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    paths.append(str(tmp_path / "missing.png"))
+    order = _same_shape_order(paths, None)
+    assert sorted(order) == list(range(6)) and order[:1] == [5]          # unreadable header: own group, first
+    assert order[1:] == [1, 4, 0, 2, 3]
+    assert _same_shape_order(paths[:3], [(0, 0, 4, 4), None, (1, 1, 5, 5)]) == [0, 2, 1]      # crops group by box size
