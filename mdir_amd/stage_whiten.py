@@ -6,7 +6,6 @@ Same ``(params, data) -> (metadata, ...)`` protocol, same metadata keys.  The ma
 the GPU through ``mdir_amd.whiten`` (``mdx_scores``); the small dense factorisations stay on the
 host as in the reference.
 """
-import os
 import sys
 import time
 
