@@ -108,19 +108,32 @@ def infer(params, data, device=None):
     assert ds.pop("name") == "CirImageList", "only image-list datasets are on the inference path"
     image_dir = ds.pop("image_dir")
     transform = initialize_transforms(data_params["transforms"], data_params["mean_std"])
-    dataset = ImagesFromList(root="", images=[path_join(image_dir, x) for x in images], imsize=ds.pop("image_size"),
-                             bbxs=bbxs, transform=transform, **ds)
+    # same device-side pieces as extract_vectors_device: uint8 through the loader, one hipGraph
+    # replay per input shape, equal-sized images consecutively (rows stay at the caller's indices)
+    from . import ops
+    from .datasets import ToUint8HWC
+    from .graphs import ShapeGraphs, graphs_enabled
+    from .networks import _gpu_preprocess, _same_shape_order
+    paths = [path_join(image_dir, x) for x in images]
+    describe = network
+    tail = transform.device_tail() if _gpu_preprocess(device) else None
+    if tail is not None:
+        transform, describe = ToUint8HWC(), (lambda u8: network(ops.u8_to_chw(u8, tail[0], tail[1])))
+    order = list(range(len(paths)))
+    if graphs_enabled(device):
+        describe, order = ShapeGraphs(describe), _same_shape_order(paths, bbxs)
+    dataset = ImagesFromList(root="", images=paths, imsize=ds.pop("image_size"), bbxs=bbxs, transform=transform, **ds)
     import os
-    loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, pin_memory=True,
+    loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, sampler=order, pin_memory=True,
                                          num_workers=int(os.environ.get("MDIR_AMD_WORKERS", "6")),
                                          collate_fn=_collate_one)
     t0 = time.time()
     with torch.no_grad():
-        for i, indata in enumerate(loader):
+        for i, indata in zip(order, loader):
             if isinstance(indata, dict) and indata == {}:
                 output.add(i, None, None)
             else:
-                output.add(i, indata, network(indata.to(device, non_blocking=True)))
+                output.add(i, indata, describe(indata.to(device, non_blocking=True)))
     total = time.time() - t0
     metadata = {"stats": {"total_time": int(total), "avg_time": total / len(loader)}}
     return (metadata,) + output.postprocess()
