@@ -106,6 +106,20 @@ def cpu_baseline(vecs_dn_host, qvecs_host):
     return sc, rk, float(np.median(dots)), float(np.median(sorts))
 
 
+def cpu_dot_three_threads(vecs_dn_host, qvecs_host):
+    """np.dot with the BLAS pool limited to 3 threads: what the reference's `OMP_NUM_THREADS=3`
+    (mdir/stages/validate.py:10-12) gives when the BLAS honours it."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        return None
+    from oracle import oracle as O
+    with threadpool_limits(limits=3, user_api="blas"):
+        t0 = time.perf_counter()
+        O.scores(vecs_dn_host, qvecs_host)
+        return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +268,10 @@ def main():
                 "kind": "port",
                 "sample": "full workload, median of 3: np.dot %.2f s (BLAS, all cores) + np.argsort %.2f s (1 thread), "
                           "N=%d Q=%d D=%d fp32" % (t_dot, t_sort, n_total, NQ, DIM)}
+            t_dot3 = cpu_dot_three_threads(vecs_host, qvecs.cpu().numpy())
+            if t_dot3 is not None:
+                extra["cpu_baseline"]["value_blas_3_threads"] = round(NQ / (t_dot3 + t_sort), 3)
+                extra["cpu_baseline"]["sample"] += "; with the BLAS pool at 3 threads (the reference's OMP_NUM_THREADS=3) np.dot takes %.2f s" % t_dot3
             agree = float((rk_cpu[:100] == rk[:, :100].t().cpu().numpy()).mean())
             extra["cpu_top100_id_agreement"] = round(agree, 6)
             del vecs_host, rk_cpu
