@@ -287,54 +287,106 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
 // ---------------------------------------------------------------------------
 // counting ranks of labelled items
 // ---------------------------------------------------------------------------
+// Every lane keeps its elements (16 per 4096-element tile) in registers and a private counter per
+// labelled item.  Ids only break ties, and all rows of a tile lie on one side of a labelled id unless
+// the tile contains it, so "precedes" is a plain 32-bit `key < thr` with a per-(tile, item)
+// threshold: rk for a tile after the item (ties follow it), rk + 1 for a tile before it (ties
+// precede it).  Written mask-free -- min(usub_sat(thr, key), 1) -- so that there is no VCC/SGPR
+// round trip: compares through VCC serialised the first versions of this kernel (0.5 ms at
+// 1 M x 70 x 20 items, twenty times the cost of its instruction count).  The tile holding the item
+// and NaN items (rk = all ones) take an exact 64-bit compare from the same registers.  Items are
+// taken 16 at a time; one atomic per item and workgroup at the end.
 constexpr int CNT_TILE = 4096;
-constexpr int CNT_REFS = 256;
+constexpr int CNT_ITEMS = CNT_TILE / 256;     // elements per lane and tile
+constexpr int CNT_REFS = 16;                  // labelled items per sweep over the scores
 
 __global__ __launch_bounds__(256) void rank_count_kernel(
     const float *__restrict__ scores, int64_t n, int64_t id_offset,
     const float *__restrict__ ref_scores, const int64_t *__restrict__ ref_ids,
-    const int64_t *__restrict__ offsets, unsigned long long *__restrict__ cnt)
+    const int64_t *__restrict__ offsets, unsigned long long *__restrict__ cnt, int nblk)
 {
-    __shared__ uint32_t skey[CNT_TILE];
-    __shared__ uint32_t rkey[CNT_REFS];
-    __shared__ int64_t rid[CNT_REFS];
-    __shared__ uint32_t rcnt[CNT_REFS];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t srk[CNT_REFS], sri[CNT_REFS];
+    __shared__ uint32_t swave[4][CNT_REFS];
+    const int tid = threadIdx.x, lane = tid & 63;
     const int64_t q = blockIdx.y;
-    const int64_t t0 = (int64_t)blockIdx.x * CNT_TILE;
     const int64_t lo = offsets[q], hi = offsets[q + 1];
-    if (lo >= hi) return;
-    const int tile_n = (int)((n - t0) < CNT_TILE ? (n - t0) : CNT_TILE);
-    for (int e = tid; e < CNT_TILE; e += 256)
-        skey[e] = e < tile_n ? desc_key(scores[q * n + t0 + e]) : 0xFFFFFFFFu;
     for (int64_t r0 = lo; r0 < hi; r0 += CNT_REFS) {
         const int nref = (int)((hi - r0) < CNT_REFS ? (hi - r0) : CNT_REFS);
         __syncthreads();
-        if (tid < nref) {
-            rkey[tid] = desc_key(ref_scores[r0 + tid]);
-            rid[tid] = ref_ids[r0 + tid];
-        }
-        rcnt[tid] = 0;
-        __syncthreads();
-        // slots = power of two >= nref; the 256 threads split into 256/slots element slices
-        int slots = 1;
-        while (slots < nref) slots <<= 1;
-        const int slices = 256 / slots;
-        const int slot = tid & (slots - 1), slice = tid / slots;
-        if (slot < nref) {
-            const uint32_t rk = rkey[slot];
-            const int64_t ri = rid[slot];
-            const int per = (tile_n + slices - 1) / slices;
-            const int e0 = slice * per, e1 = (e0 + per) < tile_n ? (e0 + per) : tile_n;
-            uint32_t c = 0;
-            for (int e = e0; e < e1; ++e) {
-                const uint32_t k = skey[e];
-                c += (k < rk) || (k == rk && (t0 + e + id_offset) < ri);
+        if (tid < CNT_REFS) {
+            uint32_t rk = 0, ri = 0;                                // nothing precedes (0 : 0)
+            if (tid < nref) {
+                const int64_t id = ref_ids[r0 + tid];
+                ri = id < 0 ? 0u : (id > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)id);
+                rk = desc_key(ref_scores[r0 + tid]);
             }
-            if (c) atomicAdd(&rcnt[slot], c);
+            srk[tid] = rk;
+            sri[tid] = ri;
         }
         __syncthreads();
-        if (tid < nref && rcnt[tid]) atomicAdd(&cnt[r0 + tid], (unsigned long long)rcnt[tid]);
+        uint32_t c[CNT_REFS];
+#pragma unroll
+        for (int k = 0; k < CNT_REFS; ++k) c[k] = 0;
+        for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+            const int64_t t0 = (int64_t)b * CNT_TILE;
+            uint32_t key[CNT_ITEMS];
+#pragma unroll
+            for (int e = 0; e < CNT_ITEMS; ++e) {
+                const int64_t i = t0 + e * 256 + tid;
+                key[e] = i < n ? desc_key(scores[q * n + i]) : 0xFFFFFFFFu;      // padding precedes nothing
+            }
+            const uint64_t gid0 = (uint64_t)(t0 + id_offset);
+            uint32_t thr[CNT_REFS], exact = 0;
+#pragma unroll
+            for (int k = 0; k < CNT_REFS; ++k) {
+                const uint32_t rk = __builtin_amdgcn_readfirstlane(srk[k]), ri = __builtin_amdgcn_readfirstlane(sri[k]);
+                const bool before = gid0 + CNT_TILE <= (uint64_t)ri, after = gid0 > (uint64_t)ri;
+                const bool ex = k < nref && (!(before || after) || rk == 0xFFFFFFFFu);
+                exact |= ex ? 1u << k : 0u;
+                thr[k] = (ex || k >= nref) ? 0u : rk + (before ? 1u : 0u);       // thr 0 counts nothing
+            }
+#pragma unroll
+            for (int g = 0; g < CNT_REFS / 8; ++g)
+                if (g * 8 < nref) {                                 // uniform: skip empty groups of 8 items
+#pragma unroll
+                    for (int e = 0; e < CNT_ITEMS; ++e)
+#pragma unroll
+                        for (int k = g * 8; k < g * 8 + 8; ++k) {
+                            // min(usub_sat(thr, key), 1) = [key < thr]; as asm because the optimiser folds
+                            // the C form back into a compare + carry through VCC
+                            uint32_t d;
+                            asm("v_sub_u32_e64 %0, %1, %2 clamp\n\tv_min_u32_e32 %0, 1, %0" : "=v"(d) : "s"(thr[k]), "v"(key[e]));
+                            c[k] += d;
+                        }
+                }
+            if (exact) {                                            // uniform, rare
+#pragma unroll
+                for (int k = 0; k < CNT_REFS; ++k)
+                    if ((exact >> k) & 1u) {
+                        const uint64_t r = ((uint64_t)__builtin_amdgcn_readfirstlane(srk[k]) << 32) |
+                                           __builtin_amdgcn_readfirstlane(sri[k]);
+#pragma unroll
+                        for (int e = 0; e < CNT_ITEMS; ++e) {
+                            const uint64_t el = ((uint64_t)key[e] << 32) | ((uint32_t)gid0 + (uint32_t)(e * 256 + tid));
+                            c[k] += (t0 + e * 256 + tid) < n && el < r ? 1u : 0u;
+                        }
+                    }
+            }
+        }
+        // wave reduction, then ONE global atomic per item and workgroup (device-scope atomics on a
+        // shared address serialise across the XCDs)
+#pragma unroll
+        for (int k = 0; k < CNT_REFS; ++k) {
+            uint32_t v = c[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) swave[tid >> 6][k] = v;
+        }
+        __syncthreads();
+        if (tid < nref) {
+            const unsigned long long v = (unsigned long long)swave[0][tid] + swave[1][tid] + swave[2][tid] + swave[3][tid];
+            if (v) atomicAdd(&cnt[r0 + tid], v);
+        }
     }
 }
 
@@ -755,9 +807,14 @@ int mdx_rank_count(const float *scores, int64_t n, int64_t nq, int64_t id_offset
     MDX_CHECK_ARG(scores && ref_scores && ref_ids && offsets && cnt, "mdx_rank_count: NULL pointer");
     MDX_CHECK_ARG(n > 0 && nq > 0 && total >= 0 && nq < 65536, "mdx_rank_count: bad sizes");
     if (total == 0) return MDX_OK;
-    const dim3 grid((unsigned)ceil_div(n, CNT_TILE), (unsigned)nq);
+    MDX_CHECK_ARG(n + id_offset < (1ll << 32) && id_offset >= 0, "mdx_rank_count: ids must fit 32 bits");
+    const int64_t nblk = ceil_div(n, CNT_TILE);
+    // enough workgroups to fill the chip (~8 per CU), each striding over its share of the tiles
+    int64_t gx = ceil_div((int64_t)2048, nq);
+    gx = gx < 1 ? 1 : (gx > nblk ? nblk : gx);
+    const dim3 grid((unsigned)gx, (unsigned)nq);
     hipLaunchKernelGGL(rank_count_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, n,
-                       id_offset, ref_scores, ref_ids, offsets, (unsigned long long *)cnt);
+                       id_offset, ref_scores, ref_ids, offsets, (unsigned long long *)cnt, (int)nblk);
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
