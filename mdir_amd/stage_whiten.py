@@ -31,67 +31,70 @@ def resource_usage():
     return out
 
 
+def _metadata(label, started, **sections):
+    """``{"timings": {label: seconds}, "resource_usage": ..., **sections}`` as every stage reports it."""
+    out = dict(sections)
+    out["timings"] = {label: round(time.time() - started, 2)}
+    out["resource_usage"] = resource_usage()
+    return out
+
+
 def whiten(params, data, device="cuda"):
     """Apply a pre-computed whitening to ``values [N,D]``: returns ``(metadata, names, [N,d])``."""
     dimensions = params.pop("dimensions", None) or None
     assert not params, params.keys()
     whitening, names, values = data
     assert len(names) == len(values)
-    time0 = time.time()
-    whitened = W.whitenapply(values.T, whitening["m"], whitening["P"], dimensions, device=device)
-    timing = time.time() - time0
-    metadata = {"timings": {"whitening_apply": round(timing, 2)}, "resource_usage": resource_usage()}
-    return metadata, names, whitened.T
+    started = time.time()
+    projected = W.whitenapply(values.T, whitening["m"], whitening["P"], dimensions, device=device)
+    return _metadata("whitening_apply", started), names, projected.T
+
+
+def _pair_subset(qidxs, pidxs, trial, max_trials, max_excluded):
+    """Trial 0 uses every (query, positive) pair; trial t keeps a random ``1 - t/max_trials * max_excluded``
+    share of them (the reference's answer to a covariance that is not positive definite)."""
+    if trial == 0:
+        return qidxs, pidxs
+    keep = int(len(qidxs) * (1 - trial / max_trials * max_excluded))
+    chosen = np.random.permutation(len(qidxs))[:keep]
+    print("Using subset of queries (%s/%s) trial %s" % (len(chosen), len(qidxs), trial), file=sys.stderr)
+    return qidxs[chosen], pidxs[chosen]
 
 
 def learn_lw_whitening(params, data, device="cuda"):
-    """Learned whitening from (query, positive) name pairs.  If the pair covariance is not positive
-    definite the reference retries on a shrinking random subset of the pairs (up to 100 trials, at
-    most 95 % excluded); ``whitenlearn``'s own ``cholesky`` already regularises the diagonal, so
-    like there the retry loop only triggers on a ``LinAlgError`` that escapes it."""
+    """Learned whitening from (query, positive) name pairs.  ``whitenlearn``'s own ``cholesky``
+    already regularises the diagonal, so like in the reference the shrinking-subset retry (up to 100
+    trials, at most 95 % of the pairs excluded) only triggers on a ``LinAlgError`` that escapes it."""
     assert not params
     names, values, queries, positives = data
     assert len(names) == len(values)
     assert len(queries) == len(positives)
-    values = values.astype(np.float64).T
-    name_index = {x: i for i, x in enumerate(names)}
-    qidxs = np.array([name_index[x] for x in queries])
-    pidxs = np.array([name_index[x] for x in positives])
+    row_of = {name: row for row, name in enumerate(names)}
+    qidxs = np.array([row_of[name] for name in queries])
+    pidxs = np.array([row_of[name] for name in positives])
+    columns = values.astype(np.float64).T
 
-    time0 = time.time()
-    max_trials, max_excluded, trial = 100, 0.95, 0
-    while True:
+    started, max_trials = time.time(), 100
+    for trial in range(max_trials):
+        qsel, psel = _pair_subset(qidxs, pidxs, trial, max_trials, max_excluded=0.95)
         try:
-            if trial == 0:
-                qwhit, pwhit = qidxs, pidxs
-            else:
-                keep = int(len(qidxs) * (1 - trial / max_trials * max_excluded))
-                idxs = np.random.permutation(len(qidxs))[:keep]
-                print("Using subset of queries (%s/%s) trial %s" % (len(idxs), len(qidxs), trial), file=sys.stderr)
-                qwhit, pwhit = qidxs[idxs], pidxs[idxs]
-            whit_m, whit_p = W.whitenlearn(values, qwhit, pwhit, device=device)
+            mean, proj = W.whitenlearn(columns, qsel, psel, device=device)
             break
         except np.linalg.LinAlgError as err:
-            if str(err) != "Matrix is not positive definite" or trial >= max_trials - 1:
+            if str(err) != "Matrix is not positive definite" or trial == max_trials - 1:
                 raise
-            trial += 1
-    timing = time.time() - time0
-    metadata = {"stats": {"failed_times": trial, "vectors_used": round(len(qwhit) / float(len(qidxs)), 2),
-                          "vectors_total": len(qidxs)},
-                "timings": {"whitening_learn": round(timing, 2)}, "resource_usage": resource_usage()}
-    return metadata, {"m": whit_m, "P": whit_p}
+    stats = {"failed_times": trial, "vectors_used": round(len(qsel) / float(len(qidxs)), 2),
+             "vectors_total": len(qidxs)}
+    return _metadata("whitening_learn", started, stats=stats), {"m": mean, "P": proj}
 
 
 def learn_pca_whitening(params, data, device="cuda"):
     shrink = params.pop("shrink", None) or None
     assert not params
     values, = data
-    values = values.astype(np.float64).T
-    time0 = time.time()
-    whit_m, whit_p = W.pcawhitenlearn(values, shrink, device=device)
-    timing = time.time() - time0
-    metadata = {"timings": {"whitening_learn": round(timing, 2)}, "resource_usage": resource_usage()}
-    return metadata, {"m": whit_m, "P": whit_p}
+    started = time.time()
+    mean, proj = W.pcawhitenlearn(values.astype(np.float64).T, shrink, device=device)
+    return _metadata("whitening_learn", started), {"m": mean, "P": proj}
 
 
 def paste_pca_normalize(params, data, device="cuda"):
@@ -104,16 +107,13 @@ def paste_pca_normalize(params, data, device="cuda"):
     assert len(set(len(x) for x in data)) == 1
     if data[0].shape == (0,):
         return {}, data[0]
-    value = np.concatenate(data, axis=1)
+    pasted = np.concatenate(data, axis=1)
+    metadata = {}
     if dimensions:
-        time0 = time.time()
-        value = value - np.mean(value)
-        eigval, eigvec = np.linalg.eig(W.gram(value.T, device).astype(value.dtype))     # value.T @ value, [D,D]
-        vecs = eigvec[:, np.argsort(eigval)[-dimensions:]]
-        value = value.dot(vecs.dot(vecs.T))
-        timing = time.time() - time0
-        metadata = {"timings": {"pca_compute": round(timing, 2)}, "resource_usage": resource_usage()}
-    else:
-        metadata = {}
-    value = value / np.expand_dims(np.linalg.norm(value, axis=1), axis=1)
-    return metadata, value
+        started = time.time()
+        pasted = pasted - np.mean(pasted)
+        eigval, eigvec = np.linalg.eig(W.gram(pasted.T, device).astype(pasted.dtype))     # pasted.T @ pasted, [D,D]
+        top = eigvec[:, np.argsort(eigval)[-dimensions:]]
+        pasted = pasted.dot(top.dot(top.T))
+        metadata = _metadata("pca_compute", started)
+    return metadata, pasted / np.linalg.norm(pasted, axis=1, keepdims=True)

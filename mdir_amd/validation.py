@@ -14,72 +14,71 @@ def get_dataset_params(params, net_defaults):
 
 
 class NoValidation:
+    """``validation: false`` (or a disabled entry of a multi-criterial tree)."""
     decisive_criterion = ""
-
-    def validations(self, _epoch):
-        return []
-
-    def should_validate(self, _epoch):
-        return False
+    validations = staticmethod(lambda _epoch: [])
+    should_validate = staticmethod(lambda _epoch: False)
 
 
 class SingleValidation:
+    """One score on one test set.  ``frequency`` only matters during training (every k-th epoch);
+    ``epoch=None`` -- the stand-alone ``validate`` stage -- always runs."""
+
+    decisive_criterion = "val/learning/score:total"
+
     def __init__(self, data_loader, criterion, network_overlay, frequency):
         assert data_loader is None, "only score validations (data: null) are on the MI355X path"
-        self.data_loader = None
-        self.criterion = criterion
-        self.network_overlay = network_overlay
-        self.frequency = frequency
-        self.decisive_criterion = "val/learning/score:total"
+        self.data_loader, self.criterion = None, criterion
+        self.network_overlay, self.frequency = network_overlay, frequency
 
     @classmethod
     def initialize(cls, params_validation, data, params_data, default_criterion, net_defaults):
-        data_key = params_validation.pop("data")
-        if data_key is not None:
+        section = {key: params_validation.pop(key) for key in ("data", "criterion", "network_overlay", "frequency")}
+        assert not params_validation, params_validation.keys()
+        if section["data"] is not None:
             raise NotImplementedError("validation over a data loader is training-side and out of scope")
-        criterion_section = params_validation.pop("criterion")
-        if criterion_section == "default":
-            if default_criterion is None:
-                raise ValueError("Criterion cannot be 'default' when default criterion is not specified")
+        if section["criterion"] != "default":
+            criterion = initialize_score(get_dataset_params(section["criterion"], net_defaults))
+        elif default_criterion is not None:
             criterion = default_criterion
         else:
-            criterion = initialize_score(get_dataset_params(criterion_section, net_defaults))
-        network_overlay = params_validation.pop("network_overlay")
-        frequency = params_validation.pop("frequency")
-        assert not params_validation, params_validation.keys()
-        return cls(None, criterion, network_overlay, frequency)
+            raise ValueError("Criterion cannot be 'default' when default criterion is not specified")
+        return cls(None, criterion, section["network_overlay"], section["frequency"])
+
+    def should_validate(self, epoch):
+        if epoch is None:
+            return True
+        return bool(self.frequency) and (epoch + 1) % self.frequency == 0
 
     def validations(self, epoch):
         return [("val", self)] if self.should_validate(epoch) else []
 
-    def should_validate(self, epoch):
-        return epoch is None or (self.frequency and (epoch + 1) % self.frequency == 0)
-
     def validate(self, network, device, logger):
-        network = network.overlay_params(copy.deepcopy(self.network_overlay), device)
-        network.eval()
-        return self.criterion(network, device, logger)
+        evaluated = network.overlay_params(copy.deepcopy(self.network_overlay), device)
+        evaluated.eval()
+        return self.criterion(evaluated, device, logger)
 
 
 class MultiCriterialValidation:
+    """Named sub-validations; ``validations(epoch)`` yields the ones that are due."""
+
     def __init__(self, decisive_criterion, validations):
-        self.decisive_criterion = decisive_criterion
-        self.vals = validations
+        self.decisive_criterion, self.vals = decisive_criterion, validations
 
     @classmethod
     def initialize(cls, params_validation, **kwargs):
-        decisive_criterion = params_validation.pop("decisive_criterion")
-        return cls(decisive_criterion, {key: initialize_validation(scenario, **kwargs)
-                                        for key, scenario in params_validation.items()})
+        decisive = params_validation.pop("decisive_criterion")
+        children = {name: initialize_validation(sub, **kwargs) for name, sub in params_validation.items()}
+        return cls(decisive, children)
 
     def validations(self, epoch):
-        return [(key, val) for key, val in self.vals.items() if val.should_validate(epoch)]
+        return [(name, child) for name, child in self.vals.items() if child.should_validate(epoch)]
 
 
 VALIDATIONS = {"SingleValidation": SingleValidation, "MultiCriterialValidation": MultiCriterialValidation}
 
 
 def initialize_validation(params, **kwargs):
-    if isinstance(params, bool) and not params:
+    if params is False:
         return NoValidation()
     return VALIDATIONS[params.pop("type")].initialize(params, **kwargs)

@@ -32,25 +32,23 @@ class Compose(object):
         self.device = device
 
     def __call__(self, tensor, inference, model=None):
-        if not self.wrappers:
-            return inference(tensor.to(self.device))
-        if model is None:
-            model = inference
-        metadata = []
-        for wrapper in self.wrappers:
-            tensor, meta = wrapper.preprocess(tensor, model)
-            metadata.append(meta)
-        if isinstance(tensor, list):
-            tensor = [inference(x.to(self.device)) for x in tensor]
-        else:
-            tensor = inference(tensor.to(self.device))
-        for wrapper, meta in reversed(list(zip(self.wrappers, metadata))):
-            tensor = wrapper.postprocess(tensor, model, meta)
-        return tensor
+        """Pre-process in list order, run ``inference`` on the tensor (or on every tensor of a list),
+        post-process in REVERSE order (wrapper.py:17-37)."""
+        model = inference if model is None else model
+        run = lambda x: inference(x.to(self.device))
+        pending = []                                   # (wrapper, its metadata) in application order
+        for step in self.wrappers:
+            tensor, meta = step.preprocess(tensor, model)
+            pending.append((step, meta))
+        out = [run(x) for x in tensor] if isinstance(tensor, list) else run(tensor)
+        while pending:
+            step, meta = pending.pop()
+            out = step.postprocess(out, model, meta)
+        return out
 
     def __repr__(self):
-        nice = "\n" + "".join("    %s\n" % x for x in self.wrappers) if self.wrappers else ""
-        return "%s([%s])" % (self.__class__.__name__, nice)
+        body = "".join("\n    %s" % w for w in self.wrappers)
+        return "%s([%s])" % (type(self).__name__, body + "\n" if body else "")
 
 
 class Wrapper(object):
@@ -146,16 +144,20 @@ WRAPPERS_LABELS = {
 }
 
 
+def _from_string(spec, device):
+    """``"name[:arg],name2[:arg]"`` -> wrapper objects; the argument arrives as a string."""
+    out = []
+    for piece in filter(None, spec.split(",")):
+        name, colon, arg = piece.partition(":")
+        out.append(WRAPPERS_LABELS[name](*([arg] if colon else []), device=device))
+    return out
+
+
 def initialize_wrappers(net_wrappers, device):
-    """``None`` | ``"name:arg,arg,name2"`` | ``{"<order>_<name>": kwargs}`` (sorted by key)."""
-    if net_wrappers is None:
-        wraps = []
-    elif isinstance(net_wrappers, str):
-        wraps = []
-        for wrap in [x for x in net_wrappers.split(",") if x]:
-            wname, *args = wrap.split(":", 1)
-            args = args[0].split(",") if args else []
-            wraps.append(WRAPPERS_LABELS[wname](*args, device=device))
-    else:
-        wraps = [WRAPPERS_LABELS[x.split("_", 1)[1]](**net_wrappers[x], device=device) for x in sorted(net_wrappers)]
-    return Compose(wraps, device)
+    """``None`` | ``"name:arg,name2"`` | ``{"<order>_<name>": kwargs}`` (applied in sorted key order)."""
+    if not net_wrappers:
+        return Compose([], device)
+    if isinstance(net_wrappers, str):
+        return Compose(_from_string(net_wrappers, device), device)
+    ordered = sorted(net_wrappers)
+    return Compose([WRAPPERS_LABELS[key.split("_", 1)[1]](device=device, **net_wrappers[key]) for key in ordered], device)
