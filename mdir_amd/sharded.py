@@ -278,6 +278,10 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
     from the sort-free position counts.  Returns the same ``(averages, per_query)`` on every rank."""
     from .evaluate import _evaluate, map_from_positions
     import numpy as np
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if len(images) < world:
+        raise ValueError("%d database images cannot be sharded over %d ranks (every rank needs at least one)"
+                         % (len(images), world))
     vecs, _ = extract_shard(net, images, image_size, transform, device, group, **kwargs)
     if images == qimages and set(bbxs) == {None}:
         qlocal = vecs            # the query set IS the database (cirscore.py:56-57): slices coincide
