@@ -19,6 +19,36 @@ def graphs_enabled(device):
     return torch.device(device).type == "cuda" and os.environ.get("MDIR_AMD_GRAPHS", "1") != "0"
 
 
+_side_streams = {}
+
+
+def parallel_map(fn, items):
+    """``[fn(x) for x in items]`` with every item after the first on its own HIP stream, joined
+    before returning.  The scales of the image pyramid are independent, and the trunk kernels of the
+    smaller ones (a quarter / half of the pixels) leave most CUs idle; as parallel branches of the
+    captured graph they fill each other's gaps.  Eager launches are host-bound and gain nothing, so
+    this matters inside ``ShapeGraphs`` captures (where the forked streams become graph branches)."""
+    if len(items) < 2 or not isinstance(items[0], torch.Tensor) or not items[0].is_cuda \
+            or os.environ.get("MDIR_AMD_SCALE_STREAMS", "1") == "0":
+        return [fn(x) for x in items]
+    dev = items[0].device
+    cur = torch.cuda.current_stream(dev)
+    side = _side_streams.setdefault(dev.index, [])
+    while len(side) < len(items) - 1:
+        side.append(torch.cuda.Stream(device=dev))
+    outs = [None] * len(items)
+    for i in range(1, len(items)):
+        side[i - 1].wait_stream(cur)                  # inputs were produced on the current stream
+        with torch.cuda.stream(side[i - 1]):
+            outs[i] = fn(items[i])
+    outs[0] = fn(items[0])
+    for i in range(1, len(items)):
+        cur.wait_stream(side[i - 1])
+        if isinstance(outs[i], torch.Tensor):
+            outs[i].record_stream(cur)                # allocated on the side stream, consumed on this one
+    return outs
+
+
 class _Entry:
     __slots__ = ("graph", "static_in", "static_out")
 

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from . import ops
 from .backbones import OUTPUT_DIM, TrunkSequential, build_features
 from .datasets import ImagesFromList, ToUint8HWC, get_data_root
-from .graphs import ShapeGraphs, graphs_enabled
+from .graphs import ShapeGraphs, graphs_enabled, parallel_map
 from .layers import POOLING, L2N, pool_kind
 
 
@@ -150,13 +150,9 @@ def extract_ss(net, input):
 
 def extract_ms(net, input, ms, msp):
     """One image, several scales -> device vector ``[D]`` (imageretrievalnet.py:309-324)."""
-    per_scale = []
-    for s in ms:
-        if s == 1:
-            input_t = input
-        else:
-            input_t = F.interpolate(input, scale_factor=s, mode="bilinear", align_corners=False)
-        per_scale.append(net(input_t).reshape(-1).contiguous())
+    pyramid = [input if s == 1 else F.interpolate(input, scale_factor=s, mode="bilinear", align_corners=False)
+               for s in ms]
+    per_scale = parallel_map(lambda x: net(x).reshape(-1).contiguous(), pyramid)      # one stream per scale
     return ops.ms_aggregate(per_scale, msp)
 
 

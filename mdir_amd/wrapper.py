@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .graphs import parallel_map
 
 
 def load_path(path):
@@ -40,7 +41,7 @@ class Compose(object):
         for step in self.wrappers:
             tensor, meta = step.preprocess(tensor, model)
             pending.append((step, meta))
-        out = [run(x) for x in tensor] if isinstance(tensor, list) else run(tensor)
+        out = parallel_map(run, tensor) if isinstance(tensor, list) else run(tensor)
         while pending:
             step, meta = pending.pop()
             out = step.postprocess(out, model, meta)
