@@ -143,17 +143,30 @@ def _out_dim(net):
     return net.meta["out_channels"] if "out_channels" in net.meta else net.meta["outputdim"]
 
 
+def _rows(net, x):
+    """``net(x)`` as one descriptor row per image of the batch: ``[B, D]``.  Networks answer ``[D,B]``
+    (ImageRetrievalNet) or, for a wrapped mdir network, ``[D]`` / ``[B,D]``."""
+    out = net(x)
+    if out.dim() == 1:
+        return out.reshape(1, -1)
+    if x.shape[0] > 1:
+        return out.t() if isinstance(net, nn.Module) else out        # raw model: [D,B]; wrapped network: rows
+    return out.reshape(1, -1)
+
+
 def extract_ss(net, input):
-    """One image, one scale -> device vector ``[D]`` (no host copy)."""
-    return net(input).reshape(-1)
+    """One scale -> device vector ``[D]`` (or ``[B,D]`` for a batch of equal-sized images; no host copy)."""
+    rows = _rows(net, input)
+    return rows if input.shape[0] > 1 else rows.reshape(-1)
 
 
 def extract_ms(net, input, ms, msp):
     """One image, several scales -> device vector ``[D]`` (imageretrievalnet.py:309-324)."""
     pyramid = [input if s == 1 else F.interpolate(input, scale_factor=s, mode="bilinear", align_corners=False)
                for s in ms]
-    per_scale = parallel_map(lambda x: net(x).reshape(-1).contiguous(), pyramid)      # one stream per scale
-    return ops.ms_aggregate(per_scale, msp)
+    per_scale = parallel_map(lambda x: _rows(net, x).contiguous(), pyramid)           # one stream per scale
+    agg = [ops.ms_aggregate([rows[b] for rows in per_scale], msp) for b in range(input.shape[0])]
+    return torch.stack(agg) if input.shape[0] > 1 else agg[0]
 
 
 def _gpu_preprocess(device):
@@ -204,20 +217,43 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     loader = torch.utils.data.DataLoader(
         ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),
         batch_size=1, shuffle=False, sampler=order, num_workers=num_workers, pin_memory=True)
+    # consecutive equal-sized images go through the trunk as one batch (only under graph replay,
+    # where equal sizes have been made consecutive): larger GEMMs, fewer launches per image
+    bmax = max(1, int(os.environ.get("MDIR_AMD_BATCH", "4"))) if graphs_enabled(device) else 1
+    state = {"vecs": None}
+
+    def store(i, v):
+        if state["vecs"] is None:
+            # width from the first descriptor: a dimension-reducing whitening wrapper
+            # (cirwhiten dimensions=d) yields d < meta['out_channels'], which the
+            # reference's fixed-size buffer (imageretrievalnet.py:291) cannot hold
+            state["vecs"] = torch.empty(len(images), v.numel(), dtype=torch.float32, device=device)
+        state["vecs"][i].copy_(v.reshape(-1), non_blocking=True)      # row = position in the caller's list
+
+    def flush(buf):
+        if len(buf) == bmax and bmax > 1:
+            rows = describe(torch.cat([t for _, t in buf], dim=0))
+            for (i, _), row in zip(buf, rows):
+                store(i, row)
+        else:
+            for i, t in buf:
+                store(i, describe(t))
+        buf.clear()
+
     with torch.no_grad():
-        vecs = None
+        buf = []
         for done, (i, input) in enumerate(zip(order, loader)):
             input = input.to(device, non_blocking=True)
-            v = describe(input)
-            if vecs is None:
-                # width from the first descriptor: a dimension-reducing whitening wrapper
-                # (cirwhiten dimensions=d) yields d < meta['out_channels'], which the
-                # reference's fixed-size buffer (imageretrievalnet.py:291) cannot hold
-                vecs = torch.empty(len(images), v.numel(), dtype=torch.float32, device=device)
-            vecs[i].copy_(v.reshape(-1), non_blocking=True)      # row = position in the caller's list
+            if buf and buf[0][1].shape != input.shape:
+                flush(buf)
+            buf.append((i, input))
+            if len(buf) == bmax:
+                flush(buf)
             if (done + 1) % print_freq == 0 or (done + 1) == len(images):
                 print("\r>>>> {}/{} done...".format(done + 1, len(images)), end="")
+        flush(buf)
         print("")
+    vecs = state["vecs"]
     return vecs
 
 

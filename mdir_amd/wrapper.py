@@ -36,7 +36,14 @@ class Compose(object):
         """Pre-process in list order, run ``inference`` on the tensor (or on every tensor of a list),
         post-process in REVERSE order (wrapper.py:17-37)."""
         model = inference if model is None else model
-        run = lambda x: inference(x.to(self.device))
+
+        def run(x):
+            out = inference(x.to(self.device))
+            # a batch of equal-sized images (the reference is batch-1 only): [D,B] -> one row per image
+            if x.dim() == 4 and x.shape[0] > 1 and isinstance(out, torch.Tensor) and out.dim() == 2:
+                out = out.t()
+            return out
+
         pending = []                                   # (wrapper, its metadata) in application order
         for step in self.wrappers:
             tensor, meta = step.preprocess(tensor, model)
@@ -92,6 +99,9 @@ class CirMultiscaleAggregation(Wrapper):
     @staticmethod
     def aggregate_tensor(tensor, nscales, outputdim, msp):
         assert len(tensor) == nscales, "%s != %s" % (len(tensor), nscales)
+        if tensor[0].dim() == 2 and tensor[0].shape[0] > 1 and tensor[0].shape[1] == outputdim:
+            rows = [t.contiguous() for t in tensor]            # batch: S x [B,D], aggregated image by image
+            return torch.stack([ops.ms_aggregate([t[b] for t in rows], msp) for b in range(rows[0].shape[0])])
         flat = [t.reshape(-1).contiguous() for t in tensor]
         assert all(t.numel() == outputdim for t in flat)
         return ops.ms_aggregate(flat, msp)
@@ -133,6 +143,8 @@ class CirtorchWhiten(Wrapper):
     def postprocess(self, tensor, model, _meta):
         if isinstance(tensor, list):
             return [self.postprocess(t, model, _meta) for t in tensor]
+        if tensor.dim() == 2 and tensor.shape[0] > 1 and tensor.shape[1] == self.P.shape[1]:
+            return self.whiten_rows(tensor)                     # batch: one row per image
         return self.whiten_rows(tensor.reshape(1, -1)).reshape(-1)
 
     def __repr__(self):

@@ -321,8 +321,8 @@ def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
     from mdir_amd.networks import extract_vectors_device, init_network
     rng = np.random.default_rng(3)
     paths = []
-    for i in range(9):
-        size = (160, 120) if i % 3 else (120, 160)
+    for i in range(16):
+        size = (160, 120) if i % 5 else (120, 160)
         p = str(tmp_path / ("im%d.png" % i))
         Image.fromarray(rng.integers(0, 255, (size[1], size[0], 3), dtype=np.uint8)).save(p)
         paths.append(p)
@@ -339,13 +339,18 @@ def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
     monkeypatch.setattr(ShapeGraphs, "__init__", spy)
     monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
     from mdir_amd.networks import _same_shape_order
-    assert _same_shape_order(paths, None) == [0, 3, 6, 1, 2, 4, 5, 7, 8]       # equal sizes made consecutive
+    assert _same_shape_order(paths, None) == [0, 5, 10, 15, 1, 2, 3, 4, 6, 7, 8, 9, 11, 12, 13, 14]      # equal sizes consecutive
     graphed = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
-    assert len(made) == 1 and made[0].replays == 9 - 2 * 2 and len(made[0].graphs) == 2 and not made[0].refused
+    # 4 images of one size = one batch of 4 (eager); 12 of the other = three batches (eager, eager, replay)
+    assert len(made) == 1 and made[0].replays == 1 and len(made[0].graphs) == 1 and not made[0].refused
+    monkeypatch.setenv("MDIR_AMD_BATCH", "1")
+    single = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
+    assert len(made) == 2 and made[1].replays == 16 - 2 * 2 and len(made[1].graphs) == 2 and not made[1].refused
+    np.testing.assert_allclose(graphed.cpu().numpy(), single.cpu().numpy(), rtol=0, atol=2e-6)
     monkeypatch.setenv("MDIR_AMD_GRAPHS", "0")
     eager = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
-    assert len(made) == 1
-    np.testing.assert_allclose(graphed.cpu().numpy(), eager.cpu().numpy(), rtol=0, atol=1e-6)
+    assert len(made) == 2
+    np.testing.assert_allclose(graphed.cpu().numpy(), eager.cpu().numpy(), rtol=0, atol=2e-6)
     # GPU-side `pil2np | totensor | normalize` (uint8 through the loader) == the host transform chain
     assert tr.device_tail() is not None
     monkeypatch.setenv("MDIR_AMD_GPU_PREPROCESS", "0")

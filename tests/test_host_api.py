@@ -723,3 +723,30 @@ def test_device_tail_detection_and_shape_order(tmp_path):
     assert sorted(order) == list(range(6)) and order[:1] == [5]          # unreadable header: own group, first
     assert order[1:] == [1, 4, 0, 2, 3]
     assert _same_shape_order(paths[:3], [(0, 0, 4, 4), None, (1, 1, 5, 5)]) == [0, 2, 1]      # crops group by box size
+
+
+def test_batches_of_equal_sized_images_equal_single_images(fops):
+    """Equal-sized images may go through the network as one batch (the reference is batch-1 only):
+    every row equals the single-image descriptor, on the cirtorch path and through the mdir wrapper
+    chain (multi-scale aggregation + whitening)."""
+    from mdir_amd.networks import extract_ms, extract_ss, init_network
+    from mdir_amd.wrapper import initialize_wrappers
+    torch.manual_seed(4)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False}).eval()
+    net.meta["in_channels"], net.meta["out_channels"] = 3, 256
+    x = torch.randn(3, 3, 160, 224)
+    ms = [1, 2 ** -0.5, 0.5]
+    rng = np.random.default_rng(0)
+    wh = {"P": rng.standard_normal((256, 256)), "m": rng.standard_normal((256, 1))}
+    chain = initialize_wrappers({"0_cirwhiten": {"whitening": wh, "dimensions": 64}, "1_cirmultiscale": {"scales": True}}, "cpu")
+    plain = initialize_wrappers(None, "cpu")
+    with torch.no_grad():
+        ss, msd, wrapped, raw = extract_ss(net, x), extract_ms(net, x, ms, 3.0), chain(x, net), plain(x, net)
+        assert ss.shape == (3, 256) and msd.shape == (3, 256) and wrapped.shape == (3, 64) and raw.shape == (3, 256)
+        for b in range(3):
+            one = x[b:b + 1]
+            np.testing.assert_allclose(ss[b].numpy(), extract_ss(net, one).numpy(), rtol=0, atol=1e-6)
+            np.testing.assert_allclose(msd[b].numpy(), extract_ms(net, one, ms, 3.0).numpy(), rtol=0, atol=1e-6)
+            np.testing.assert_allclose(wrapped[b].numpy(), chain(one, net).numpy(), rtol=0, atol=2e-6)
+            np.testing.assert_allclose(raw[b].numpy(), plain(one, net).reshape(-1).numpy(), rtol=0, atol=1e-6)
+        assert extract_ss(net, x[:1]).shape == (256,) and chain(x[:1], net).shape == (64,)      # batch 1: the reference's shapes

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--images", type=int, default=30)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="eager launches instead of one hipGraph replay per image")
+    ap.add_argument("--batch", type=int, default=4, help="equal-sized images per trunk pass (1 = the reference's batch size)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find mode)")
     print(json.dumps(measure(ap.parse_args())))
 
@@ -60,16 +61,26 @@ def measure(args):
     m32 = torch.tensor(wh["m"], dtype=torch.float32, device=dev)
 
     from mdir_amd.graphs import ShapeGraphs, graphs_enabled
-    describe = lambda x: chain(x, net).reshape(-1)
+    describe = lambda x: chain(x, net)
     if graphs_enabled(dev) and not getattr(args, "no_graphs", False):
         describe = ShapeGraphs(describe)       # as extract_vectors_device does
 
-    def run(n):
-        for i in range(n):
-            vecs[i % args.images].copy_(describe(imgs[i % 4]))
+    bmax = 1 if getattr(args, "no_graphs", False) else max(1, getattr(args, "batch", 4))
+
+    def run(n):                 # as extract_vectors_device: equal-sized images in batches of bmax
+        i = 0
+        while i < n:
+            if bmax > 1 and i + bmax <= n:
+                rows = describe(torch.cat([imgs[(i + j) % 4] for j in range(bmax)], dim=0))
+                for j in range(bmax):
+                    vecs[(i + j) % args.images].copy_(rows[j].reshape(-1))
+                i += bmax
+            else:
+                vecs[i % args.images].copy_(describe(imgs[i % 4]).reshape(-1))
+                i += 1
 
     with torch.no_grad():
-        run(3)
+        run(3 * bmax)           # eager warm-up of every (shape, batch) + the graph captures
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(args.images)
