@@ -59,7 +59,7 @@ class ShapeGraphs:
     def __init__(self, fn, warmup=2, max_graphs=None):
         self.fn = fn
         self.warmup = warmup
-        self.max_graphs = max_graphs or int(os.environ.get("MDIR_AMD_MAX_GRAPHS", "12"))
+        self.max_graphs = max_graphs or int(os.environ.get("MDIR_AMD_MAX_GRAPHS", "32"))
         self.graphs = collections.OrderedDict()
         self.seen = collections.Counter()
         self.refused = set()
