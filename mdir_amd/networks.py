@@ -193,6 +193,40 @@ def _same_shape_order(images, bbxs):
     return sorted(range(len(images)), key=lambda i: (keys[i], i))
 
 
+def batched_loop(loader, order, device, describe, store, missing=None, progress=None):
+    """Drive ``describe`` over a batch-size-1 loader: consecutive equal-sized images go through the
+    network as ONE batch of ``MDIR_AMD_BATCH`` (default 4; only under graph replay, where equal sizes
+    have been made consecutive) -- larger GEMMs, fewer launches per image; anything else one by one.
+    ``store(index, descriptor)`` receives every result, ``missing(index)`` every unreadable image
+    (a loader item that is ``{}``)."""
+    bmax = max(1, int(os.environ.get("MDIR_AMD_BATCH", "4"))) if graphs_enabled(device) else 1
+    buf = []
+
+    def flush():
+        if len(buf) == bmax and bmax > 1:
+            rows = describe(torch.cat([t for _, t in buf], dim=0))
+            for (i, _), row in zip(buf, rows):
+                store(i, row)
+        else:
+            for i, t in buf:
+                store(i, describe(t))
+        buf.clear()
+
+    for done, (i, item) in enumerate(zip(order, loader)):
+        if isinstance(item, dict) and item == {}:
+            missing(i)
+        else:
+            item = item.to(device, non_blocking=True)
+            if buf and buf[0][1].shape != item.shape:
+                flush()
+            buf.append((i, item))
+            if len(buf) == bmax:
+                flush()
+        if progress:
+            progress(done + 1)
+    flush()
+
+
 def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1], msp=1, print_freq=10,
                            device=None, num_workers=None):
     """Like :func:`extract_vectors` but the result stays on the GPU as ``[N,D]``
@@ -217,9 +251,6 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     loader = torch.utils.data.DataLoader(
         ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),
         batch_size=1, shuffle=False, sampler=order, num_workers=num_workers, pin_memory=True)
-    # consecutive equal-sized images go through the trunk as one batch (only under graph replay,
-    # where equal sizes have been made consecutive): larger GEMMs, fewer launches per image
-    bmax = max(1, int(os.environ.get("MDIR_AMD_BATCH", "4"))) if graphs_enabled(device) else 1
     state = {"vecs": None}
 
     def store(i, v):
@@ -230,28 +261,12 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
             state["vecs"] = torch.empty(len(images), v.numel(), dtype=torch.float32, device=device)
         state["vecs"][i].copy_(v.reshape(-1), non_blocking=True)      # row = position in the caller's list
 
-    def flush(buf):
-        if len(buf) == bmax and bmax > 1:
-            rows = describe(torch.cat([t for _, t in buf], dim=0))
-            for (i, _), row in zip(buf, rows):
-                store(i, row)
-        else:
-            for i, t in buf:
-                store(i, describe(t))
-        buf.clear()
+    def progress(done):
+        if done % print_freq == 0 or done == len(images):
+            print("\r>>>> {}/{} done...".format(done, len(images)), end="")
 
     with torch.no_grad():
-        buf = []
-        for done, (i, input) in enumerate(zip(order, loader)):
-            input = input.to(device, non_blocking=True)
-            if buf and buf[0][1].shape != input.shape:
-                flush(buf)
-            buf.append((i, input))
-            if len(buf) == bmax:
-                flush(buf)
-            if (done + 1) % print_freq == 0 or (done + 1) == len(images):
-                print("\r>>>> {}/{} done...".format(done + 1, len(images)), end="")
-        flush(buf)
+        batched_loop(loader, order, device, describe, store, progress=progress)
         print("")
     vecs = state["vecs"]
     return vecs

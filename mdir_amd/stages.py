@@ -113,7 +113,7 @@ def infer(params, data, device=None):
     from . import ops
     from .datasets import ToUint8HWC
     from .graphs import ShapeGraphs, graphs_enabled
-    from .networks import _gpu_preprocess, _same_shape_order
+    from .networks import _gpu_preprocess, _same_shape_order, batched_loop
     paths = [path_join(image_dir, x) for x in images]
     describe = network
     tail = transform.device_tail() if _gpu_preprocess(device) else None
@@ -129,11 +129,8 @@ def infer(params, data, device=None):
                                          collate_fn=_collate_one)
     t0 = time.time()
     with torch.no_grad():
-        for i, indata in zip(order, loader):
-            if isinstance(indata, dict) and indata == {}:
-                output.add(i, None, None)
-            else:
-                output.add(i, indata, describe(indata.to(device, non_blocking=True)))
+        batched_loop(loader, order, device, describe, store=lambda i, v: output.add(i, True, v),
+                     missing=lambda i: output.add(i, None, None))
     total = time.time() - t0
     metadata = {"stats": {"total_time": int(total), "avg_time": total / len(loader)}}
     return (metadata,) + output.postprocess()
