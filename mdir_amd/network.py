@@ -62,6 +62,8 @@ class SingleNetwork:
         extra = network_params.runtime.get("data", {}).keys() - {"mean_std", "transforms"}
         assert not extra, extra
 
+    supports_batches = True          # the wrapper chain answers one row per image for a batch (wrapper.Compose)
+
     def __call__(self, image):
         return self.wrappers[self.stage](image, self.model)
 

@@ -29,6 +29,8 @@ from .layers import POOLING, L2N, pool_kind
 
 
 class ImageRetrievalNet(nn.Module):
+    supports_batches = True          # forward answers [D,B]; extract_vectors may batch equal-sized images
+
     def __init__(self, features, lwhiten, pool, whiten, meta):
         super().__init__()
         self.features = TrunkSequential(*features)
@@ -193,13 +195,14 @@ def _same_shape_order(images, bbxs):
     return sorted(range(len(images)), key=lambda i: (keys[i], i))
 
 
-def batched_loop(loader, order, device, describe, store, missing=None, progress=None):
+def batched_loop(loader, order, device, describe, store, missing=None, progress=None, batches=True):
     """Drive ``describe`` over a batch-size-1 loader: consecutive equal-sized images go through the
     network as ONE batch of ``MDIR_AMD_BATCH`` (default 4; only under graph replay, where equal sizes
     have been made consecutive) -- larger GEMMs, fewer launches per image; anything else one by one.
     ``store(index, descriptor)`` receives every result, ``missing(index)`` every unreadable image
-    (a loader item that is ``{}``)."""
-    bmax = max(1, int(os.environ.get("MDIR_AMD_BATCH", "4"))) if graphs_enabled(device) else 1
+    (a loader item that is ``{}``).  ``batches=False`` for a network that only takes one image at a
+    time (the reference's protocol; this package's networks declare ``supports_batches``)."""
+    bmax = max(1, int(os.environ.get("MDIR_AMD_BATCH", "4"))) if batches and graphs_enabled(device) else 1
     buf = []
 
     def flush():
@@ -266,7 +269,8 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
             print("\r>>>> {}/{} done...".format(done, len(images)), end="")
 
     with torch.no_grad():
-        batched_loop(loader, order, device, describe, store, progress=progress)
+        batched_loop(loader, order, device, describe, store, progress=progress,
+                     batches=getattr(net, "supports_batches", False))
         print("")
     vecs = state["vecs"]
     return vecs

@@ -130,7 +130,7 @@ def infer(params, data, device=None):
     t0 = time.time()
     with torch.no_grad():
         batched_loop(loader, order, device, describe, store=lambda i, v: output.add(i, True, v),
-                     missing=lambda i: output.add(i, None, None))
+                     missing=lambda i: output.add(i, None, None), batches=getattr(network, "supports_batches", False))
     total = time.time() - t0
     metadata = {"stats": {"total_time": int(total), "avg_time": total / len(loader)}}
     return (metadata,) + output.postprocess()
