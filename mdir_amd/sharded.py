@@ -35,6 +35,10 @@ class HipBackend:
         from . import ops
         return ops.rank_full(scores, id_offset)
 
+    def topk(self, scores, k, id_offset=0):
+        from . import ops
+        return ops.topk(scores, k, id_offset)
+
     def gather_scores(self, scores, ids, offsets):
         from . import ops
         return ops.gather_scores(scores, ids, offsets)
@@ -193,6 +197,45 @@ class ShardedIndex:
         if qhi == qlo:
             return torch.empty((0, self.n_total), dtype=torch.int64, device=self.device), s_mine, (qlo, qhi)
         return self.backend.rank_full(s_mine, 0), s_mine, (qlo, qhi)
+
+    # ------------------------------------------------------------ global top-k
+    def topk_queries(self, queries, k, qlayout="DN"):
+        """Exact global top-k of every query on every rank: ``(ids int64 [Q,k'], scores [Q,k'])`` with
+        ``k' = min(k, N)``.  Each shard selects its own best ``min(k, n_local)`` rows (``mdx_topk``),
+        only those candidates travel (one all-gather of ``Q*k`` (id, score) pairs per rank instead of
+        the ``Q*n_local`` scores of the full ranking), and the ``G*k`` candidates are ranked again.
+        Candidates are laid out shard after shard and each shard's list is already in (score
+        descending, id ascending) order, so equal scores keep ascending global ids: the tie rule of
+        the full ranking."""
+        s_local = self.local_scores(queries, qlayout)
+        nq, n_local = s_local.shape
+        k_total = min(int(k), self.n_total)
+        k_local = min(int(k), n_local)
+        ids, vals = self.backend.topk(s_local, k_local, self.lo)
+        if self.world == 1:
+            return ids, vals
+        # shards differ by at most one row, but k may exceed a shard: pad to a common width
+        width = min(int(k), shard_bounds(self.n_total, self.world, 0)[1])
+        if k_local < width:
+            pad = width - k_local
+            ids = torch.cat([ids, torch.full((nq, pad), -1, dtype=ids.dtype, device=ids.device)], dim=1)
+            vals = torch.cat([vals, torch.full((nq, pad), float("nan"), dtype=vals.dtype, device=vals.device)], dim=1)
+        all_ids = self._all_gather(ids.contiguous())            # G x [Q, width]
+        all_vals = self._all_gather(vals.contiguous())
+        cand_ids = torch.cat(all_ids, dim=1)
+        cand_vals = torch.cat(all_vals, dim=1).contiguous()      # NaN padding ranks last
+        order = self.backend.rank_full(cand_vals, 0)[:, :k_total]
+        return torch.gather(cand_ids, 1, order), torch.gather(cand_vals, 1, order)
+
+    def _all_gather(self, t):
+        if self._host_staged:
+            h = t.cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(parts, h, group=self.group)
+            return [p.to(t.device) for p in parts]
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t, group=self.group)
+        return parts
 
     # -------------------------------------------------- positions w/o sorting
     def positions(self, s_local, id_lists):

@@ -36,6 +36,11 @@ class OracleBackend:
         from oracle import chain as OC
         return torch.from_numpy(OC.rank_full(scores.numpy()) + id_offset)
 
+    def topk(self, scores, k, id_offset=0):
+        from oracle import chain as OC
+        rk = OC.rank_full(scores.numpy())[:, :k]
+        return torch.from_numpy(rk + id_offset), torch.from_numpy(np.take_along_axis(scores.numpy(), rk, axis=1))
+
     def gather_scores(self, scores, ids, offsets):
         s, off = scores.numpy(), offsets.numpy()
         out = np.empty(len(ids), dtype=np.float32)
@@ -81,8 +86,10 @@ def _worker(rank, world, port, n, nq, d, out_dir, chunks):
     lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
     lists[0] = np.array([3, 7, n - 1])
     pos, off = sh.positions(sh.local_scores(torch.from_numpy(qvecs), "DN"), lists)
+    tk_ids, tk_vals = sh.topk_queries(torch.from_numpy(qvecs), 9, "DN")
+    big_ids, _ = sh.topk_queries(torch.from_numpy(qvecs), n + 5, "DN")          # k beyond every shard and beyond N
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), ranks=rk.numpy(), scores=sc.numpy(), q=np.array([qlo, qhi]),
-             pos=pos.numpy(), off=np.array(off))
+             pos=pos.numpy(), off=np.array(off), tk_ids=tk_ids.numpy(), tk_vals=tk_vals.numpy(), big_ids=big_ids.numpy())
     dist.destroy_process_group()
 
 
@@ -108,6 +115,10 @@ def test_sharded_equals_single_process(tmp_path, world, n, nq, chunks):
         np.testing.assert_array_equal(g["scores"], want_sc[qlo:qhi])
         np.testing.assert_array_equal(g["ranks"], want_rk[qlo:qhi])
         covered += qhi - qlo
+        # global top-k from per-shard candidates == prefix of the full ranking, on every rank (ties included)
+        np.testing.assert_array_equal(g["tk_ids"], want_rk[:, :9])
+        np.testing.assert_array_equal(g["tk_vals"], np.take_along_axis(want_sc, want_rk[:, :9], axis=1))
+        np.testing.assert_array_equal(g["big_ids"], want_rk)
         for q in range(nq):
             np.testing.assert_array_equal(g["pos"][g["off"][q]:g["off"][q + 1]], OC.rank_of(want_sc[q], lists[q]))
     assert covered == nq
