@@ -90,7 +90,10 @@ class ShapeGraphs:
         entry.static_in = x.clone()
         entry.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(entry.graph):
+            # thread_local: the loader's pin-memory thread and RCCL's watchdog thread keep making HIP
+            # calls (host allocations, event queries) while this thread captures; only calls made by
+            # the capturing thread itself may invalidate the capture
+            with torch.cuda.graph(entry.graph, capture_error_mode="thread_local"):
                 entry.static_out = self.fn(entry.static_in)
         except Exception as err:                     # keep extracting eagerly; never silently change results
             torch.cuda.synchronize()

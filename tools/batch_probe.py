@@ -31,3 +31,22 @@ with torch.no_grad():
             g(x)
         c.record(); torch.cuda.synchronize()
         print("%s batch %d: %.3f ms per image (replays %d)" % (arch, b, a.elapsed_time(c) / 10 / b, g.replays), flush=True)
+
+# two graph instances of the batch-4 function replayed alternately on two streams
+with torch.no_grad():
+    x = torch.randn(4, 3, 768, 1024, device=dev)
+    gs = [ShapeGraphs(trunk, warmup=1) for _ in range(2)]
+    for g in gs:
+        g(x); g(x); g(x)
+    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(20):
+        st[i % 2].wait_stream(torch.cuda.current_stream()) if i < 2 else None
+        with torch.cuda.stream(st[i % 2]):
+            gs[i % 2](x)
+    for s_ in st:
+        torch.cuda.current_stream().wait_stream(s_)
+    c.record(); torch.cuda.synchronize()
+    print("%s batch 4, two graphs in flight: %.3f ms per image" % (arch, a.elapsed_time(c) / 20 / 4), flush=True)
