@@ -275,26 +275,36 @@ def main():
             agree = float((rk_cpu[:100] == rk[:, :100].t().cpu().numpy()).mean())
             extra["cpu_top100_id_agreement"] = round(agree, 6)
             del vecs_host, rk_cpu
-        except MemoryError:
-            extra["cpu_baseline"] = None
+        except Exception as exc:          # the reported baseline must not cost the measured line
+            extra["cpu_baseline"] = {"value": None, "unit": "queries/s", "error": "%s: %s" % (type(exc).__name__, exc)}
 
     if args.extract_images > 0:
         # second half of BASELINE.json's metric: descriptors/sec (every rank extracts its own images)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import types
         from bench_extract import measure
-        with contextlib.redirect_stdout(sys.stderr):
-            ex = measure(types.SimpleNamespace(arch="resnet101", images=args.extract_images, channels_last=False,
-                                               miopen_find=False, batch=4))
-        per_gpu = torch.tensor([ex["value"]], dtype=torch.float64, device="cpu" if dryrun else device)
+        ex, err = None, None
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                ex = measure(types.SimpleNamespace(arch="resnet101", images=args.extract_images, channels_last=False,
+                                                   miopen_find=False, batch=4))
+        except Exception as exc:        # an untimed side leg must not cost the ranking result (or hang the other ranks)
+            err = "%s: %s" % (type(exc).__name__, exc)
+        agg = torch.tensor([ex["value"] if ex else 0.0, 1.0 if ex else 0.0], dtype=torch.float64,
+                           device="cpu" if dryrun else device)
         if world > 1:
-            dist.all_reduce(per_gpu, op=dist.ReduceOp.SUM)
-        extra["descriptors_per_s"] = {
-            "value": round(float(per_gpu.item()), 2), "unit": "descriptors/s", "n_gpus": world,
-            "config": "ResNet101-GeM random init, synthetic 1024x768 images resident on the GPU, 3 scales + learned "
-                      "whitening through the wrapper chain, fp32, equal-sized images in batches of 4; %d images per GPU" % args.extract_images,
-            "backbone_ms_per_image": ex["backbone_ms_per_image"], "tail_ms_per_image_mdx": ex["tail_ms_per_image_mdx"],
-            "tail_ms_per_image_torch_ops": ex["tail_ms_per_image_torch_ops"]}
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        if ex and int(agg[1].item()) == world:
+            extra["descriptors_per_s"] = {
+                "value": round(float(agg[0].item()), 2), "unit": "descriptors/s", "n_gpus": world,
+                "config": "ResNet101-GeM random init, synthetic 1024x768 images resident on the GPU, 3 scales + learned "
+                          "whitening through the wrapper chain, fp32, equal-sized images in batches of 4; %d images per GPU"
+                          % args.extract_images,
+                "backbone_ms_per_image": ex["backbone_ms_per_image"], "tail_ms_per_image_mdx": ex["tail_ms_per_image_mdx"],
+                "tail_ms_per_image_torch_ops": ex["tail_ms_per_image_torch_ops"]}
+        else:
+            extra["descriptors_per_s"] = {"value": None, "unit": "descriptors/s", "n_gpus": world,
+                                          "error": err or "the extraction leg failed on another rank"}
 
     if rank == 0:
         qps = NQ * args.steps / elapsed
