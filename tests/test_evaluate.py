@@ -63,3 +63,53 @@ def test_positions_route_equals_ranking_route():
     ref = O.compute_map(rk, gnd, [1, 5])
     for a, b in zip(want, ref):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def _brute_force_ap(ranking, ok, junk):
+    """AP exactly as the retrieval benchmarks define it: drop junk from the ranking, then the
+    trapezoidal area under precision/recall at every positive (evaluate.py:3-37 restated from the
+    definition, without the position bookkeeping of the reference)."""
+    ok, junk = set(int(x) for x in ok), set(int(x) for x in junk)
+    if not ok:
+        return float("nan")
+    cleaned = [int(r) for r in ranking if int(r) not in junk]
+    ap, hits = 0.0, 0
+    for j, r in enumerate(cleaned):
+        if r in ok:
+            prec_before = hits / j if j else 1.0
+            hits += 1
+            ap += (prec_before + hits / (j + 1)) / 2.0 / len(ok)
+    return ap
+
+
+def test_compute_map_property_random_rankings():
+    """hypothesis: shipped compute_map == oracle compute_map == the brute-force definition, on random
+    permutations with random positive / junk sets (incl. empty positives and junk overlapping nothing)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(2, 60), st.integers(1, 6), st.integers(0, 2 ** 31 - 1))
+    def check(n, nq, seed):
+        rng = np.random.default_rng(seed)
+        rk = np.stack([rng.permutation(n) for _ in range(nq)], axis=1)          # [N,Q] as the reference
+        gnd = []
+        for _ in range(nq):
+            ok = rng.choice(n, int(rng.integers(0, min(n, 6) + 1)), replace=False)
+            rest = np.setdiff1d(np.arange(n), ok)
+            junk = rng.choice(rest, int(rng.integers(0, min(len(rest), 5) + 1)), replace=False) if len(rest) else rest
+            gnd.append({"ok": ok, "junk": junk})
+        if all(len(g["ok"]) == 0 for g in gnd):
+            # no query with positives: the reference divides by nq - nempty = 0 (evaluate.py:108) and raises
+            import pytest
+            with pytest.raises(ZeroDivisionError):
+                E.compute_map(rk, gnd, [1, 5])
+            return
+        m, aps, pr, prs = E.compute_map(rk, gnd, [1, 5])
+        mo, apso, pro, prso = O.compute_map(rk, gnd, [1, 5])
+        np.testing.assert_array_equal(aps, apso)
+        np.testing.assert_array_equal(prs, prso)
+        assert (np.isnan(m) and np.isnan(mo)) or m == mo
+        want = np.array([_brute_force_ap(rk[:, q], gnd[q]["ok"], gnd[q]["junk"]) for q in range(nq)])
+        np.testing.assert_allclose(aps, want, rtol=0, atol=1e-12, equal_nan=True)
+
+    check()
