@@ -6,7 +6,8 @@ ResNet101 trunk at three scales is ~700-1100 kernel launches per image, each ~13
 dispatcher time, against 9-11 ms of GPU work.  The launch sequence of a given input shape never
 changes at inference, so it is captured once (after the eager warm-up runs that let MIOpen pick its
 algorithms) and replayed with one call.  One graph per input shape, least-recently-used eviction;
-shapes seen fewer than ``warmup`` + 1 times stay eager.
+the first ``warmup`` (default 1) occurrences of a shape run eagerly
+(MIOpen's algorithm search happens there), the next one is captured.
 """
 import collections
 import os
@@ -56,7 +57,7 @@ class _Entry:
 class ShapeGraphs:
     """``fn``: tensor -> tensor (or list/tuple of tensors) with no host synchronisation inside."""
 
-    def __init__(self, fn, warmup=2, max_graphs=None):
+    def __init__(self, fn, warmup=1, max_graphs=None):
         self.fn = fn
         self.warmup = warmup
         self.max_graphs = max_graphs or int(os.environ.get("MDIR_AMD_MAX_GRAPHS", "32"))

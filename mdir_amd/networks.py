@@ -249,7 +249,7 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
         describe = lambda u8: from_tensor(ops.u8_to_chw(u8, tail[0], tail[1]))
     order = list(range(len(images)))
     if graphs_enabled(device):
-        describe = ShapeGraphs(describe)      # per input shape: eager twice, then one hipGraph replay per image
+        describe = ShapeGraphs(describe)      # per input shape: eager once, then one hipGraph replay per call
         order = _same_shape_order(images, bbxs)
     loader = torch.utils.data.DataLoader(
         ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),

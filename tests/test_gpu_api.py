@@ -341,11 +341,11 @@ def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
     from mdir_amd.networks import _same_shape_order
     assert _same_shape_order(paths, None) == [0, 5, 10, 15, 1, 2, 3, 4, 6, 7, 8, 9, 11, 12, 13, 14]      # equal sizes consecutive
     graphed = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
-    # 4 images of one size = one batch of 4 (eager); 12 of the other = three batches (eager, eager, replay)
-    assert len(made) == 1 and made[0].replays == 1 and len(made[0].graphs) == 1 and not made[0].refused
+    # 4 images of one size = one batch of 4 (eager); 12 of the other = three batches (eager, replay, replay)
+    assert len(made) == 1 and made[0].replays == 2 and len(made[0].graphs) == 1 and not made[0].refused
     monkeypatch.setenv("MDIR_AMD_BATCH", "1")
     single = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
-    assert len(made) == 2 and made[1].replays == 16 - 2 * 2 and len(made[1].graphs) == 2 and not made[1].refused
+    assert len(made) == 2 and made[1].replays == 16 - 2 and len(made[1].graphs) == 2 and not made[1].refused
     np.testing.assert_allclose(graphed.cpu().numpy(), single.cpu().numpy(), rtol=0, atol=2e-6)
     monkeypatch.setenv("MDIR_AMD_GRAPHS", "0")
     eager = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
