@@ -198,6 +198,24 @@ class ShardedIndex:
             return torch.empty((0, self.n_total), dtype=torch.int64, device=self.device), s_mine, (qlo, qhi)
         return self.backend.rank_full(s_mine, 0), s_mine, (qlo, qhi)
 
+    # ------------------------------------------------- all-gather of partial scores
+    def all_scores(self, queries, qlayout="DN"):
+        """``[Q, N]`` similarities of ALL queries against ALL rows on every rank: the literal
+        "all-gather of per-shard partial scores" (G times the bytes of ``rank_queries``' all-to-all
+        per rank, and every rank then holds -- and would sort -- everything; use it when one rank
+        needs the whole score matrix)."""
+        s_local = self.local_scores(queries, qlayout)
+        if self.world == 1:
+            return s_local
+        nq = s_local.shape[0]
+        widths = [shard_bounds(self.n_total, self.world, r)[1] - shard_bounds(self.n_total, self.world, r)[0]
+                  for r in range(self.world)]
+        wmax = max(widths)
+        mine = s_local if s_local.shape[1] == wmax else torch.cat(
+            [s_local, s_local.new_zeros((nq, wmax - s_local.shape[1]))], dim=1)      # shards differ by <= 1 row
+        parts = self._all_gather(mine.contiguous())
+        return torch.cat([p[:, :w] for p, w in zip(parts, widths)], dim=1)
+
     # ------------------------------------------------------------ global top-k
     def topk_queries(self, queries, k, qlayout="DN"):
         """Exact global top-k of every query on every rank: ``(ids int64 [Q,k'], scores [Q,k'])`` with

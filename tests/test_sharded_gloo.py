@@ -86,6 +86,8 @@ def _worker(rank, world, port, n, nq, d, out_dir, chunks):
     lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
     lists[0] = np.array([3, 7, n - 1])
     pos, off = sh.positions(sh.local_scores(torch.from_numpy(qvecs), "DN"), lists)
+    assert np.array_equal(sh.all_scores(torch.from_numpy(qvecs), "DN").numpy(),
+                          __import__("oracle.chain", fromlist=["x"]).scores_chain(vecs, qvecs))      # all-gather form
     tk_ids, tk_vals = sh.topk_queries(torch.from_numpy(qvecs), 9, "DN")
     big_ids, _ = sh.topk_queries(torch.from_numpy(qvecs), n + 5, "DN")          # k beyond every shard and beyond N
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), ranks=rk.numpy(), scores=sc.numpy(), q=np.array([qlo, qhi]),
