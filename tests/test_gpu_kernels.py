@@ -328,9 +328,15 @@ def test_rank_full_degenerate_distributions(ops, kind):
 @pytest.mark.parametrize("n,nq,k,kind", [(200000, 5, 100, "gauss"), (70000, 3, 1, "gauss"), (65536, 4, 1000, "ties"),
                                          (100000, 2, 50, "allequal"), (300000, 3, 257, "concentrated"),
                                          (50000, 2, 10, "nan"), (20000, 6, 100, "gauss"), (1000, 3, 10, "gauss"),
-                                         (40000, 2, 5000, "gauss")])
+                                         (40000, 2, 5000, "gauss"), (300000, 4, 100, "clustered"),
+                                         (1004993, 3, 100, "gauss"), (400000, 2, 1000, "sortedrows"),
+                                         (262144, 3, 64, "mostlynan"), (300000, 3, 100, "adversarial")])
 def test_topk_radix_select(ops, n, nq, k, kind):
-    """mdx_topk (radix select for k << n, trimmed full sort otherwise) = first k of the oracle ranking."""
+    """mdx_topk (sampled threshold for k <<< n, radix select for k << n, trimmed full sort otherwise)
+    = first k of the oracle ranking.  "clustered" puts all the high scores into two tiles (per-tile
+    candidate slots overflow into the query's spill list); "adversarial" makes exactly the rows the
+    sampled path looks at score LOW, so that its threshold admits nearly every row and the exact
+    in-kernel fallback has to produce the answer; "mostlynan" leaves few finite scores."""
     rng = np.random.default_rng(n + k)
     sc = (rng.standard_normal((nq, n)) * 0.022).astype(np.float32)
     if kind == "ties":
@@ -341,6 +347,21 @@ def test_topk_radix_select(ops, n, nq, k, kind):
         sc = (0.3 + rng.standard_normal((nq, n)) * 1e-4).astype(np.float32)
     if kind == "nan":
         sc[:, ::3] = np.nan
+    if kind == "clustered":
+        sc[:, 1000:7000] += 1.0
+    if kind == "sortedrows":
+        sc = -np.sort(-sc, axis=1)                   # score descending with the row id
+    if kind == "adversarial":                        # the sample positions of tks_sample_kernel, restated
+        stride = n // 4096
+        j = np.arange(4096, dtype=np.uint64)
+        for q in range(nq):
+            jitter = (((j * 2654435761) & 0xFFFFFFFF) ^ ((q * 40503 + 0x9E3779B9) & 0xFFFFFFFF)) >> 9
+            rows = (j * stride + jitter % stride).astype(np.int64)
+            sc[q] += 1.0
+            sc[q, rows] -= 2.0
+    if kind == "mostlynan":
+        sc[:, 40:] = np.nan
+        sc[1, :] = np.nan
     want = OC.rank_full(sc)[:, :k]
     ids, vals = ops.topk(dev(sc), k, id_offset=7)
     np.testing.assert_array_equal(ids.cpu().numpy(), want + 7)
