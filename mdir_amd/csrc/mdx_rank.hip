@@ -1063,7 +1063,7 @@ int mdx_topk(const float *scores, int64_t n, int64_t nq, int64_t k, int64_t id_o
         return MDX_ERR_WORKSPACE;
     }
     // k <<< n (serving): sampled threshold, one pass over the scores
-    if (n >= 65536 && k <= 1024 && 256 * k <= n && sampled_workspace(n, nq) <= workspace_bytes && !getenv("MDX_NO_SAMPLED_TOPK"))
+    if (n >= 16384 && k <= 1024 && 256 * k <= n && sampled_workspace(n, nq) <= workspace_bytes && !getenv("MDX_NO_SAMPLED_TOPK"))
         return topk_sampled(scores, n, nq, k, id_offset, top_ids, top_scores, workspace, (hipStream_t)stream);
     // k << n: radix select + sort of the candidates; otherwise the full ranking, trimmed in its last pass
     if (4 * (k + SEL_CAP) <= n && carve_select(nullptr, nullptr, n, nq, k) <= workspace_bytes)

@@ -30,7 +30,7 @@ for it in range(iters):
     if not np.array_equal(got, want):
         bad += 1
         print("rank_full MISMATCH it=%d n=%d nq=%d kind=%d" % (it, n, nq, kind))
-    k = int(min(n, rng.integers(1, 300)))
+    k = int(min(n, rng.integers(1, 300))) if it % 2 else int(max(1, min(n, n // 256)))    # every other one: sampled-threshold regime
     ids, vals = ops.topk(sd, k)
     if not np.array_equal(ids.cpu().numpy(), want[:, :k]):
         bad += 1
