@@ -31,6 +31,23 @@ __device__ __forceinline__ uint32_t load_key(const float *scores, const uint32_t
     return first ? desc_key(scores[i]) : keys[i];
 }
 
+// ascending bitonic sort of buf[0..P) (P a power of two) by all threads of the workgroup
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *buf, int P, int tid, int nthreads)
+{
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += nthreads) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const uint64_t a = buf[i], b = buf[j];
+                if ((a > b) == ((i & size) == 0)) {
+                    buf[i] = b;
+                    buf[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+}
+
 // per-tile digit histogram -> block_hist[q][b][digit].  One workgroup takes HIST_TILES
 // consecutive tiles: all their loads are issued before the first LDS atomic, so that a
 // short-lived workgroup still keeps enough bytes in flight.
@@ -287,105 +304,87 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
 // ---------------------------------------------------------------------------
 // counting ranks of labelled items
 // ---------------------------------------------------------------------------
-// Every lane keeps its elements (16 per 4096-element tile) in registers and a private counter per
-// labelled item.  Ids only break ties, and all rows of a tile lie on one side of a labelled id unless
-// the tile contains it, so "precedes" is a plain 32-bit `key < thr` with a per-(tile, item)
-// threshold: rk for a tile after the item (ties follow it), rk + 1 for a tile before it (ties
-// precede it).  Written mask-free -- min(usub_sat(thr, key), 1) -- so that there is no VCC/SGPR
-// round trip: compares through VCC serialised the first versions of this kernel (0.5 ms at
-// 1 M x 70 x 20 items, twenty times the cost of its instruction count).  The tile holding the item
-// and NaN items (rk = all ones) take an exact 64-bit compare from the same registers.  Items are
-// taken 16 at a time; one atomic per item and workgroup at the end.
 constexpr int CNT_TILE = 4096;
 constexpr int CNT_ITEMS = CNT_TILE / 256;     // elements per lane and tile
-constexpr int CNT_REFS = 16;                  // labelled items per sweep over the scores
 
-__global__ __launch_bounds__(256) void rank_count_kernel(
+// Instead of comparing every row with every labelled item (rows x items compares; rOxford queries
+// list up to hundreds), the items of a query are SORTED (64-bit composite (key : id), the ranking
+// order) and every row binary-searches its place among them: u = number of
+// items that rank before-or-at the row.  A row precedes item j iff j >= u, so the per-item counts
+// are the prefix sums of the histogram of u -- log2(items) compares per row.  Rows behind all items
+// (the vast majority) touch nothing; the histogram lives in LDS, one atomic per item and workgroup
+// at the end.
+constexpr int CNTB_REFS = 256;
+
+__global__ __launch_bounds__(256) void rank_count_bsearch_kernel(
     const float *__restrict__ scores, int64_t n, int64_t id_offset,
     const float *__restrict__ ref_scores, const int64_t *__restrict__ ref_ids,
     const int64_t *__restrict__ offsets, unsigned long long *__restrict__ cnt, int nblk)
 {
-    __shared__ uint32_t srk[CNT_REFS], sri[CNT_REFS];
-    __shared__ uint32_t swave[4][CNT_REFS];
+    __shared__ uint64_t sref[CNTB_REFS];
+    __shared__ uint32_t hist[CNTB_REFS + 1];
+    __shared__ uint32_t wsum[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t q = blockIdx.y;
     const int64_t lo = offsets[q], hi = offsets[q + 1];
-    for (int64_t r0 = lo; r0 < hi; r0 += CNT_REFS) {
-        const int nref = (int)((hi - r0) < CNT_REFS ? (hi - r0) : CNT_REFS);
+    for (int64_t r0 = lo; r0 < hi; r0 += CNTB_REFS) {
+        const int nref = (int)((hi - r0) < CNTB_REFS ? (hi - r0) : CNTB_REFS);
+        int P = 2;
+        while (P < nref) P <<= 1;                                   // search width (power of two)
         __syncthreads();
-        if (tid < CNT_REFS) {
-            uint32_t rk = 0, ri = 0;                                // nothing precedes (0 : 0)
-            if (tid < nref) {
-                const int64_t id = ref_ids[r0 + tid];
-                ri = id < 0 ? 0u : (id > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)id);
-                rk = desc_key(ref_scores[r0 + tid]);
-            }
-            srk[tid] = rk;
-            sri[tid] = ri;
+        uint64_t mine = ~0ull;                                      // padding ranks after everything
+        if (tid < nref) {
+            const int64_t id = ref_ids[r0 + tid];
+            const uint32_t idc = id < 0 ? 0u : (id > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)id);
+            mine = ((uint64_t)desc_key(ref_scores[r0 + tid]) << 32) | idc;
         }
+        sref[tid] = mine;
+        hist[tid] = 0;
+        if (tid == 0) hist[CNTB_REFS] = 0;
         __syncthreads();
-        uint32_t c[CNT_REFS];
-#pragma unroll
-        for (int k = 0; k < CNT_REFS; ++k) c[k] = 0;
+        bitonic_sort_lds(sref, CNTB_REFS, tid, 256);
         for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
             const int64_t t0 = (int64_t)b * CNT_TILE;
-            uint32_t key[CNT_ITEMS];
+            uint64_t el[CNT_ITEMS];
 #pragma unroll
             for (int e = 0; e < CNT_ITEMS; ++e) {
                 const int64_t i = t0 + e * 256 + tid;
-                key[e] = i < n ? desc_key(scores[q * n + i]) : 0xFFFFFFFFu;      // padding precedes nothing
+                el[e] = i < n ? ((uint64_t)desc_key(scores[q * n + i]) << 32) | (uint32_t)(i + id_offset) : ~0ull;
             }
-            const uint64_t gid0 = (uint64_t)(t0 + id_offset);
-            uint32_t thr[CNT_REFS], exact = 0;
+            const uint64_t last = sref[nref - 1];                   // broadcast: rows behind every item are skipped
 #pragma unroll
-            for (int k = 0; k < CNT_REFS; ++k) {
-                const uint32_t rk = __builtin_amdgcn_readfirstlane(srk[k]), ri = __builtin_amdgcn_readfirstlane(sri[k]);
-                const bool before = gid0 + CNT_TILE <= (uint64_t)ri, after = gid0 > (uint64_t)ri;
-                const bool ex = k < nref && (!(before || after) || rk == 0xFFFFFFFFu);
-                exact |= ex ? 1u << k : 0u;
-                thr[k] = (ex || k >= nref) ? 0u : rk + (before ? 1u : 0u);       // thr 0 counts nothing
+            for (int e = 0; e < CNT_ITEMS; ++e) {
+                const bool live = el[e] < last;                     // else u = nref: precedes no item
+                if (__ballot(live) == 0) continue;                  // uniform: the common case for most tiles
+                // u = #{j : sref[j] <= el}: branch-free binary search over the P-padded array
+                uint32_t u = 0;
+                for (int step = P >> 1; step > 0; step >>= 1)
+                    u += (sref[u + step - 1] <= el[e]) ? (uint32_t)step : 0u;
+                if (live) atomicAdd(&hist[u], 1u);
             }
-#pragma unroll
-            for (int g = 0; g < CNT_REFS / 8; ++g)
-                if (g * 8 < nref) {                                 // uniform: skip empty groups of 8 items
-#pragma unroll
-                    for (int e = 0; e < CNT_ITEMS; ++e)
-#pragma unroll
-                        for (int k = g * 8; k < g * 8 + 8; ++k) {
-                            // min(usub_sat(thr, key), 1) = [key < thr]; as asm because the optimiser folds
-                            // the C form back into a compare + carry through VCC
-                            uint32_t d;
-                            asm("v_sub_u32_e64 %0, %1, %2 clamp\n\tv_min_u32_e32 %0, 1, %0" : "=v"(d) : "s"(thr[k]), "v"(key[e]));
-                            c[k] += d;
-                        }
-                }
-            if (exact) {                                            // uniform, rare
-#pragma unroll
-                for (int k = 0; k < CNT_REFS; ++k)
-                    if ((exact >> k) & 1u) {
-                        const uint64_t r = ((uint64_t)__builtin_amdgcn_readfirstlane(srk[k]) << 32) |
-                                           __builtin_amdgcn_readfirstlane(sri[k]);
-#pragma unroll
-                        for (int e = 0; e < CNT_ITEMS; ++e) {
-                            const uint64_t el = ((uint64_t)key[e] << 32) | ((uint32_t)gid0 + (uint32_t)(e * 256 + tid));
-                            c[k] += (t0 + e * 256 + tid) < n && el < r ? 1u : 0u;
-                        }
-                    }
-            }
-        }
-        // wave reduction, then ONE global atomic per item and workgroup (device-scope atomics on a
-        // shared address serialise across the XCDs)
-#pragma unroll
-        for (int k = 0; k < CNT_REFS; ++k) {
-            uint32_t v = c[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if (lane == 0) swave[tid >> 6][k] = v;
         }
         __syncthreads();
+        // inclusive prefix over u (thread = position in the sorted order)
+        uint32_t inc = hist[tid];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        for (int w = 0; w < (tid >> 6); ++w) inc += wsum[w];
+        __syncthreads();
+        hist[tid] = inc;                                            // rows preceding the item at sorted position tid
+        __syncthreads();
         if (tid < nref) {
-            const unsigned long long v = (unsigned long long)swave[0][tid] + swave[1][tid] + swave[2][tid] + swave[3][tid];
-            if (v) atomicAdd(&cnt[r0 + tid], v);
+            // my item's position among the sorted ones (items are distinct unless listed twice, and
+            // equal items have equal counts)
+            uint32_t pos = 0;
+            for (int step = CNTB_REFS >> 1; step > 0; step >>= 1)
+                pos += (sref[pos + step - 1] < mine) ? (uint32_t)step : 0u;
+            const uint32_t v = hist[pos];
+            if (v) atomicAdd(&cnt[r0 + tid], (unsigned long long)v);
         }
     }
 }
@@ -766,23 +765,6 @@ constexpr int TKS_CAP = 16384;
 
 __device__ __forceinline__ uint64_t tk_comp(float s, uint32_t i) { return ((uint64_t)desc_key(s) << 32) | i; }
 
-// ascending bitonic sort of buf[0..P) (P a power of two) by all threads of the workgroup
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t *buf, int P, int tid, int nthreads)
-{
-    for (int size = 2; size <= P; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (P >> 1); t += nthreads) {
-                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
-                const uint64_t a = buf[i], b = buf[j];
-                if ((a > b) == ((i & size) == 0)) {
-                    buf[i] = b;
-                    buf[j] = a;
-                }
-            }
-            __syncthreads();
-        }
-}
-
 // Bin of a 256-bin histogram that holds the `rem`-th element (1-based), by ONE wave: lane l owns
 // bins 4l..4l+3, a shuffle scan gives the cumulative counts; `rem` is reduced to the rank inside
 // that bin.  (A single thread walking the bins costs 256 dependent LDS reads per level.)
@@ -1097,7 +1079,7 @@ int mdx_rank_count(const float *scores, int64_t n, int64_t nq, int64_t id_offset
     int64_t gx = ceil_div((int64_t)2048, nq);
     gx = gx < 1 ? 1 : (gx > nblk ? nblk : gx);
     const dim3 grid((unsigned)gx, (unsigned)nq);
-    hipLaunchKernelGGL(rank_count_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, n,
+    hipLaunchKernelGGL(rank_count_bsearch_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, n,
                        id_offset, ref_scores, ref_ids, offsets, (unsigned long long *)cnt, (int)nblk);
     MDX_LAUNCH_CHECK();
     return MDX_OK;

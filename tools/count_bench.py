@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
 sc = torch.randn((nq, n), generator=g, device=dev) * 0.022
 rng = np.random.default_rng(1)
-for per in (20, 200):
+for per in (4, 12, 20, 200):
     lists = [rng.choice(4993, per, replace=False) for _ in range(nq)]
     pos, _, off = ops.rank_of(sc, lists)
     torch.cuda.synchronize()
