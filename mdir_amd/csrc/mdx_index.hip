@@ -104,14 +104,14 @@ constexpr int LC_KC = 2, LC_NSTAGE = 3;
 
 template <int QT, int R, typename MM>
 static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
-                            int KB, int nq_valid, hipStream_t s)
+                            int KB, int nq_valid, hipStream_t s, int passes = 1)
 {
     auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM>;   // 2 = non-temporal database stream
     constexpr int lds = LC_NSTAGE * (QT + 4 * R) * LC_KC * 1024;
     // > 64 KiB of dynamic LDS needs the opt-in; per device, so set on every launch (host-side, cheap)
     MDX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
                        (unsigned long long *)nullptr);
     return MDX_OK;
 }
@@ -119,13 +119,13 @@ static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_
 // mode bit0: R = 2 (else 1), bit1: fp16 shard
 template <int QT>
 static int launch_qt(int mode, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
-                     int KB, int nq_valid, hipStream_t s)
+                     int KB, int nq_valid, hipStream_t s, int passes = 1)
 {
     switch (mode) {
-        case 0: return launch_scores_lc<QT, 1, MmaF32>(db, q, out, n, RT, KB, nq_valid, s);
-        case 1: return launch_scores_lc<QT, 2, MmaF32>(db, q, out, n, RT, KB, nq_valid, s);
-        case 2: return launch_scores_lc<QT, 1, MmaF16>(db, q, out, n, RT, KB, nq_valid, s);
-        default: return launch_scores_lc<QT, 2, MmaF16>(db, q, out, n, RT, KB, nq_valid, s);
+        case 0: return launch_scores_lc<QT, 1, MmaF32>(db, q, out, n, RT, KB, nq_valid, s, passes);
+        case 1: return launch_scores_lc<QT, 2, MmaF32>(db, q, out, n, RT, KB, nq_valid, s, passes);
+        case 2: return launch_scores_lc<QT, 1, MmaF16>(db, q, out, n, RT, KB, nq_valid, s, passes);
+        default: return launch_scores_lc<QT, 2, MmaF16>(db, q, out, n, RT, KB, nq_valid, s, passes);
     }
 }
 
@@ -271,7 +271,19 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
     if (rc != MDX_OK) return rc;
 
     const bool small = ix->RT < 2048;                 // < 32 768 rows: 64-row workgroups
-    for (int64_t qt0 = 0; qt0 < QT_total; qt0 += MAX_QT) {
+    int64_t qt_begin = 0;
+    const int64_t full_passes = QT_total / MAX_QT;
+    if (full_passes > 1 && full_passes < 65536 && !getenv("MDX_NO_PASS_GRID")) {
+        // many queries: all full groups of MAX_QT query tiles in ONE launch (grid.y = group), so that a
+        // small database still fills the chip (20 000 rows are 313 workgroups per group)
+        const int mode = (small ? 0 : 1) | (ix->storage == MDX_F16 ? 2 : 0);
+        rc = launch_qt<MAX_QT>(mode, ix->tiles, qtiles, scores, ix->n, ix->RT, (int)ix->KB, MAX_QT * TILE_ROWS, s,
+                               (int)full_passes);
+        if (rc != MDX_OK) return rc;
+        MDX_LAUNCH_CHECK();
+        qt_begin = full_passes * MAX_QT;
+    }
+    for (int64_t qt0 = qt_begin; qt0 < QT_total; qt0 += MAX_QT) {
         const int qt = (int)((QT_total - qt0) < MAX_QT ? (QT_total - qt0) : MAX_QT);
         const int64_t q0 = qt0 * TILE_ROWS;
         const int nq_valid = (int)((nq - q0) < qt * TILE_ROWS ? (nq - q0) : qt * TILE_ROWS);

@@ -71,6 +71,10 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunks = KB / KC;
     const int64_t rt_wg = (int64_t)blockIdx.x * CW * R;            // first row tile of the workgroup
+    // blockIdx.y = query pass: several full groups of QT query tiles in one launch (many queries
+    // against a small database: one pass alone would not fill the chip)
+    qtiles += (int64_t)blockIdx.y * QT * KB * 64;
+    out += (int64_t)blockIdx.y * QT * TILE_ROWS * n;
 
     if (wave >= CW) {
         // ------------------------------------------------------------- loader

@@ -35,7 +35,9 @@ def _unit_rows(rng, n, d):
 @pytest.mark.parametrize("n,d,nq", [(4993, 2048, 70), (1000, 512, 1), (333, 100, 17), (16, 64, 16),
                                     (5000, 256, 130), (70, 2048, 70),
                                     (70000, 64, 1), (66001, 100, 17), (70001, 256, 130), (65600, 2048, 70),
-                                    (65537, 32, 128), (131072, 96, 33)])
+                                    (65537, 32, 128), (131072, 96, 33),
+                                    # > 256 queries: the full groups of 128 go out as ONE launch (grid.y = group)
+                                    (1125, 512, 1125), (3000, 128, 300), (40000, 64, 389), (2000, 256, 256)])
 def test_scores_bit_exact_vs_chain(ops, n, d, nq):
     rng = np.random.default_rng(n + d + nq)
     db, qv = _unit_rows(rng, n, d), _unit_rows(rng, nq, d)
