@@ -277,11 +277,23 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
         // many queries: all full groups of MAX_QT query tiles in ONE launch (grid.y = group), so that a
         // small database still fills the chip (20 000 rows are 313 workgroups per group)
         const int mode = (small ? 0 : 1) | (ix->storage == MDX_F16 ? 2 : 0);
-        rc = launch_qt<MAX_QT>(mode, ix->tiles, qtiles, scores, ix->n, ix->RT, (int)ix->KB, MAX_QT * TILE_ROWS, s,
-                               (int)full_passes);
+        rc = launch_qt<MAX_QT>(mode, ix->tiles, qtiles, scores, ix->n, ix->RT, (int)ix->KB,
+                               (int)(full_passes * MAX_QT * TILE_ROWS), s, (int)full_passes);     // nq_valid = queries of the launch
         if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK();
         qt_begin = full_passes * MAX_QT;
+    }
+    if (qt_begin == 0 && QT_total <= MAX_QT && QT_total > 1 && ix->storage == MDX_F32 && !getenv("MDX_NO_QUERY_SPLIT")) {
+        // few queries against a small shard (rOxford5k alone: 70 x 4 993): 64-row workgroups taking all
+        // query tiles are only RT/4 = 79 workgroups, each a 5-tile-long MFMA chain.  Give every workgroup
+        // ONE query tile instead (grid.y = tile): 5x the workgroups, a fifth of the chain each.
+        const int64_t blocks = ceil_div(ix->RT, (int64_t)4);
+        if (small && blocks * QT_total <= 1024) {
+            rc = launch_qt<1>(0, ix->tiles, qtiles, scores, ix->n, ix->RT, (int)ix->KB, (int)nq, s, (int)QT_total);
+            if (rc != MDX_OK) return rc;
+            MDX_LAUNCH_CHECK();
+            return MDX_OK;
+        }
     }
     for (int64_t qt0 = qt_begin; qt0 < QT_total; qt0 += MAX_QT) {
         const int qt = (int)((QT_total - qt0) < MAX_QT ? (QT_total - qt0) : MAX_QT);

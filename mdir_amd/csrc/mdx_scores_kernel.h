@@ -184,7 +184,10 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
     __builtin_amdgcn_s_barrier();
     const int64_t row0 = rt_wg * TILE_ROWS;
     const int rows_valid = (int)((n - row0) < ROWS ? (n - row0) : ROWS);
-    for (int e = tid; e < nq_valid * ROWS; e += CW * 64) {
+    // queries of this group that exist (the last group of a launch may be partial)
+    const int nq_here = (nq_valid - (int)blockIdx.y * QT * TILE_ROWS) < QT * TILE_ROWS ? (nq_valid - (int)blockIdx.y * QT * TILE_ROWS)
+                                                                                   : QT * TILE_ROWS;
+    for (int e = tid; e < nq_here * ROWS; e += CW * 64) {
         const int qi = e / ROWS, rr = e % ROWS;
         if (rr < rows_valid) out[(int64_t)qi * n + row0 + rr] = stage[qi * LDW + rr];
     }
