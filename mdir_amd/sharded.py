@@ -20,6 +20,8 @@ The compute backend is injected so the exchange logic is testable on CPU: the
 product default is the HIP library (``HipBackend``) and raises without a GPU;
 tests pass an oracle-backed object explicitly.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -106,6 +108,7 @@ class ShardedIndex:
         # RCCL moves device buffers directly; under gloo (CPU tests, or several ranks
         # sharing one GPU for a dry run) collectives are staged through host memory.
         self._host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
+        self._a2a_broken = os.environ.get("MDIR_AMD_EXCHANGE") == "allgather"
 
     def _all_reduce_sum(self, t):
         if self._host_staged:
@@ -145,14 +148,33 @@ class ShardedIndex:
         if self._host_staged:
             send, host_recv = s_part.reshape(-1).cpu(), torch.empty(recv.shape, dtype=recv.dtype)
             work = dist.all_to_all_single(host_recv, send, out_split, in_split, group=self.group, async_op=True)
-        else:
-            send, host_recv = s_part.reshape(-1), None
-            work = dist.all_to_all_single(recv, send, out_split, in_split, group=self.group, async_op=True)
-        return work, recv, host_recv, send
+            return work, recv, host_recv, send
+        send = s_part.reshape(-1)
+        if not self._a2a_broken:
+            try:
+                work = dist.all_to_all_single(recv, send, out_split, in_split, group=self.group, async_op=True)
+                return work, recv, None, send
+            except (RuntimeError, NotImplementedError) as err:
+                # a backend without uneven all-to-all: every rank all-gathers the (padded) blocks and
+                # keeps its own queries -- G times the bytes, same result
+                import warnings
+                warnings.warn("all_to_all_single refused (%s); falling back to all_gather" % err)
+                self._a2a_broken = True
+        wmax = max(widths)
+        block = s_part if s_part.shape[1] == wmax else torch.cat(
+            [s_part, s_part.new_zeros((nq, wmax - s_part.shape[1]))], dim=1)
+        parts = [torch.empty_like(block) for _ in range(self.world)]
+        dist.all_gather(parts, block.contiguous(), group=self.group)
+        o = 0
+        for part, w in zip(parts, widths):
+            recv[o:o + (qhi - qlo) * w].copy_(part[qlo:qhi, :w].reshape(-1))
+            o += (qhi - qlo) * w
+        return None, recv, None, send
 
     def _finish_exchange(self, pending, widths, nq_mine):
         work, recv, host_recv, _send = pending
-        work.wait()                                   # compute stream waits for the collective
+        if work is not None:
+            work.wait()                               # compute stream waits for the collective
         if host_recv is not None:
             recv.copy_(host_recv)
         blocks, o = [], 0

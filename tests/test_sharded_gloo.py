@@ -66,12 +66,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, nq, d, out_dir, chunks):
+def _worker(rank, world, port, n, nq, d, out_dir, chunks, exchange=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if chunks:
         os.environ["MDIR_AMD_EXCHANGE_CHUNKS"] = str(chunks)
+    if exchange:
+        os.environ["MDIR_AMD_EXCHANGE"] = exchange
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mdir_amd.sharded import ShardedIndex, shard_bounds
     from oracle import oracle as O
@@ -95,14 +97,16 @@ def _worker(rank, world, port, n, nq, d, out_dir, chunks):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,nq,chunks", [(2, 301, 7, 0), (3, 100, 2, 0), (2, 301, 7, 3), (3, 101, 5, 2)])
-def test_sharded_equals_single_process(tmp_path, world, n, nq, chunks):
+@pytest.mark.parametrize("world,n,nq,chunks,exchange", [(2, 301, 7, 0, None), (3, 100, 2, 0, None), (2, 301, 7, 3, None),
+                                                        (3, 101, 5, 2, None), (3, 101, 5, 2, "allgather")])
+def test_sharded_equals_single_process(tmp_path, world, n, nq, chunks, exchange):
     """chunks > 0: every shard is cut into row chunks whose all-to-alls are in flight together
-    (the overlap pipeline used for big shards)."""
+    (the overlap pipeline used for big shards); exchange="allgather": the fallback taken when the
+    backend refuses an uneven all-to-all."""
     from oracle import chain as OC
     from oracle import oracle as O
     d = 32
-    mp.spawn(_worker, args=(world, _free_port(), n, nq, d, str(tmp_path), chunks), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, nq, d, str(tmp_path), chunks, exchange), nprocs=world, join=True)
     vecs, qvecs, _ = O.synth_ranking_problem(n, nq, d, seed=4)
     vecs[:, 7] = vecs[:, 3]; vecs[:, n - 1] = vecs[:, 3]
     want_sc = OC.scores_chain(vecs, qvecs)
