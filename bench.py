@@ -154,6 +154,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+        # communicator set-up (lazy peer connections of the first all-to-all) is not a step; a backend that
+        # refuses all-to-all is answered with the all-gather form of the exchange (mdir_amd/sharded.py)
+        pre = torch.zeros(world, device="cpu" if dryrun else device)
+        try:
+            dist.all_to_all_single(torch.empty_like(pre), pre)
+        except (RuntimeError, NotImplementedError) as err:
+            sys.stderr.write("all_to_all_single unavailable (%s): using all_gather\n" % err)
+            os.environ["MDIR_AMD_EXCHANGE"] = "allgather"
 
     from mdir_amd import ops
     from mdir_amd.sharded import ShardedIndex, shard_bounds
@@ -191,10 +199,6 @@ def main():
         def step(i=None):
             keep["rk"], keep["sc"], keep["q"] = sharded.rank_queries(qvecs, "DN")
 
-    if world > 1:
-        # communicator set-up (lazy peer connections of the first all-to-all) is not a step
-        pre = torch.zeros(world, device="cpu" if dryrun else device)
-        dist.all_to_all_single(torch.empty_like(pre), pre)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
