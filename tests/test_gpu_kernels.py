@@ -116,6 +116,24 @@ def test_topk_and_rank_of(ops):
         np.testing.assert_array_equal(idsc[off[q]:off[q + 1]], sc[q][lists[q]])
 
 
+def test_rank_of_many_labelled_ids(ops):
+    """mdx_rank_of with more labelled ids than one sweep of the counting kernel sorts (256), duplicates in
+    the list, an empty list, ties and NaN scores: positions == the inverse of the oracle ranking."""
+    rng = np.random.default_rng(5)
+    n, nq = 50000, 4
+    s = (np.round(rng.standard_normal((nq, n)) * 40) / 40).astype(np.float32)        # heavy ties
+    s[2, ::7] = np.nan
+    lists = [rng.choice(n, 700, replace=False), np.array([5, 5, 9, 123, 9]), np.array([], dtype=np.int64),
+             rng.choice(n, 257, replace=False)]
+    pos, sc, off = ops.rank_of(dev(s), lists)
+    pos = pos.cpu().numpy()
+    want = OC.rank_full(s)
+    inv = np.empty_like(want)
+    np.put_along_axis(inv, want, np.broadcast_to(np.arange(n), want.shape), axis=1)
+    for q in range(nq):
+        np.testing.assert_array_equal(pos[off[q]:off[q + 1]], inv[q][lists[q]])
+
+
 def test_pool_l2n_golden(ops, golden):
     g = golden("g1_pool.npz")
     for c, h, w in [(2048, 24, 32), (2048, 17, 23), (512, 48, 64), (256, 7, 5)]:
