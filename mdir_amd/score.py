@@ -20,6 +20,7 @@ from .datasets import configdataset, get_data_root, initialize_transforms
 from .evaluate import compute_map_and_print, compute_map_and_print_from_scores
 from .networks import extract_vectors_device
 from .scenario import StopWatch, path_join
+from .trace import range_
 
 
 def _read_table(path, keys):
@@ -76,23 +77,27 @@ class CirDatasetAp:
             self._log(logger, stopwatch, averages, scores_per_query)
             return
         print(">> {}: database images...".format(self.dataset))
-        vecs = extract_vectors_device(network, self.images, self.image_size, self.transforms, device=device)
-        print(">> {}: query images...".format(self.dataset))
-        if self.images == self.qimages and set(self.bbxs) == {None}:
-            qvecs = vecs.clone()
-        else:
-            qvecs = extract_vectors_device(network, self.qimages, self.image_size, self.transforms, device=device,
-                                           bbxs=self.bbxs)
+        with range_("%s/extract_descriptors" % self.dataset):
+            vecs = extract_vectors_device(network, self.images, self.image_size, self.transforms, device=device)
+            print(">> {}: query images...".format(self.dataset))
+            if self.images == self.qimages and set(self.bbxs) == {None}:
+                qvecs = vecs.clone()
+            else:
+                qvecs = extract_vectors_device(network, self.qimages, self.image_size, self.transforms, device=device,
+                                               bbxs=self.bbxs)
         stopwatch.lap("extract_descriptors")
 
         print(">> {}: Evaluating...".format(self.dataset))
-        index = ops.DescriptorIndex(vecs, "ND")
-        scores = index.scores(qvecs, "ND")                      # [Q,N] = (vecs.T @ qvecs).T
-        if self.ranking == "full":
-            ranks = ops.rank_full(scores)                       # [Q,N] = argsort(-scores, axis=0).T
-            averages, scores_per_query = compute_map_and_print(self.dataset, ranks.t(), self.gnd)
-        else:
-            averages, scores_per_query = compute_map_and_print_from_scores(self.dataset, scores, self.gnd)
+        with range_("%s/compute_score" % self.dataset):
+            index = ops.DescriptorIndex(vecs, "ND")
+            with range_("similarity"):
+                scores = index.scores(qvecs, "ND")                  # [Q,N] = (vecs.T @ qvecs).T
+            if self.ranking == "full":
+                with range_("ranking"):
+                    ranks = ops.rank_full(scores)                   # [Q,N] = argsort(-scores, axis=0).T
+                averages, scores_per_query = compute_map_and_print(self.dataset, ranks.t(), self.gnd)
+            else:
+                averages, scores_per_query = compute_map_and_print_from_scores(self.dataset, scores, self.gnd)
         stopwatch.lap("compute_score")
         index.close()
         self._log(logger, stopwatch, averages, scores_per_query)
