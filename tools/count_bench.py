@@ -24,4 +24,4 @@ for per in (4, 12, 20, 200):
     # check one query against a direct count
     q = 3; s = sc[q]; ids = torch.as_tensor(lists[q], device=dev)
     want = [(int((s > s[i]).sum()) + int(((s == s[i]) & (torch.arange(n, device=dev) < i)).sum())) for i in ids[:5]]
-    print("refs/query %3d: rank_count kernel %.3f ms; check %s" % (per, a.elapsed_time(b) / 10, want == [int(x) for x in pos[off[q]:off[q] + 5]]), flush=True)
+    print("refs/query %3d: rank_count kernel %.3f ms; check %s" % (per, a.elapsed_time(b) / 10, want == [int(x) for x in pos[off[q]:off[q] + len(want)]]), flush=True)
