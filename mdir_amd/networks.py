@@ -239,7 +239,7 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
         device = torch.device("cuda")
     net.eval()
     if num_workers is None:
-        num_workers = int(os.environ.get("MDIR_AMD_WORKERS", "6"))
+        num_workers = int(os.environ.get("MDIR_AMD_WORKERS", "8"))
     describe = (lambda x: extract_ss(net, x)) if len(ms) == 1 else (lambda x: extract_ms(net, x, ms, msp))
     tail = transform.device_tail() if hasattr(transform, "device_tail") and _gpu_preprocess(device) else None
     if tail is not None:

@@ -125,7 +125,7 @@ def infer(params, data, device=None):
     dataset = ImagesFromList(root="", images=paths, imsize=ds.pop("image_size"), bbxs=bbxs, transform=transform, **ds)
     import os
     loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, sampler=order, pin_memory=True,
-                                         num_workers=int(os.environ.get("MDIR_AMD_WORKERS", "6")),
+                                         num_workers=int(os.environ.get("MDIR_AMD_WORKERS", "8")),
                                          collate_fn=_collate_one)
     t0 = time.time()
     with torch.no_grad():
