@@ -9,9 +9,10 @@ rows, same printed lines.  What changed underneath (cirscore.py:54-71):
     np.argsort(-scores, axis=0)     -> rank_full(scores)                     (mdx_rank_full)
     compute_map_and_print(ranks)    -> same function on the device ranking
 
-``ranking="positions"`` skips the full ranking and feeds compute_map from
-``mdx_rank_of`` (identical APs, no N-long sort); the default keeps the reference's
-dot + argsort + compute_map sequence.
+The default ``ranking="positions"`` feeds compute_map from ``mdx_rank_of`` (identical APs --
+asserted in the tests and in bench.py -- without an N-long sort; the score object exposes
+nothing but the APs); ``ranking="full"`` runs the reference's dot + argsort + compute_map
+sequence literally.
 """
 import os.path
 
@@ -42,7 +43,7 @@ class CirDatasetAp:
         self.image_size = params.pop("image_size")
         self.dataset = params.pop("dataset")
         self.transforms = initialize_transforms(params.pop("transforms"), params.pop("mean_std"))
-        self.ranking = params.pop("ranking", "full")
+        self.ranking = params.pop("ranking", "positions")
         assert self.ranking in {"full", "positions"}, self.ranking
         if isinstance(self.dataset, dict):
             assert self.dataset.keys() == {"name", "queries", "db", "imgdir"}

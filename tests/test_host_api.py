@@ -335,8 +335,8 @@ def test_extract_vectors_and_score_end_to_end(fops, tmp_path, monkeypatch, capsy
         for k in ("ap_easy", "ap_medium", "ap_hard"):
             np.testing.assert_allclose(rows[2 + i][3][k], per[k][i], rtol=0, atol=1e-12)
     assert ">> roxford5k: mAP E:" in capsys.readouterr().out
-    # positions route gives the same averages
-    score2 = initialize_score({"type": "cirdatasetap", "image_size": 224, "dataset": "roxford5k", "ranking": "positions",
+    # the literal dot + argsort route gives the same averages as the default (sort-free) one
+    score2 = initialize_score({"type": "cirdatasetap", "image_size": 224, "dataset": "roxford5k", "ranking": "full",
                                "transforms": "pil2np | totensor | normalize",
                                "mean_std": net.network_params.runtime["data"]["mean_std"]})
     rows2 = []
