@@ -120,7 +120,12 @@ def load_checkpoint(path):
 
 def initialize_network(params, device, state=None, runtime=None):
     assert state is not None, "only checkpoint-backed networks are supported on the eval path"
-    cls = NETWORKS[state["net"]["type"]]
+    kind = state["net"]["type"]
+    if kind not in NETWORKS:
+        raise NotImplementedError("network type %r is outside the MI355X hot path (%s are supported; "
+                                  "SequentialNetwork = U-Net generator + embedding network, DESIGN.md section 7)"
+                                  % (kind, sorted(NETWORKS)))
+    cls = NETWORKS[kind]
     return cls.initialize_from_state({"net": state["net"]}, device, params, runtime)
 
 
