@@ -63,23 +63,34 @@ def query_bounds(nq, world, rank):
 
 def exchange_chunks(n_total, world):
     """How many row chunks every shard is cut into so that the all-to-all of chunk c runs on
-    RCCL's stream while the similarity kernel of chunk c+1 runs on the compute stream.  Chunks
-    below ~250 k rows cost more in kernel efficiency than the hidden transfer gains (measured:
-    tools/shard_model.py), so only big shards (G=2 at 1 M rows) are split.  Same value on every
+    RCCL's stream while the similarity kernel of chunk c+1 runs on the compute stream.  Small
+    chunks cost kernel efficiency (measured: tools/shard_model.py), so only big shards (G=2 at 1 M
+    rows) are split, into three chunks of halving size (see ``chunk_bounds``).  Same value on every
     rank (derived from the largest shard)."""
     import os
     forced = os.environ.get("MDIR_AMD_EXCHANGE_CHUNKS")
     if forced:
-        return max(1, int(forced))
+        chunks = max(1, int(forced))
+        return chunks if n_total // world >= (1 << chunks) else 1      # no empty chunk on any rank
     if world == 1:
         return 1
     biggest = shard_bounds(n_total, world, 0)[1]
-    return max(1, min(4, biggest // 250_000))
+    return 3 if biggest >= 400_000 else 1
 
 
 def chunk_bounds(lo, hi, chunks):
-    """Chunk c of rows ``[lo, hi)``: the same near-equal contiguous split as ``shard_bounds``."""
-    return [tuple(lo + x for x in shard_bounds(hi - lo, chunks, c)) for c in range(chunks)]
+    """Contiguous chunks of rows ``[lo, hi)`` with sizes halving from one to the next (4/7, 2/7, 1/7 for
+    three): a link moves a chunk's scores in about half the time the similarity kernel needs for the
+    same rows, so the transfer of chunk c hides behind the kernel of the half-sized chunk c+1, and
+    only the LAST, smallest transfer is exposed."""
+    n = hi - lo
+    weights = [1 << (chunks - 1 - c) for c in range(chunks)]
+    total, edges, acc = sum(weights), [lo], 0
+    for w in weights[:-1]:
+        acc += w
+        edges.append(lo + (n * acc) // total)
+    edges.append(hi)
+    return [(edges[c], edges[c + 1]) for c in range(chunks)]
 
 
 class ShardedIndex:

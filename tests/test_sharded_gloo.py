@@ -133,11 +133,14 @@ def test_sharded_equals_single_process(tmp_path, world, n, nq, chunks, exchange)
 def test_exchange_chunk_policy():
     from mdir_amd.sharded import chunk_bounds, exchange_chunks
     assert exchange_chunks(1004993, 1) == 1
-    assert exchange_chunks(1004993, 2) == 2          # 502 k-row shards: transfer hidden behind the second half
+    assert exchange_chunks(1004993, 2) == 3          # 502 k-row shards: 4/7, 2/7, 1/7 -- only the last transfer is exposed
     assert exchange_chunks(1004993, 4) == 1 and exchange_chunks(1004993, 8) == 1
     assert exchange_chunks(4993, 8) == 1
     b = chunk_bounds(10, 21, 3)
     assert b[0][0] == 10 and b[-1][1] == 21 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    sizes = [y - x for x, y in chunk_bounds(0, 700000, 3)]
+    assert sizes == [400000, 200000, 100000]
+    assert chunk_bounds(5, 9, 1) == [(5, 9)] and all(y >= x for x, y in chunk_bounds(0, 2, 3))
 
 
 def test_shard_bounds_cover_everything():
