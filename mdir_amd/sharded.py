@@ -64,8 +64,8 @@ def query_bounds(nq, world, rank):
 def exchange_chunks(n_total, world):
     """How many row chunks every shard is cut into so that the all-to-all of chunk c runs on
     RCCL's stream while the similarity kernel of chunk c+1 runs on the compute stream.  Small
-    chunks cost kernel efficiency (measured: tools/shard_model.py), so only big shards (G=2 at 1 M
-    rows) are split, into three chunks of halving size (see ``chunk_bounds``).  Same value on every
+    chunks cost kernel efficiency (measured: tools/shard_model.py), so only big shards are split
+    (three chunks at G=2, two at G=4 for 1 M rows; chunk sizes halve, see ``chunk_bounds``).  Same value on every
     rank (derived from the largest shard)."""
     import os
     forced = os.environ.get("MDIR_AMD_EXCHANGE_CHUNKS")
@@ -75,7 +75,7 @@ def exchange_chunks(n_total, world):
     if world == 1:
         return 1
     biggest = shard_bounds(n_total, world, 0)[1]
-    return 3 if biggest >= 400_000 else 1
+    return 3 if biggest >= 400_000 else (2 if biggest >= 200_000 else 1)
 
 
 def chunk_bounds(lo, hi, chunks):
