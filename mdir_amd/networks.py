@@ -175,24 +175,64 @@ def _gpu_preprocess(device):
     return torch.device(device).type == "cuda" and os.environ.get("MDIR_AMD_GPU_PREPROCESS", "1") != "0"
 
 
-def _same_shape_order(images, bbxs):
-    """Indices of ``images`` ordered so that images of equal raw size (hence equal network input
-    shape) are consecutive: every hipGraph is then captured once and replayed for its whole group
-    instead of being evicted and re-captured.  Sizes come from the file headers (no decode); an
-    unreadable header keeps its place in a group of its own (the loader reports the error)."""
+def _shape_key(images, bbxs, i):
+    """Raw size of image i from its file header (no decode), or of its crop box."""
     from PIL import Image
-    keys = []
-    for i, path in enumerate(images):
-        box = bbxs[i] if bbxs else None
-        if box:
-            keys.append((int(box[2] - box[0]), int(box[3] - box[1])))
-            continue
-        try:
-            with Image.open(path) as handle:
-                keys.append(tuple(handle.size))
-        except Exception:
-            keys.append((-1, i))
-    return sorted(range(len(images)), key=lambda i: (keys[i], i))
+    box = bbxs[i] if bbxs else None
+    if box:
+        return (int(box[2] - box[0]), int(box[3] - box[1]))
+    try:
+        with Image.open(images[i]) as handle:
+            return tuple(handle.size)
+    except Exception:
+        return (-1, i)                       # unreadable header: a group of its own (the loader reports the error)
+
+
+def _same_shape_order(images, bbxs, lo=0, hi=None):
+    """Indices ``lo..hi`` of ``images`` ordered so that images of equal raw size (hence equal network
+    input shape) are consecutive: every hipGraph is then captured once and replayed for its whole
+    group instead of being evicted and re-captured."""
+    hi = len(images) if hi is None else hi
+    keys = {i: _shape_key(images, bbxs, i) for i in range(lo, hi)}
+    return sorted(range(lo, hi), key=lambda i: (keys[i], i))
+
+
+class ShapeOrder:
+    """Sampler form of :func:`_same_shape_order` for long image lists: the list is ordered window by
+    window (4096 images) WHILE the loader consumes it, so a million-image extraction does not open
+    a million files before its first image.  ``emitted[k]`` is the list index of the k-th item the
+    loader yields."""
+
+    WINDOW = 4096
+
+    def __init__(self, images, bbxs):
+        self.images, self.bbxs, self.emitted = images, bbxs, []
+
+    def __len__(self):
+        return len(self.images)
+
+    def __iter__(self):
+        self.emitted = []
+        for lo in range(0, len(self.images), self.WINDOW):
+            for i in _same_shape_order(self.images, self.bbxs, lo, min(len(self.images), lo + self.WINDOW)):
+                self.emitted.append(i)
+                yield i
+
+
+class _Sequential:
+    """The caller's order, with the same ``emitted`` bookkeeping as :class:`ShapeOrder`."""
+
+    def __init__(self, n):
+        self.n, self.emitted = n, []
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        self.emitted = []
+        for i in range(self.n):
+            self.emitted.append(i)
+            yield i
 
 
 def batched_loop(loader, order, device, describe, store, missing=None, progress=None, batches=True):
@@ -215,7 +255,8 @@ def batched_loop(loader, order, device, describe, store, missing=None, progress=
                 store(i, describe(t))
         buf.clear()
 
-    for done, (i, item) in enumerate(zip(order, loader)):
+    for done, item in enumerate(loader):
+        i = order.emitted[done] if hasattr(order, "emitted") else order[done]
         if isinstance(item, dict) and item == {}:
             missing(i)
         else:
@@ -247,10 +288,10 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
         # and PCIe, and no float arithmetic on the host); /255, -mean, /std happen on the GPU
         transform, from_tensor = ToUint8HWC(), describe
         describe = lambda u8: from_tensor(ops.u8_to_chw(u8, tail[0], tail[1]))
-    order = list(range(len(images)))
+    order = _Sequential(len(images))
     if graphs_enabled(device):
         describe = ShapeGraphs(describe)      # per input shape: eager once, then one hipGraph replay per call
-        order = _same_shape_order(images, bbxs)
+        order = ShapeOrder(images, bbxs)
     loader = torch.utils.data.DataLoader(
         ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),
         batch_size=1, shuffle=False, sampler=order, num_workers=num_workers, pin_memory=True)

@@ -113,15 +113,15 @@ def infer(params, data, device=None):
     from . import ops
     from .datasets import ToUint8HWC
     from .graphs import ShapeGraphs, graphs_enabled
-    from .networks import _gpu_preprocess, _same_shape_order, batched_loop
+    from .networks import ShapeOrder, _Sequential, _gpu_preprocess, batched_loop
     paths = [path_join(image_dir, x) for x in images]
     describe = network
     tail = transform.device_tail() if _gpu_preprocess(device) else None
     if tail is not None:
         transform, describe = ToUint8HWC(), (lambda u8: network(ops.u8_to_chw(u8, tail[0], tail[1])))
-    order = list(range(len(paths)))
+    order = _Sequential(len(paths))
     if graphs_enabled(device):
-        describe, order = ShapeGraphs(describe), _same_shape_order(paths, bbxs)
+        describe, order = ShapeGraphs(describe), ShapeOrder(paths, bbxs)
     dataset = ImagesFromList(root="", images=paths, imsize=ds.pop("image_size"), bbxs=bbxs, transform=transform, **ds)
     import os
     loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, sampler=order, pin_memory=True,

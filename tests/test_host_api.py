@@ -723,6 +723,18 @@ def test_device_tail_detection_and_shape_order(tmp_path):
     assert sorted(order) == list(range(6)) and order[:1] == [5]          # unreadable header: own group, first
     assert order[1:] == [1, 4, 0, 2, 3]
     assert _same_shape_order(paths[:3], [(0, 0, 4, 4), None, (1, 1, 5, 5)]) == [0, 2, 1]      # crops group by box size
+    # long lists are ordered window by window while the loader consumes them
+    from mdir_amd.datasets import ImagesFromList
+    from mdir_amd.networks import ShapeOrder
+    so = ShapeOrder(paths[:5], None)
+    so.WINDOW = 3
+    assert list(so) == [1, 0, 2, 4, 3] and so.emitted == [1, 0, 2, 4, 3] and len(so) == 5
+    for workers in (0, 2):
+        dl = torch.utils.data.DataLoader(ImagesFromList("", paths[:5], transform=ToUint8HWC()), batch_size=1, sampler=so,
+                                         num_workers=workers)
+        shapes = [tuple(x.shape[1:3]) for x in dl]
+        assert so.emitted == [1, 0, 2, 4, 3]
+        assert shapes == [(8, 6), (6, 8), (6, 8), (8, 6), (9, 9)]          # (H, W) of images 1, 0, 2, 4, 3
 
 
 def test_batches_of_equal_sized_images_equal_single_images(fops):
