@@ -102,14 +102,27 @@ __global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ s
 // spread over the CUs -- measured crossover, tools/scores_ablate.hip.
 constexpr int LC_KC = 2, LC_NSTAGE = 3;
 
-template <int QT, int R, typename MM>
+// > 64 KiB of dynamic LDS needs an opt-in per kernel and device: done once, not on every launch
+static int lds_opt_in(const void *kern, int lds, bool *done)
+{
+    int dev = 0;
+    MDX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        MDX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return MDX_OK;
+}
+
+template <int QT, int R, typename MM, int QR = 0>
 static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
                             int KB, int nq_valid, hipStream_t s, int passes = 1)
 {
-    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM>;   // 2 = non-temporal database stream
-    constexpr int lds = LC_NSTAGE * (QT + 4 * R) * LC_KC * 1024;
-    // > 64 KiB of dynamic LDS needs the opt-in; per device, so set on every launch (host-side, cheap)
-    MDX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR>;   // 2 = non-temporal database stream
+    constexpr int lds = LC_NSTAGE * (QT + QR + 4 * R) * LC_KC * 1024;
+    static bool opted[64];
+    int rc = lds_opt_in((const void *)kern, lds, opted);
+    if (rc != MDX_OK) return rc;
     const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
                        (unsigned long long *)nullptr);
@@ -126,6 +139,22 @@ static int launch_qt(int mode, const f32x4 *db, const f32x4 *q, float *out, int6
         case 1: return launch_scores_lc<QT, 2, MmaF32>(db, q, out, n, RT, KB, nq_valid, s, passes);
         case 2: return launch_scores_lc<QT, 1, MmaF16>(db, q, out, n, RT, KB, nq_valid, s, passes);
         default: return launch_scores_lc<QT, 2, MmaF16>(db, q, out, n, RT, KB, nq_valid, s, passes);
+    }
+}
+
+// `qt` query tiles of which the last holds <= 8 queries: qt-1 full tiles on the 16x16x4 MFMA + the leftover
+// tile on v_mfma_f32_4x4x1 (fp32 shards with 128-row workgroups)
+static int dispatch_leftover(int qt, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT, int KB,
+                             int nq_valid, hipStream_t s)
+{
+    switch (qt) {
+        case 2: return launch_scores_lc<1, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
+        case 3: return launch_scores_lc<2, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
+        case 4: return launch_scores_lc<3, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
+        case 5: return launch_scores_lc<4, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
+        case 6: return launch_scores_lc<5, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
+        case 7: return launch_scores_lc<6, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
+        default: return launch_scores_lc<7, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
     }
 }
 
@@ -273,7 +302,9 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
     const bool small = ix->RT < 2048;                 // < 32 768 rows: 64-row workgroups
     int64_t qt_begin = 0;
     const int64_t full_passes = QT_total / MAX_QT;
-    if (full_passes > 1 && full_passes < 65536 && !getenv("MDX_NO_PASS_GRID")) {
+    static const bool no_pass_grid = getenv("MDX_NO_PASS_GRID") != nullptr, no_query_split = getenv("MDX_NO_QUERY_SPLIT") != nullptr,
+                      no_leftover = getenv("MDX_NO_LEFTOVER_MFMA") != nullptr;
+    if (full_passes > 1 && full_passes < 65536 && !no_pass_grid) {
         // many queries: all full groups of MAX_QT query tiles in ONE launch (grid.y = group), so that a
         // small database still fills the chip (20 000 rows are 313 workgroups per group)
         const int mode = (small ? 0 : 1) | (ix->storage == MDX_F16 ? 2 : 0);
@@ -283,7 +314,7 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
         MDX_LAUNCH_CHECK();
         qt_begin = full_passes * MAX_QT;
     }
-    if (qt_begin == 0 && QT_total <= MAX_QT && QT_total > 1 && ix->storage == MDX_F32 && !getenv("MDX_NO_QUERY_SPLIT")) {
+    if (qt_begin == 0 && QT_total <= MAX_QT && QT_total > 1 && ix->storage == MDX_F32 && !no_query_split) {
         // few queries against a small shard (rOxford5k alone: 70 x 4 993): 64-row workgroups taking all
         // query tiles are only RT/4 = 79 workgroups, each a 5-tile-long MFMA chain.  Give every workgroup
         // ONE query tile instead (grid.y = tile): 5x the workgroups, a fifth of the chain each.
@@ -302,7 +333,11 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
         const f32x4 *qp = qtiles + qt0 * ix->KB * 64;
         float *op = scores + q0 * ix->n;
         const int mode = (small ? 0 : 1) | (ix->storage == MDX_F16 ? 2 : 0);
-        rc = dispatch_qt(qt, mode, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        const int tail = nq_valid - (qt - 1) * TILE_ROWS;      // queries in the last tile of this launch
+        if (mode == 1 && qt >= 2 && tail <= 8 && !no_leftover)
+            rc = dispatch_leftover(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        else
+            rc = dispatch_qt(qt, mode, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
         if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK();
     }

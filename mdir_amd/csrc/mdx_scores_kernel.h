@@ -10,6 +10,20 @@ constexpr int TILE_ROWS = 16;   // rows per tile  (MFMA N / M)
 constexpr int TILE_K = 16;      // k per tile     (4 MFMA k-steps of 4)
 constexpr int MAX_QT = 8;       // query tiles (of 16) per launch
 
+// Position (in KiB tiles) of tile (row tile rt, k-block kb) of a shard: row-tile-major.  A workgroup's chunk is then
+// 8-16 pieces of KC KiB at a KB-KiB stride.  The alternative -- blocks of 16 row tiles with the k-block as the slow
+// index, so that a chunk is ONE contiguous 32-KiB run -- was measured and is SLOWER (a pure stream of the shard
+// 1.76 ms against 1.52 ms at 1 M x 2048: the strided pieces spread over more HBM channels at any instant).
+#ifdef MDX_SHARD_BLOCKED        // tools/scores_ablate.hip: A/B timing only
+constexpr int SHARD_BLOCK = 16;
+__host__ __device__ __forceinline__ int64_t shard_tile(int64_t rt, int64_t kb, int64_t KB)
+{
+    return ((rt / SHARD_BLOCK) * KB + kb) * SHARD_BLOCK + (rt % SHARD_BLOCK);
+}
+#else
+__host__ __device__ __forceinline__ int64_t shard_tile(int64_t rt, int64_t kb, int64_t KB) { return rt * KB + kb; }
+#endif
+
 // Element type of a shard.  A tile is always 64 lanes x 16 B; what the 16 bytes are and which
 // MFMA consumes them is the only difference between the fp32 (exact chain) and the fp16
 // (BASELINE.json configs[4]: "fp16 descriptors on CDNA4 fp16 MFMA") paths.
@@ -51,15 +65,26 @@ struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e
 // then read it; the slot of stage c-1 is refilled right after B_c (every consumer has
 // finished chunk c-1 by then).  Accumulation order per output is unchanged (k ascending).
 // ===========================================================================
-template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32>
-__global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restrict__ db,
+//
+// Leftover queries (QR = 1, fp32 shards with R = 2 only): 70 queries are 4 full MFMA tiles + 6.  A fifth
+// 16-query tile would be 62 % padding (12.5 % of all MFMAs of the launch).  Instead the last query tile
+// (<= 8 valid queries, stored in the same 1-KiB fragment format) is multiplied with
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products per instruction = 2 groups of 4 queries x
+// 8 groups of 4 rows = the wave's 32 database rows x 8 queries, ONE k per instruction (8 cycles against
+// the 2 x 32 of the padded tile's two 16x16x4 MFMAs per 4 k).  A lane reads the 16 k of "its" query row
+// and of "its" database row with four ds_read_b128 each (the four lane groups g of the tile format hold
+// k = 4t+g) and issues the products in k order, so every output is still the k = 0..D-1 fma chain.
+template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0>
+__global__ __launch_bounds__(512, (R >= 4 ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
                                                            float *__restrict__ out, int64_t n, int KB,
                                                            int nq_valid, unsigned long long *dbg = nullptr)
 {
     constexpr int CW = 4;                           // consumer waves
     constexpr int LW = 4;                           // loader waves
-    constexpr int QTILES = QT * KC;                 // KiB tiles of queries per stage
+    static_assert(QR == 0 || (R == 2 && MM::STEPS == 4), "the 4x4x1 leftover path covers 32 fp32 rows per wave");
+    constexpr int QTL = QT + QR;                    // query tiles in LDS: QT full ones + the leftover tile
+    constexpr int QTILES = QTL * KC;                // KiB tiles of queries per stage
     constexpr int BTILES = CW * R * KC;             // KiB tiles of database per stage
     constexpr int STAGE_TILES = QTILES + BTILES;
     constexpr int PER_LOADER = (STAGE_TILES + LW - 1) / LW;   // uneven split: the last tile is loaded twice
@@ -69,6 +94,8 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long t_entry = 0;
+    if (STAMPS) t_entry = __builtin_amdgcn_s_memrealtime();
     const int nchunks = KB / KC;
     const int64_t rt_wg = (int64_t)blockIdx.x * CW * R;            // first row tile of the workgroup
     // blockIdx.y = query pass: several full groups of QT query tiles in one launch (many queries
@@ -92,23 +119,23 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
             } else {
                 const int j = i - QTILES;
                 const int tile = j / KC, kbc = j % KC;              // tile = cw * R + r
-                src[t] = db + ((rt_wg + tile) * KB + kbc) * 64 + lane;
+                src[t] = db + shard_tile(rt_wg + tile, kbc, KB) * 64 + lane;
             }
         }
         auto issue = [&](int c) {
             f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
 #pragma unroll
             for (int t = 0; t < PER_LOADER; ++t) {
-                // query tiles (re-read by every workgroup) keep the default cache policy; the
-                // database stream may be marked non-temporal (DB_AUX = 2)
-                if (DB_AUX != 0 && (lw + t * LW) >= QTILES)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(src[t] + (int64_t)c * KC * 64),
-                        (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, DB_AUX);
+                // query tiles (re-read by every workgroup) keep the default cache policy and are stored densely;
+                // the database stream may be marked non-temporal (DB_AUX = 2) and advances in the shard's order
+                const bool is_db = (lw + t * LW) >= QTILES;
+                const f32x4 *p = src[t] + (is_db ? shard_tile(0, (int64_t)c * KC, KB) : (int64_t)c * KC) * 64;
+                if (DB_AUX != 0 && is_db)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                                     (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, DB_AUX);
                 else
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(src[t] + (int64_t)c * KC * 64),
-                        (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                                     (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, 0);
             }
         };
 #pragma unroll
@@ -127,14 +154,21 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
     }
 
     // ----------------------------------------------------------------- consumer
-    f32x4 acc[R][QT];
+    f32x4 acc[R][QT > 0 ? QT : 1];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int q = 0; q < QT; ++q) acc[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // leftover path: lane = 4*block + i; block = 2*rg + qg: query 4*qg + i of the leftover tile (A operand),
+    // database row 4*rg + i of the wave's 32 rows (B operand); D register v = query 4*qg + v, same row
+    f32x4 accl = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int l_q = 4 * ((lane >> 2) & 1) + (lane & 3);         // query row inside the leftover tile
+    const int l_row = 4 * (lane >> 3) + (lane & 3);             // row inside the wave's 32 rows
+    const int l_boff = (l_row >> 4) * KC * 64 + (l_row & 15);   // f32x4 offset of (tile, row) inside the wave's tiles
 
     unsigned long long t_wait = 0, t_work = 0, ts0 = 0, ts1 = 0;      // STAMPS: diagnostic build only
-    if (STAMPS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory");
+    unsigned long long tr0 = 0, tc0 = 0;
+    if (STAMPS) { tr0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory"); tc0 = ts0; }
     for (int c = 0; c < nchunks; ++c) {
         __builtin_amdgcn_s_barrier();                                       // B_c
         __builtin_amdgcn_sched_barrier(0);
@@ -144,30 +178,65 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
         const f32x4 *bs = slot + (QTILES + wave * R * KC) * 64 + lane;
 #pragma unroll
         for (int kb = 0; kb < KC; ++kb) {
-            f32x4 a[QT], b[R];
+            f32x4 a[QT > 0 ? QT : 1], b[R];
 #pragma unroll
             for (int q = 0; q < QT; ++q) a[q] = qs[(q * KC + kb) * 64];
 #pragma unroll
             for (int r = 0; r < R; ++r) b[r] = bs[(r * KC + kb) * 64];
+            if constexpr (QR == 0) {
 #pragma unroll
-            for (int t = 0; t < MM::STEPS; ++t)
+                for (int t = 0; t < MM::STEPS; ++t)
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                    for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int q = 0; q < QT; ++q) acc[r][q] = MM::step(t, a[q], b[r], acc[r][q]);
+                        for (int q = 0; q < QT; ++q) acc[r][q] = MM::step(t, a[q], b[r], acc[r][q]);
+            } else {
+                f32x4 al[4], bl[4];         // [g]: element t = k 4t+g of the lane's query row / database row
+                const f32x4 *ql = slot + (QT * KC + kb) * 64 + l_q;
+                const f32x4 *bw = slot + (QTILES + wave * R * KC + kb) * 64 + l_boff;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { al[g] = ql[16 * g]; bl[g] = bw[16 * g]; }
+                // MFMA order is pinned (LDS reads, VALU, SALU may still move): the one-k products of step t ride
+                // between the 16x16x4 MFMAs of step t+1, so that their operands (read at the top of the k-block)
+                // have landed long before; a small MFMA costs 8-9 cycles there, a dependent run of them 12.5 each
+                constexpr int PIN = 0x0002 | 0x0004 | 0x0070 | 0x0380 | 0x0400;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int n_small = t == 0 ? 0 : (t == 3 ? 8 : 4);
+                    int done = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) {
+                            acc[r][q] = MM::step(t, a[q], b[r], acc[r][q]);
+                            __builtin_amdgcn_sched_barrier(PIN);
+                            const int due = ((r * QT + q + 1) * n_small) / (R * QT);
+#pragma unroll
+                            for (; done < due; ++done) {
+                                const int st = (t == 3 && done >= 4) ? 3 : t - 1, g = done & 3;
+                                accl = __builtin_amdgcn_mfma_f32_4x4x1f32(al[g][st], bl[g][st], accl, 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(PIN);
+                            }
+                        }
+                }
+            }
         }
         // all LDS reads of this stage are consumed by the MFMAs above before the next barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (STAMPS) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); t_work += ts1 - ts0; ts0 = ts1; }
     }
-    if (STAMPS && dbg && lane == 0) { dbg[((int64_t)blockIdx.x * CW + wave) * 2] = t_wait; dbg[((int64_t)blockIdx.x * CW + wave) * 2 + 1] = t_work; }
+    if (STAMPS && dbg && lane == 0) {       // diagnostic build only: wait / work cycles, loop cycles and 100 MHz ticks (in-kernel clock)
+        unsigned long long *d = dbg + ((int64_t)blockIdx.x * CW + wave) * 8;
+        d[0] = t_wait; d[1] = t_work; d[2] = ts0 - tc0; d[3] = __builtin_amdgcn_s_memrealtime() - tr0;
+        d[4] = t_entry; d[5] = tr0;
+    }
 
     // Epilogue: the ring is free now (loaders have left, consumers are past their last read);
     // transpose the accumulators through LDS so that every query row of the workgroup's
     // 64*R database rows leaves as one contiguous run (full cache lines instead of 64-B pieces).
     constexpr int ROWS = CW * R * TILE_ROWS;        // database rows per workgroup
     constexpr int LDW = ROWS + 4;                   // +4: the four 16-lane groups hit different banks
-    static_assert(QT * 16 * LDW * 4 <= NSTAGE * STAGE_TILES * 1024, "output staging must fit in the ring");
+    static_assert((QT * 16 + QR * 8) * LDW * 4 <= NSTAGE * STAGE_TILES * 1024, "output staging must fit in the ring");
     __builtin_amdgcn_s_barrier();
     float *stage = (float *)ring;
     {
@@ -179,17 +248,28 @@ __global__ __launch_bounds__(512, 2) void scores_lc_kernel(const f32x4 *__restri
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     stage[(q * 16 + qrow + i) * LDW + (wave * R + r) * TILE_ROWS + col] = acc[r][q][i];
+        if constexpr (QR != 0) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                stage[(QT * 16 + 4 * ((lane >> 2) & 1) + v) * LDW + wave * R * TILE_ROWS + l_row] = accl[v];
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const int64_t row0 = rt_wg * TILE_ROWS;
     const int rows_valid = (int)((n - row0) < ROWS ? (n - row0) : ROWS);
     // queries of this group that exist (the last group of a launch may be partial)
-    const int nq_here = (nq_valid - (int)blockIdx.y * QT * TILE_ROWS) < QT * TILE_ROWS ? (nq_valid - (int)blockIdx.y * QT * TILE_ROWS)
-                                                                                   : QT * TILE_ROWS;
+    constexpr int QCAP = QT * TILE_ROWS + QR * 8;   // query rows staged (grid.y > 1 only with QR = 0)
+    const int nq_here = (nq_valid - (int)blockIdx.y * QT * TILE_ROWS) < QCAP ? (nq_valid - (int)blockIdx.y * QT * TILE_ROWS) : QCAP;
     for (int e = tid; e < nq_here * ROWS; e += CW * 64) {
         const int qi = e / ROWS, rr = e % ROWS;
         if (rr < rows_valid) out[(int64_t)qi * n + row0 + rr] = stage[qi * LDW + rr];
+    }
+    if (STAMPS && dbg && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *d = dbg + ((int64_t)blockIdx.x * CW + wave) * 8;
+        d[6] = __builtin_amdgcn_s_memrealtime();
+        d[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID (cu / se / simd / wave slot)
     }
 }
 

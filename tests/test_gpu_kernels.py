@@ -31,9 +31,12 @@ def _unit_rows(rng, n, d):
     return v / np.linalg.norm(v, axis=1, keepdims=True)
 
 
-# n >= 65536 takes the loader/consumer kernel (LDS-DMA ring), smaller shards the register-streaming one
-@pytest.mark.parametrize("n,d,nq", [(4993, 2048, 70), (1000, 512, 1), (333, 100, 17), (16, 64, 16),
+# shards of >= 32 768 rows take 128-row workgroups (R = 2), smaller ones 64-row workgroups; with R = 2 a last
+# query tile of <= 8 queries goes through the v_mfma_f32_4x4x1 leftover path (mdx_scores_kernel.h)
+@pytest.mark.parametrize("n,d,nq", [(4993, 2048, 70), (6322, 2048, 70), (1000, 512, 1), (333, 100, 17), (16, 64, 16),
                                     (5000, 256, 130), (70, 2048, 70),
+                                    # leftover path: 1, 2, 6 and 7 full tiles + a last tile of 8, 1, 4 and 8 queries
+                                    (40000, 128, 24), (32768, 32, 33), (33000, 64, 100), (50000, 48, 120),
                                     (70000, 64, 1), (66001, 100, 17), (70001, 256, 130), (65600, 2048, 70),
                                     (65537, 32, 128), (131072, 96, 33),
                                     # > 256 queries: the full groups of 128 go out as ONE launch (grid.y = group)
@@ -73,7 +76,7 @@ def test_scores_center(ops):
     np.testing.assert_array_equal(got, OC.gemm_nt_chain(X - m, P))
 
 
-@pytest.mark.parametrize("n,nq", [(4993, 70), (1, 1), (63, 3), (4096, 2), (4097, 2), (70000, 5)])
+@pytest.mark.parametrize("n,nq", [(4993, 70), (6322, 70), (1, 1), (63, 3), (4096, 2), (4097, 2), (70000, 5)])
 def test_rank_full_bit_exact(ops, n, nq):
     rng = np.random.default_rng(n * 7 + nq)
     sc = rng.standard_normal((nq, n)).astype(np.float32)

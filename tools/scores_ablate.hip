@@ -5,9 +5,11 @@
 #include <math.h>
 #include <stdlib.h>
 #include "mdx_scores_kernel.h"
+#include "attic/scores_pb_kernel.h"      // persistent variant, measured slower: kept for the record
 #include "scores_v1_kernel.h"
 namespace mdx { void set_error(const char *, ...) {} }
 using namespace mdx;
+static int g_kbs = 0;
 
 template <int ABL, int R, bool CM = false, bool NT = false, int NS = 2, int WPS = 2, bool SP = false, int NW = 4, int KC = 4>
 static float run(const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT, int KB, int reps)
@@ -27,8 +29,8 @@ int main(int argc, char **argv)
     const int64_t n = argc > 1 ? atoll(argv[1]) : 1004993, d = 2048; const int KB = d / 16;
     const int64_t RT = (n + 15) / 16, RTp = (RT + 7) / 8 * 8;
     f32x4 *db, *q; float *out;
-    hipMalloc(&db, (RTp + 256) * KB * 1024); hipMalloc(&q, 5 * KB * 1024); hipMalloc(&out, 70 * n * 4);
-    std::vector<float> h(RTp * KB * 256);
+    hipMalloc(&db, (RTp + 256) * (KB + 8) * 1024); hipMalloc(&q, 5 * KB * 1024); hipMalloc(&out, 70 * n * 4);
+    std::vector<float> h(RTp * (KB + 8) * 256);
     {   // full-mantissa gaussian data of the real magnitude (unit rows in 2048-d): power/clock as in production
         unsigned long long st = 88172645463325252ull;
         auto u = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((st >> 11) * (1.0 / 9007199254740992.0)); };
@@ -54,11 +56,40 @@ int main(int argc, char **argv)
             if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
             return ms / 10;
         };
+        float *out2; hipMalloc(&out2, 70 * n * 4);
+        auto pk = [&](auto kern, int lds, float *o, int nq, int grid = 512) {
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, db, q, o, n, RT, KB, nq);
+            hipEventRecord(a);
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, db, q, o, n, RT, KB, nq);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
+            return ms / 10;
+        };
+        // interleaved rounds in one process
         for (int rep = 0; rep < 3; ++rep)
-        printf("n=%lld: LC R2 KC2 NST3 %.4f | R1 KC2 NST3 %.4f | R1 KC2 NST4 %.4f | R1 KC4 NST3 %.4f | v1 NW4 R1 %.4f | v1 NW8 R1 %.4f ms\n", (long long)n,
-               lc(scores_lc_kernel<5, 2, 2, 3, 2>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 1, 2, 3, 2>, 1, 2, 3, 5),
-               lc(scores_lc_kernel<5, 1, 2, 4, 2>, 1, 2, 4, 5), lc(scores_lc_kernel<5, 1, 4, 3, 2>, 1, 4, 3, 5),
-               run<0, 1, false, true, 3, 2, false, 4, 4>(db, q, out, n, RT, KB, 10), run<0, 1, false, true, 3, 2, false, 8, 4>(db, q, out, n, RT, KB, 10));
+            printf("n=%lld: QT5 KC2 NST3 %.4f | QT5 KC1 NST4 (3 WG/CU) %.4f | QT5 KC1 NST6 %.4f | QT4+leftover KC2 NST3 %.4f | QT4+leftover KC1 NST6 %.4f | persistent QT5 %.4f ms\n", (long long)n,
+                   lc(scores_lc_kernel<5, 2, 2, 3, 2>, 2, 2, 3, 5), lc(scores_lc_kernel<5, 2, 1, 4, 2>, 2, 1, 4, 5), lc(scores_lc_kernel<5, 2, 1, 6, 2>, 2, 1, 6, 5),
+                   lc(scores_lc_kernel<4, 2, 2, 3, 2, false, MmaF32, 1>, 2, 2, 3, 5), lc(scores_lc_kernel<4, 2, 1, 6, 2, false, MmaF32, 1>, 2, 1, 6, 5),
+                   pk(scores_pb_kernel<5, 0, 2, 3>, pb_lds_bytes<5, 0, 2, 3>(), out2, 70));
+        {   // bitwise: persistent kernels against the per-block padded kernel
+            lc(scores_lc_kernel<5, 2, 2, 3, 2>, 2, 2, 3, 5);
+            std::vector<float> ha((size_t)70 * n), hb((size_t)70 * n);
+            hipMemcpy(ha.data(), out, ha.size() * 4, hipMemcpyDeviceToHost);
+            for (int v = 0; v < 2; ++v) {
+                hipMemset(out2, 0xFF, (size_t)70 * n * 4);
+                if (v == 0) pk(scores_pb_kernel<5, 0, 2, 3>, pb_lds_bytes<5, 0, 2, 3>(), out2, 70);
+                else pk(scores_pb_kernel<4, 1, 2, 3>, pb_lds_bytes<4, 1, 2, 3>(), out2, 70);
+                hipMemcpy(hb.data(), out2, hb.size() * 4, hipMemcpyDeviceToHost);
+                size_t bad = 0, first = 0;
+                for (size_t i = 0; i < ha.size(); ++i) if (memcmp(&ha[i], &hb[i], 4)) { if (!bad) first = i; ++bad; }
+                printf("persistent %s vs per-block kernel: %zu of %zu scores differ (first at q=%zu row=%zu)\n",
+                       v == 0 ? "QT5" : "QT4+leftover", bad, ha.size(), first / n, first % n);
+            }
+        }
     }
     return 0;
 }
