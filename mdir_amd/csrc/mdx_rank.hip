@@ -69,27 +69,40 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__
 {
     __shared__ uint32_t h[HIST_TILES][HIST_COPIES][RADIX + 1];
     const int tid = threadIdx.x, copy = tid & (HIST_COPIES - 1);
-#ifdef MDX_HIST_REVERSE
-    const int64_t q = blockIdx.y, b0 = ((int64_t)gridDim.x - 1 - blockIdx.x) * HIST_TILES;   // newest data first
-#else
-    const int64_t q = blockIdx.y, b0 = (int64_t)blockIdx.x * HIST_TILES;
-#endif
+    // pass 0 reads the scores newest rows first (the similarity kernel has just written them: the tail of its
+    // output is still in the Infinity Cache) and leaves the head cached for the scatter, which then runs forward
+    const int64_t q = FIRST ? (int64_t)gridDim.y - 1 - blockIdx.y : (int64_t)blockIdx.y;
+    const int64_t b0 = (FIRST ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x) * HIST_TILES;
     for (int e = tid; e < HIST_TILES * HIST_COPIES * (RADIX + 1); e += SORT_THREADS) (&h[0][0][0])[e] = 0;
     const int64_t base = q * n;
     uint32_t k[HIST_TILES][SORT_ITEMS];
+    // A histogram does not care which lane counts which element, so a lane takes 4 consecutive elements with one
+    // 16-byte load (dword-aligned: rows of an odd length start anywhere): a quarter of the memory requests.  It
+    // matters for pass 0, whose input comes from HBM (112 -> ~60 us); later passes find theirs in the caches.
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int VEC = SORT_ITEMS / 4;
 #pragma unroll
     for (int t = 0; t < HIST_TILES; ++t)
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = (b0 + t) * SORT_TILE + r * SORT_THREADS + tid;
-            k[t][r] = i < n ? load_key(scores, keys, base + i, FIRST) : 0u;
+        for (int v = 0; v < VEC; ++v) {
+            const int64_t i = (b0 + t) * SORT_TILE + (v * SORT_THREADS + tid) * 4;
+            u32x4u w = {0u, 0u, 0u, 0u};
+            if (i + 3 < n) {
+                w = *(const u32x4u *)(FIRST ? (const uint32_t *)scores + base + i : keys + base + i);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j < n) w[j] = FIRST ? ((const uint32_t *)scores)[base + i + j] : keys[base + i + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[t][v * 4 + j] = FIRST ? desc_key(__uint_as_float(w[j])) : w[j];
         }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < HIST_TILES; ++t)
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = (b0 + t) * SORT_TILE + r * SORT_THREADS + tid;
+            const int64_t i = (b0 + t) * SORT_TILE + ((r / 4) * SORT_THREADS + tid) * 4 + (r % 4);
             if (i < n) atomicAdd(&h[t][copy][(k[t][r] >> shift) & 255u], 1u);
         }
     __syncthreads();
@@ -153,7 +166,11 @@ __global__ __launch_bounds__(SCAN_GROUPS * SCAN_DIGITS) void sort_scan_kernel(ui
 // same digit, lower lane first) and keeps a running per-digit count in LDS.  The
 // tile is then put in digit order in LDS, so that consecutive lanes write
 // consecutive global addresses inside each digit run (coalesced scatter).
-template <bool FIRST, bool LAST>
+//
+// PACK (ids fit 24 bits, i.e. n <= 2^24): after three passes only the top key byte is still needed, so pass 2
+// (PACK = 1) writes ONE word per element, (top key byte : id), and the last pass (PACK = 2) reads one word:
+// 8 of the 76 bytes per element of the four passes are not moved at all.
+template <bool FIRST, bool LAST, int PACK = 0>
 __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAVES) / 4)) void sort_scatter_kernel(
     const float *__restrict__ scores, const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
@@ -168,11 +185,7 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
     __shared__ uint32_t skey[SORT_TILE];
     __shared__ uint32_t sval[SORT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifndef MDX_SORT_FORWARD
-    const int64_t q = (int64_t)gridDim.y - 1 - blockIdx.y;
-#else
-    const int64_t q = blockIdx.y;
-#endif
+    const int64_t q = FIRST ? (int64_t)blockIdx.y : (int64_t)gridDim.y - 1 - blockIdx.y;
     // Neighbouring tiles end their digit runs in the same cache lines.  Workgroups are dealt
     // round-robin over the 8 XCDs (speed only, never correctness), so give each XCD a
     // contiguous range of tiles: partial lines then meet in one L2 instead of two.
@@ -183,9 +196,7 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         b = (x < rn ? (int64_t)x * (qn + 1) : (int64_t)rn * (qn + 1) + (int64_t)(x - rn) * qn) + k;
     }
 #endif
-#ifndef MDX_SORT_FORWARD
-    b = (int64_t)nblk - 1 - b;      // the histogram pass just streamed the keys forward: the tail is still in the Infinity Cache
-#endif
+    if (!FIRST) b = (int64_t)nblk - 1 - b;  // the histogram pass just streamed the keys forward: the tail is still in the Infinity Cache
     for (int e = tid; e < SORT_WAVES * RADIX; e += SORT_THREADS) (&wcnt[0][0])[e] = 0;
     __syncthreads();
 
@@ -201,12 +212,41 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         gbase = block_hist[(q * nblk + b) * RADIX + tid];
         qtot = digit_tot[q * RADIX + tid];
     }
+    if (FIRST) {
+        // pass 0 reads the scores from HBM: 16-byte loads (a quarter of the memory requests: 317 -> 243 us); the keys
+        // go through LDS (skey is free until the tile is staged) to reach the (wave, round, lane) order the ranking
+        // is defined on.  Later passes find their input in the caches, where the same detour costs 6-30 us per pass.
+        typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int64_t i = sub0 + r * 64 + lane;
-        const bool valid = i < n;
-        key[r] = valid ? load_key(scores, keys_in, base + i, FIRST) : 0xFFFFFFFFu;
-        val[r] = FIRST ? (uint32_t)i : (valid ? vals_in[base + i] : 0u);
+        for (int v = 0; v < SORT_ITEMS / 4; ++v) {
+            const int e = (v * SORT_THREADS + tid) * 4;             // element of the tile
+            const int64_t i = tile0 + e;
+            u32x4u w = {0u, 0u, 0u, 0u};
+            if (i + 3 < n) {
+                w = *(const u32x4u *)((const uint32_t *)scores + base + i);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j < n) w[j] = ((const uint32_t *)scores)[base + i + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) skey[e + j] = desc_key(__uint_as_float(w[j]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = sub0 + r * 64 + lane;
+            key[r] = i < n ? skey[wave * SUB_TILE + r * 64 + lane] : 0xFFFFFFFFu;
+            val[r] = (uint32_t)i;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = sub0 + r * 64 + lane;
+            const bool valid = i < n;
+            key[r] = valid ? keys_in[base + i] : 0xFFFFFFFFu;
+            val[r] = PACK == 2 ? (key[r] & 0x00FFFFFFu) : (valid ? vals_in[base + i] : 0u);
+        }
     }
     if (tid < RADIX) {
         gdelta[tid] = gbase;
@@ -280,20 +320,22 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         const uint32_t d = (key[r] >> shift) & 255u;
         const uint32_t lp = scan[d] + wcnt[wave][d] + pos[r];
         skey[lp] = key[r];
-        sval[lp] = val[r];
+        if (PACK != 2) sval[lp] = val[r];
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int i = r * SORT_THREADS + tid;
         if (i >= tile_n) continue;
-        const uint32_t k = skey[i], v = sval[i];
+        const uint32_t k = skey[i], v = PACK == 2 ? (k & 0x00FFFFFFu) : sval[i];
         const int64_t dst = (int64_t)(uint32_t)(gdelta[(k >> shift) & 255u] + (uint32_t)i);
         if (LAST) {
             if (dst < klimit) {
                 if (ranks) ranks[q * klimit + dst] = (int64_t)v + id_offset;
                 if (top_scores) top_scores[q * klimit + dst] = scores[base + v];
             }
+        } else if (PACK == 1) {
+            keys_out[base + dst] = (k & 0xFF000000u) | v;
         } else {
             keys_out[base + dst] = k;
             vals_out[base + dst] = v;
@@ -450,6 +492,7 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
     RankWs ws;
     carve(&ws, (char *)workspace, n, nq);
     const dim3 grid((unsigned)ws.nblk, (unsigned)nq), blk(SORT_THREADS);
+    const bool pack = n <= (1ll << 24);         // ids fit 24 bits: (top key byte : id) in one word between passes 2 and 3
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 8 * pass;
         const uint32_t *kin = pass == 0 ? nullptr : ws.keys[(pass - 1) & 1];
@@ -468,8 +511,16 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
             hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, blk, 0, s, scores, kin, vin,
                                kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
                                ws.digit_tot, id_offset, klimit);
-        else if (pass < 3)
+        else if (pass == 1 || (pass == 2 && !pack))
             hipLaunchKernelGGL((sort_scatter_kernel<false, false>), grid, blk, 0, s, scores, kin, vin,
+                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
+                               ws.digit_tot, id_offset, klimit);
+        else if (pass == 2)
+            hipLaunchKernelGGL((sort_scatter_kernel<false, false, 1>), grid, blk, 0, s, scores, kin, vin,
+                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
+                               ws.digit_tot, id_offset, klimit);
+        else if (pack)
+            hipLaunchKernelGGL((sort_scatter_kernel<false, true, 2>), grid, blk, 0, s, scores, kin, vin,
                                kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
                                ws.digit_tot, id_offset, klimit);
         else
