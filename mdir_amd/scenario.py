@@ -47,50 +47,15 @@ def dict_deep_overlay(*data, list_replace=False):
     return overlay
 
 
-def validate_hash(content, path):
-    """A name ending in ``-<8+ hex digits>.<ext>`` promises the sha256 prefix of its content
-    (``mdir/tools/utils.py:27-34``); a mismatch is a ``ValueError``."""
-    import hashlib
-    import re
-    match = re.search(r".*-([a-f0-9]{8,})\.[a-zA-Z0-9]{2,}$", path)
-    if match:
-        stored = match.group(1)
-        computed = hashlib.sha256(content).hexdigest()[:len(stored)]
-        if computed != stored:
-            raise ValueError("Computed hash '%s' is not consistent with stored hash '%s'" % (computed, stored))
-
-
 def open_resource(path):
-    """Bytes of a checkpoint / whitening file given as a local path or a URL, hash-checked as
-    ``load_url`` does (``mdir/tools/utils.py:36-41``).  A URL is first looked up by file name in
-    ``$MDIR_AMD_MODELS`` and ``<data root>/networks`` (the MI355X boxes have no network: put the
-    published files there), and only then fetched."""
+    """Bytes of a checkpoint / whitening file.  Local paths only: the reference also accepts URLs and
+    downloads them (``mdir/tools/utils.py:36-41``); fetching models is outside this build (the MI355X
+    boxes have no network), so a URL is answered with an error that says where to put the file."""
     import io
-    if not (path.startswith("http://") or path.startswith("https://")):
-        with open(path, "rb") as handle:
-            return io.BytesIO(handle.read())
-    name = path.rsplit("/", 1)[1]
-    roots = [os.environ.get("MDIR_AMD_MODELS")]
-    try:
-        from .datasets import get_data_root
-        roots.append(os.path.join(get_data_root(), "networks"))
-    except Exception:
-        pass
-    for root in roots:
-        if root and os.path.isfile(os.path.join(root, name)):
-            with open(os.path.join(root, name), "rb") as handle:
-                content = handle.read()
-            validate_hash(content, path)
-            return io.BytesIO(content)
-    try:
-        from urllib.request import urlopen
-        with urlopen(path, timeout=20) as handle:
-            content = handle.read()
-    except Exception as err:
-        raise RuntimeError("cannot fetch '%s' (%s): place the file as %s under $MDIR_AMD_MODELS or %s"
-                           % (path, err, name, roots[-1] if roots[-1] else "<data root>/networks"))
-    validate_hash(content, path)
-    return io.BytesIO(content)
+    if path.startswith("http://") or path.startswith("https://"):
+        raise RuntimeError("'%s' is a URL: download it yourself and give the scenario the local path" % path)
+    with open(path, "rb") as handle:
+        return io.BytesIO(handle.read())
 
 
 def path_join(*paths):

@@ -392,56 +392,3 @@ def test_eval_py_two_processes_print_the_same_numbers(tmp_path):
     assert single == double, (single, double)
 
 
-def test_cirtorch_test_cli_end_to_end(tmp_path):
-    """`python -m mdir_amd.examples.test` (the upstream cirtorch CLI, second caller of the API):
-    multi-scale descriptors, learned whitening (whitenlearn on the fly), both mAP lines equal an
-    independent CPU pipeline built from torch-CPU features + the oracle + numpy statements."""
-    import re
-    from test_host_api import _reference_whitenlearn
-    root = str(tmp_path / "synth")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_eval.py"), root])
-    env = dict(os.environ, CIRTORCH_ROOT=root, MDIR_AMD_WORKERS="2", PYTHONPATH=ROOT)
-    proc = subprocess.run([sys.executable, "-m", "mdir_amd.examples.test", "--network-path",
-                           os.path.join(root, "net_cirtorch.pth"), "--datasets", "roxford5k", "--image-size", "320",
-                           "--multiscale", "[1, 1/2**(1/2), 1/2]", "--whitening", "retrieval-SfM-30k"],
-                          env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
-    assert proc.returncode == 0, proc.stdout[-3000:]
-    lines = [l for l in proc.stdout.splitlines() if "mAP E:" in l]
-    assert len(lines) == 2 and lines[1].startswith(">> roxford5k + whiten:"), proc.stdout[-2000:]
-    got = [[float(x) for x in re.findall(r"[EMH]: ([0-9.]+)", l)] for l in lines]
-    assert os.path.isfile(os.path.join(root, "net_cirtorch.pth_retrieval-SfM-30k_whiten_ms.pth"))
-
-    from mdir_amd.datasets import Compose, ImagesFromList, Normalize, ToTensor, configdataset
-    from mdir_amd.examples.test import cid2filename
-    from mdir_amd.networks import init_network
-    import torch.nn.functional as F
-    state = torch.load(os.path.join(root, "net_cirtorch.pth"), weights_only=False)
-    model = init_network({"architecture": "alexnet", "pretrained": False})
-    model.load_state_dict(state["state_dict"])
-    model.eval()
-    p = float(model.pool.p)
-    tr = Compose([ToTensor(), Normalize(model.meta["mean"], model.meta["std"])])
-
-    def describe(paths, bbxs=None):
-        vecs = []
-        for img in ImagesFromList("", paths, imsize=320, bbxs=bbxs, transform=tr):
-            per = []
-            for s in O.MS_SCALES:
-                x = img[None] if s == 1 else F.interpolate(img[None], scale_factor=float(s), mode="bilinear",
-                                                          align_corners=False)
-                with torch.no_grad():
-                    per.append(O.l2n(O.gem(model.features(x).numpy(), p))[0])
-            vecs.append(O.ms_aggregate(np.stack(per), p))
-        return np.stack(vecs, axis=1)
-
-    db = pickle.load(open(os.path.join(root, "data", "train", "retrieval-SfM-30k", "retrieval-SfM-30k-whiten.pkl"), "rb"))
-    wroot = os.path.join(root, "data", "train", "retrieval-SfM-30k", "ims")
-    m, P = _reference_whitenlearn(describe([cid2filename(c, wroot) for c in db["cids"]]), db["qidxs"], db["pidxs"])
-    cfg = configdataset("roxford5k", os.path.join(root, "data", "test"))
-    vecs = describe([cfg["im_fname"](cfg, i) for i in range(cfg["n"])])
-    qvecs = describe([cfg["qim_fname"](cfg, i) for i in range(cfg["nq"])], [tuple(g["bbx"]) if g["bbx"] else None for g in cfg["gnd"]])
-    want = []
-    for v, q in ((vecs, qvecs), (O.whitenapply(vecs, m, P), O.whitenapply(qvecs, m, P))):
-        avg, _ = O.compute_map_and_print("roxford5k", O.ranks(O.scores(v.astype(np.float32), q.astype(np.float32))), cfg["gnd"])
-        want.append([float(np.around(avg["map_" + k] * 100, decimals=2)) for k in ("easy", "medium", "hard")])
-    assert got == want, (got, want)

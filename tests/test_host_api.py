@@ -531,165 +531,63 @@ def test_whitening_learning(fops):
     assert np.allclose(L @ L.T, S, atol=1e-6)
 
 
-# ------------------------------------------------------------------ f2/f3: stage wrappers
+# ------------------------------------------------------------------ f2: embed stage
 
-def test_whitening_stages(fops):
-    """mdir/stages/whiten.py: whiten / learn_lw_whitening / learn_pca_whitening / paste_pca_normalize
-    keep the (params, data) -> (metadata, ...) protocol and the reference's arithmetic."""
-    from mdir_amd import stage_whiten as S
-    rng = np.random.default_rng(1)
-    D, N, npairs = 16, 300, 120
-    basis = np.linalg.qr(rng.standard_normal((D, D)))[0] * np.geomspace(2.0, 0.3, D)
-    values = (basis @ rng.standard_normal((D, N))).T.astype(np.float32)           # [N,D] as the stages carry them
-    values /= np.linalg.norm(values, axis=1, keepdims=True)
-    names = ["img%03d" % i for i in range(N)]
-    q = [names[i] for i in rng.choice(N, npairs, replace=False)]
-    p = [names[i] for i in rng.choice(N, npairs, replace=False)]
-    meta, Lw = S.learn_lw_whitening({}, (names, values, q, p), device="cpu")
-    assert meta["stats"] == {"failed_times": 0, "vectors_used": 1.0, "vectors_total": npairs}
-    assert set(meta) == {"stats", "timings", "resource_usage"} and "whitening_learn" in meta["timings"]
-    idx = {x: i for i, x in enumerate(names)}
-    mr, Pr = _reference_whitenlearn(values.astype(np.float64).T, np.array([idx[x] for x in q]), np.array([idx[x] for x in p]))
-    np.testing.assert_allclose(Lw["m"], mr, rtol=1e-6)
-    sign = np.sign(np.sum(Lw["P"] * Pr, axis=1, keepdims=True))
-    np.testing.assert_allclose(Lw["P"] * sign, Pr, rtol=2e-2, atol=2e-3)
-    # apply stage: [N,D] in, [N,d] out, unit rows, names passed through
-    meta, names_out, wh = S.whiten({"dimensions": 8}, (Lw, names, values), device="cpu")
-    assert names_out is names and wh.shape == (N, 8) and "whitening_apply" in meta["timings"]
-    X = (Lw["P"][:8] @ (values.T.astype(np.float64) - Lw["m"]))
-    np.testing.assert_allclose(wh, (X / (np.linalg.norm(X, axis=0, keepdims=True) + 1e-6)).T, rtol=1e-4, atol=1e-5)
-    with pytest.raises(AssertionError):
-        S.whiten({"dimensions": 8, "bogus": 1}, (Lw, names, values), device="cpu")
-    # pca
-    meta, pca = S.learn_pca_whitening({"shrink": None}, (values,), device="cpu")
-    Xw = pca["P"] @ (values.T.astype(np.float64) - pca["m"])
-    np.testing.assert_allclose(Xw @ Xw.T / N, np.eye(D), atol=5e-3)
-    # paste + pca + normalise: numpy restatement of whiten.py:90-118
-    a, b = values[:, :10].astype(np.float64), values[:, 10:].astype(np.float64)
-    meta, pasted = S.paste_pca_normalize({"dimensions": 5}, (a.copy(), b.copy()), device="cpu")
-    v = np.concatenate([a, b], axis=1)
-    v = v - np.mean(v)
-    ev, evec = np.linalg.eig(v.T.dot(v))
-    keep = evec[:, np.argsort(ev)[-5:]]
-    want = v.dot(keep.dot(keep.T))
-    want = want / np.linalg.norm(want, axis=1, keepdims=True)
-    np.testing.assert_allclose(pasted, want, rtol=1e-3, atol=1e-4)
-    assert "pca_compute" in meta["timings"]
-    meta, plain = S.paste_pca_normalize({"dimensions": None}, (a, b), device="cpu")
-    assert meta == {} and np.allclose(np.linalg.norm(plain, axis=1), 1.0)
-    assert S.paste_pca_normalize({"dimensions": None}, (np.empty((0,)),), device="cpu")[1].shape == (0,)
-
-
-def test_cirtorch_format_stages(fops, tmp_path, monkeypatch):
-    """mdir/stages/cirtorch_format/test.py: embed / learn_whitening / load_whitening /
-    convert_contained_net on an upstream-format checkpoint."""
+def test_embed_stage_on_upstream_checkpoint(fops, tmp_path, monkeypatch):
+    """`embed` (mdir/stages/cirtorch_format/test.py:17-89): images of a directory -> (metadata, names, [N,D] descriptors
+    [, whitened]) for an upstream-format checkpoint, equal to extract_vectors + the whitening formula."""
+    from PIL import Image
     from mdir_amd import cirtorch_format as C
     from mdir_amd.datasets import Compose, Normalize, ToTensor
-    from mdir_amd.network import load_network
     from mdir_amd.networks import extract_vectors, init_network
     monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
     rng = np.random.default_rng(5)
-    root = tmp_path / "data"
-    monkeypatch.setenv("CIRTORCH_ROOT", str(tmp_path))
-    # a whitening training set in the upstream layout: train/<name>/ims/<c[-2:]>/<c[-4:-2]>/<c[-6:-4]>/<cid>
-    name = "retrieval-SfM-30k"
-    cids = ["%032x" % int(x) for x in rng.integers(1, 2 ** 62, 12)]
-    for cid in cids:
-        path = C.cid2filename(cid, str(root / "train" / name / "ims"))
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        from PIL import Image
-        Image.fromarray(rng.integers(0, 255, (200, 240, 3), dtype=np.uint8)).save(path, format="JPEG")
-    db = {"cids": cids, "qidxs": [0, 1, 2, 3, 4, 5], "pidxs": [6, 7, 8, 9, 10, 11]}
-    with open(root / "train" / name / (name + "-whiten.pkl"), "wb") as f:
-        pickle.dump(db, f)
-    # upstream checkpoint with a stored whitening
+    imgdir = tmp_path / "ims"
+    imgdir.mkdir()
+    imgs = ["a%d.jpg" % i for i in range(4)]
+    for name in imgs:
+        Image.fromarray(rng.integers(0, 255, (200, 240, 3), dtype=np.uint8)).save(imgdir / name, format="JPEG")
     torch.manual_seed(2)
     net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False})
-    stored = {"m": rng.standard_normal((256, 1)), "P": rng.standard_normal((256, 256))}
     meta = {"architecture": "alexnet", "pooling": "gem", "whitening": False, "mean": net.meta["mean"], "std": net.meta["std"],
-            "outputdim": 256, "local_whitening": False, "regional": False,
-            "Lw": {name: {"ms": stored, "ss": {"m": stored["m"] + 1, "P": stored["P"]}}}}
+            "outputdim": 256, "local_whitening": False, "regional": False}
     ckpt = str(tmp_path / "upstream.pth")
     torch.save({"meta": meta, "state_dict": net.state_dict()}, ckpt)
+    wdir = tmp_path / "wh"
+    wdir.mkdir()
+    Lw = {"m": rng.normal(0, 0.01, (256, 1)), "P": np.linalg.qr(rng.standard_normal((256, 256)))[0]}
+    with open(wdir / "synth_None_192_True.lw.pkl", "wb") as f:
+        pickle.dump(Lw, f)
 
-    # load_whitening: both return styles, alias names
-    out = C.load_whitening({"net": ckpt, "whitening": "sfm30k", "multiscale": True}, ())
-    assert out[0] == {} and out[1] is not None and np.array_equal(out[1]["m"], stored["m"])
-    wdir = str(tmp_path / "wh")
-    assert C.load_whitening({"net": ckpt, "whitening": name, "multiscale": False, "whitening_dir": wdir, "image_size": 192}, ()) == ({},)
-    assert os.path.isfile(os.path.join(wdir, "%s_None_192_False.lw.pkl" % name))
-
-    # learn_whitening writes <whitening>_None_<size>_<multiscale>.lw.pkl and embed consumes it
-    meta_l, = C.learn_whitening({"net": ckpt, "whitening": "sfm30k", "whitening_dir": wdir, "image_size": 192,
-                                 "multiscale": True}, (), device="cpu")
-    assert set(meta_l) == {"whitening_learn"}
-    with open(os.path.join(wdir, "%s_None_192_True.lw.pkl" % name), "rb") as f:
-        Lw = pickle.load(f)
-    assert Lw["P"].shape == (256, 256) and Lw["m"].shape == (256, 1)
-    imgs = [os.path.relpath(C.cid2filename(c, "ims"), "ims") for c in cids[:4]]
-    imgdir = str(root / "train" / name / "ims")
-    res = C.embed({"net": ckpt, "imgdir": imgdir, "whitening": name, "whitening_dir": wdir, "image_size": 192,
+    res = C.embed({"net": ckpt, "imgdir": str(imgdir), "whitening": "synth", "whitening_dir": str(wdir), "image_size": 192,
                    "multiscale": True}, (imgs,), device="cpu")
     assert res[0] == {} and res[1] == imgs and res[2].shape == (4, 256) and res[3].shape == (4, 256)
     tr = Compose([ToTensor(), Normalize(net.meta["mean"], net.meta["std"])])
     with torch.no_grad():
-        want = extract_vectors(net.eval(), [os.path.join(imgdir, x) for x in imgs], 192, tr,
+        want = extract_vectors(net.eval(), [str(imgdir / x) for x in imgs], 192, tr,
                                ms=[1, 2 ** -0.5, 0.5], msp=float(net.pool.p), device="cpu").numpy()
     np.testing.assert_allclose(res[2], want.T, rtol=0, atol=1e-6)
     X = Lw["P"] @ (want.astype(np.float64) - Lw["m"])
     np.testing.assert_allclose(res[3], (X / (np.linalg.norm(X, axis=0, keepdims=True) + 1e-6)).T, rtol=1e-3, atol=1e-4)
-    assert C.embed({"net": ckpt, "imgdir": imgdir}, ([],)) == ({"status": "skipped"}, [], [])
-    assert C.embed({"net": ckpt, "imgdir": imgdir, "whitening_dir": wdir}, ([],)) == ({"status": "skipped"}, [], [], [])
-
-    # convert_contained_net -> a CirNetwork checkpoint that load_network reads
-    converted = str(tmp_path / "conv" / "net.pth")
-    assert C.convert_contained_net({"source": ckpt, "net": converted}, ()) == ({},)
-    state = torch.load(converted, weights_only=False)
-    assert state["type"] == "CirNetwork" and state["network_params"]["model"]["cir_architecture"] == "alexnet"
-    assert state["network_params"]["runtime"]["data"]["transforms"] == "pil2np | totensor | normalize"
-    loaded = load_network({"path": converted, "runtime": {}}, "cpu")
-    for k, v in net.state_dict().items():
-        assert torch.equal(loaded.model.state_dict()[k], v)
-    broken = str(tmp_path / "broken.pth")
-    torch.save({"meta": dict(meta, surprise=1), "state_dict": net.state_dict()}, broken)
+    plain = C.embed({"net": ckpt, "imgdir": str(imgdir), "image_size": 192, "multiscale": False}, (imgs,), device="cpu")
+    assert len(plain) == 3 and plain[2].shape == (4, 256)
+    assert C.embed({"net": ckpt, "imgdir": str(imgdir)}, ([],)) == ({"status": "skipped"}, [], [])
+    assert C.embed({"net": ckpt, "imgdir": str(imgdir), "whitening_dir": str(wdir)}, ([],)) == ({"status": "skipped"}, [], [], [])
     with pytest.raises(AssertionError):
-        C.convert_contained_net({"source": broken, "net": converted}, ())
+        C.embed({"net": ckpt, "imgdir": str(imgdir), "bogus": 1}, (imgs,), device="cpu")
 
 
-def test_url_resources_are_mirrored_and_hash_checked(tmp_path, monkeypatch):
-    """mdir/tools/utils.py:27-51: `...-<sha256 prefix>.<ext>` names are verified; URLs resolve from a
-    local mirror directory on boxes without a network."""
-    import hashlib
-    from mdir_amd.scenario import open_resource, validate_hash
+def test_resources_are_local_files(tmp_path):
+    """Checkpoints and whitening files are read from local paths; a URL (the reference would download it,
+    mdir/tools/utils.py:36-41) is refused with a message, never fetched."""
+    from mdir_amd.scenario import open_resource
     from mdir_amd.wrapper import load_path
-    payload = pickle.dumps({"m": np.zeros((2, 1)), "P": np.eye(2)})
-    good = hashlib.sha256(payload).hexdigest()[:8]
-    validate_hash(payload, "http://x/y/lw-%s.pkl" % good)
-    validate_hash(payload, "http://x/y/plain.pkl")                     # no hash in the name: nothing to check
-    with pytest.raises(ValueError, match="not consistent with stored hash"):
-        validate_hash(payload, "http://x/y/lw-%s.pkl" % ("0" * 8))
-    mirror = tmp_path / "models"
-    mirror.mkdir()
-    (mirror / ("lw-%s.pkl" % good)).write_bytes(payload)
-    (mirror / "lw-00000000.pkl").write_bytes(payload)
-    monkeypatch.setenv("MDIR_AMD_MODELS", str(mirror))
-    got = load_path("http://example.invalid/models/lw-%s.pkl" % good)
-    assert np.array_equal(got["P"], np.eye(2))
-    with pytest.raises(ValueError):
-        load_path("http://example.invalid/models/lw-00000000.pkl")
-    with pytest.raises(RuntimeError, match="MDIR_AMD_MODELS"):
+    payload = {"m": np.zeros((2, 1)), "P": np.eye(2)}
+    with open(tmp_path / "lw.pkl", "wb") as f:
+        pickle.dump(payload, f)
+    assert np.array_equal(load_path(str(tmp_path / "lw.pkl"))["P"], np.eye(2))
+    with pytest.raises(RuntimeError, match="is a URL"):
         open_resource("http://example.invalid/models/absent-12345678.pkl")
-    # the reference's three shortcut scenarios parse and overlay onto eval.yml
-    import importlib
-    import sys
-    from conftest import ROOT
-    sys.path.insert(0, ROOT)
-    ev = importlib.import_module("eval")
-    for shortcut in ("test", "clahe", "composition"):
-        sc = ev.load_scenarios([shortcut])
-        assert sc["network"]["path"].startswith("http://cmp.felk.cvut.cz/daynightretrieval/download/models/")
-        assert set(sc["network"]["runtime"]["wrappers"]["eval"]) == {"0_cirwhiten", "1_cirmultiscale"}
-        assert set(sc["validation"]) >= {"roxford5k", "rparis6k", "247tokyo1k"}
 
 
 def test_device_tail_detection_and_shape_order(tmp_path):

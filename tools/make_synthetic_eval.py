@@ -71,25 +71,6 @@ def main(root, arch="alexnet"):
     q, _ = np.linalg.qr(rng.standard_normal((d, d)))
     with open(os.path.join(root, "whiten.pkl"), "wb") as f:
         pickle.dump({"P": (q * rng.uniform(0.5, 2.0, (1, d))).T.copy(), "m": rng.normal(0, 0.01, (d, 1))}, f)
-    # upstream cirtorch checkpoint format + a whitening training set for `python -m mdir_amd.examples.test`
-    meta = {k: model.meta[k] for k in ("architecture", "pooling", "local_whitening", "regional", "whitening", "mean", "std")}
-    meta["outputdim"] = d
-    torch.save({"meta": meta, "state_dict": model.state_dict()}, os.path.join(root, "net_cirtorch.pth"))
-    wroot = os.path.join(root, "data", "train", "retrieval-SfM-30k")
-    nw = 330 if d <= 256 else 60                                # more matching pairs than dimensions, when cheap
-    cids = ["%012x" % (0xabc000 + 7 * i) for i in range(nw)]
-    for i, cid in enumerate(cids):
-        folder = os.path.join(wroot, "ims", cid[-2:], cid[-4:-2], cid[-6:-4])
-        os.makedirs(folder, exist_ok=True)
-        pat = 0.55 * base[i % len(base)] + 0.45 * rng.integers(0, 255, base[0].shape)
-        img = np.kron(pat, np.ones((28, 28, 1)))[:160, :208]
-        img = np.clip(img + rng.normal(0, 60, img.shape), 0, 255).astype(np.uint8)
-        Image.fromarray(img).save(os.path.join(folder, cid), format="JPEG", quality=92)
-    qidxs = list(range(0, nw - 2 * len(base)))
-    pidxs = [i + len(base) for i in qidxs]                      # same base pattern -> matching pair
-    with open(os.path.join(wroot, "retrieval-SfM-30k-whiten.pkl"), "wb") as f:
-        pickle.dump({"cids": cids, "qidxs": qidxs, "pidxs": pidxs}, f)
-
     overlay = {"network": {"path": os.path.join(root, "net.pth"),
                            "runtime": {"wrappers": {"eval": {"0_cirwhiten": {"whitening": os.path.join(root, "whiten.pkl")}}}}},
                "validation": {"roxford5k": {"criterion": {"image_size": 320}},
