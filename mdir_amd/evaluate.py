@@ -116,17 +116,29 @@ def positions_from_scores(scores, id_lists):
     return [pos[off[q]:off[q + 1]] for q in range(len(id_lists))]
 
 
+def labelled_lists(gnd, n):
+    """Per query ``(ok ids, junk ids, nok)`` for the sort-free route, with the meaning ``np.in1d`` gives them in
+    the reference (evaluate.py:80-81): an id listed twice occupies ONE rank position and an id that is not a
+    database row occupies none -- so the lists are made unique and restricted to ``[0, n)`` -- while the
+    normaliser stays ``len(ok)`` AS GIVEN (evaluate.py:101 passes ``len(qgnd)``).  Queries without positives
+    carry no junk either (they are skipped before junk is looked at, evaluate.py:68-72)."""
+    oks, junks, nok = [], [], []
+    for g in gnd:
+        ok = np.asarray(g["ok"], dtype=np.int64).reshape(-1)
+        junk = np.asarray(g["junk"], dtype=np.int64).reshape(-1) if "junk" in g and len(ok) else np.empty(0, dtype=np.int64)
+        nok.append(len(ok))
+        oks.append(np.unique(ok[(ok >= 0) & (ok < n)]))
+        junks.append(np.unique(junk[(junk >= 0) & (junk < n)]))
+    return oks, junks, nok
+
+
 def compute_map_from_scores(scores, gnd, kappas=[]):
     """:func:`compute_map` on scores ``[Q,N]`` (device) instead of a ranking."""
-    nq = len(gnd)
-    oks = [np.asarray(g["ok"], dtype=np.int64).reshape(-1) for g in gnd]
-    junks = [np.asarray(g["junk"], dtype=np.int64).reshape(-1) if "junk" in g else np.empty(0, dtype=np.int64)
-             for g in gnd]
-    junks = [j if len(o) else np.empty(0, dtype=np.int64) for o, j in zip(oks, junks)]
+    oks, junks, nok = labelled_lists(gnd, scores.shape[1])
     both = positions_from_scores(scores, [np.concatenate([o, j]) for o, j in zip(oks, junks)])
     pos_lists = [b[:len(o)] for b, o in zip(both, oks)]
     junk_lists = [b[len(o):] for b, o in zip(both, oks)]
-    return map_from_positions(pos_lists, junk_lists, [len(o) for o in oks], kappas)
+    return map_from_positions(pos_lists, junk_lists, nok, kappas)
 
 
 def _protocol_gnd(gnd, ok_keys, junk_keys):

@@ -119,7 +119,37 @@ class ShardedIndex:
         # RCCL moves device buffers directly; under gloo (CPU tests, or several ranks
         # sharing one GPU for a dry run) collectives are staged through host memory.
         self._host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
-        self._a2a_broken = os.environ.get("MDIR_AMD_EXCHANGE") == "allgather"
+        self._recv = {}                    # (chunk, elements) -> receive buffer of the exchange, allocated once
+        self.phases = None                 # events of the last rank_queries(): see phase_ms()
+        self._use_a2a = self._probe_all_to_all()
+
+    def _probe_all_to_all(self):
+        """Decide the exchange form ONCE, identically on every rank: a tiny UNEVEN all_to_all_single is run and
+        waited for, and the per-rank outcome is all-reduced with MIN.  (RCCL reports most failures at wait() or
+        from its watchdog, not at the call, and a rank that switched form alone would deadlock the others.)"""
+        if self.world == 1:
+            return True
+        ok = 0 if os.environ.get("MDIR_AMD_EXCHANGE") == "allgather" else 1
+        dev = "cpu" if self._host_staged else self.device
+        if ok:
+            try:
+                send = torch.arange(self.world * (self.world + 1) // 2, dtype=torch.float32, device=dev)
+                in_split = [r + 1 for r in range(self.world)]             # rank r receives r+1 elements from everybody
+                out_split = [self.rank + 1] * self.world
+                recv = torch.empty(sum(out_split), dtype=torch.float32, device=dev)
+                work = dist.all_to_all_single(recv, send, out_split, in_split, group=self.group, async_op=True)
+                work.wait()
+                if recv.is_cuda:
+                    torch.cuda.synchronize(recv.device)
+                lo = self.rank * (self.rank + 1) // 2
+                ok = int(bool((recv.cpu().view(self.world, -1) == torch.arange(lo, lo + self.rank + 1, dtype=torch.float32)).all()))
+            except (RuntimeError, NotImplementedError) as err:
+                import warnings
+                warnings.warn("all_to_all_single unavailable (%s)" % err)
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
 
     def _all_reduce_sum(self, t):
         if self._host_staged:
@@ -145,7 +175,7 @@ class ShardedIndex:
             out.append(b - a)
         return out
 
-    def _start_exchange(self, s_part, widths):
+    def _start_exchange(self, s_part, widths, chunk=0):
         """Enqueue the all-to-all that turns "all queries x my rows" into "my queries x every
         peer's rows" for one chunk.  Returns ``(work, recv, host_recv, keepalive)``; the
         collective runs on the communicator's own stream, so kernels launched next on the
@@ -155,22 +185,22 @@ class ShardedIndex:
         in_split = [(query_bounds(nq, self.world, r)[1] - query_bounds(nq, self.world, r)[0]) * s_part.shape[1]
                     for r in range(self.world)]
         out_split = [(qhi - qlo) * w for w in widths]
-        recv = torch.empty(sum(out_split), dtype=s_part.dtype, device=s_part.device)
+        key = (chunk, sum(out_split))
+        recv = self._recv.get(key)
+        if recv is None or recv.device != s_part.device:
+            recv = self._recv[key] = torch.empty(sum(out_split), dtype=s_part.dtype, device=s_part.device)
         if self._host_staged:
             send, host_recv = s_part.reshape(-1).cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-            work = dist.all_to_all_single(host_recv, send, out_split, in_split, group=self.group, async_op=True)
-            return work, recv, host_recv, send
+            if self._use_a2a:
+                work = dist.all_to_all_single(host_recv, send, out_split, in_split, group=self.group, async_op=True)
+                return work, recv, host_recv, send
+            s_part = s_part.cpu()
         send = s_part.reshape(-1)
-        if not self._a2a_broken:
-            try:
-                work = dist.all_to_all_single(recv, send, out_split, in_split, group=self.group, async_op=True)
-                return work, recv, None, send
-            except (RuntimeError, NotImplementedError) as err:
-                # a backend without uneven all-to-all: every rank all-gathers the (padded) blocks and
-                # keeps its own queries -- G times the bytes, same result
-                import warnings
-                warnings.warn("all_to_all_single refused (%s); falling back to all_gather" % err)
-                self._a2a_broken = True
+        if self._use_a2a:
+            work = dist.all_to_all_single(recv, send, out_split, in_split, group=self.group, async_op=True)
+            return work, recv, None, send
+        # the all-gather form (chosen by every rank in __init__): every rank gathers the (padded) blocks and keeps
+        # its own queries -- G times the bytes, same result
         wmax = max(widths)
         block = s_part if s_part.shape[1] == wmax else torch.cat(
             [s_part, s_part.new_zeros((nq, wmax - s_part.shape[1]))], dim=1)
@@ -212,13 +242,20 @@ class ShardedIndex:
             s = self.local_scores(queries, qlayout)
             return s, (0, s.shape[0])
         pending, nq = [], None
+        ev = self._events()
+        if ev:
+            ev[0].record()
         for c, (_, _, ix) in enumerate(self.parts):
             s_part = ix.scores(queries, qlayout)
             nq = s_part.shape[0]
             widths = self._peer_widths(c)
-            pending.append((self._start_exchange(s_part, widths), widths))
+            pending.append((self._start_exchange(s_part, widths, c), widths))
+        if ev:
+            ev[1].record()                                # similarity kernels enqueued up to here
         qlo, qhi = query_bounds(nq, self.world, self.rank)
         per_chunk = [self._finish_exchange(p, widths, qhi - qlo) for p, widths in pending]
+        if ev:
+            ev[2].record()                                # the compute stream has waited for the last transfer
         # global row order: peer-major, chunk-minor
         blocks = [per_chunk[c][r] for r in range(self.world) for c in range(self.chunks)]
         return torch.cat(blocks, dim=1), (qlo, qhi)
@@ -228,8 +265,30 @@ class ShardedIndex:
         with GLOBAL ids, scores [Q_mine, N], (qlo, qhi))``."""
         s_mine, (qlo, qhi) = self.exchanged_scores(queries, qlayout)
         if qhi == qlo:
-            return torch.empty((0, self.n_total), dtype=torch.int64, device=self.device), s_mine, (qlo, qhi)
-        return self.backend.rank_full(s_mine, 0), s_mine, (qlo, qhi)
+            ranks = torch.empty((0, self.n_total), dtype=torch.int64, device=self.device)
+        else:
+            ranks = self.backend.rank_full(s_mine, 0)
+        if self.phases:
+            self.phases[3].record()
+        return ranks, s_mine, (qlo, qhi)
+
+    def _events(self):
+        """Four events on the compute stream around the phases of ``rank_queries`` (GPU only)."""
+        if self.device.type != "cuda" or self.world == 1:
+            self.phases = None
+        elif self.phases is None:
+            self.phases = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        return self.phases
+
+    def phase_ms(self):
+        """``{"scores_ms", "exchange_exposed_ms", "sort_ms"}`` of the last ``rank_queries`` on this rank (call after a
+        synchronize).  ``exchange_exposed_ms`` = what the compute stream waited for transfers AFTER its last
+        similarity kernel (the re-block copy included); transfers hidden behind kernels do not show."""
+        if not self.phases:
+            return None
+        e = self.phases
+        return {"scores_ms": e[0].elapsed_time(e[1]), "exchange_exposed_ms": e[1].elapsed_time(e[2]),
+                "sort_ms": e[2].elapsed_time(e[3])}
 
     # ------------------------------------------------- all-gather of partial scores
     def all_scores(self, queries, qlayout="DN"):
@@ -370,7 +429,7 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
     slice of the database (which stays resident as its shard) and its slice of the queries, query
     descriptors are all-gathered, similarities are computed against the local shard, and mAP comes
     from the sort-free position counts.  Returns the same ``(averages, per_query)`` on every rank."""
-    from .evaluate import _evaluate, map_from_positions
+    from .evaluate import _evaluate, labelled_lists, map_from_positions
     import numpy as np
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if len(images) < world:
@@ -394,14 +453,12 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
     s_local = index.local_scores(qvecs.contiguous(), "ND")
 
     def one_map(g, kappas):
-        oks = [np.asarray(x["ok"], dtype=np.int64).reshape(-1) for x in g]
-        junks = [np.asarray(x["junk"], dtype=np.int64).reshape(-1) if "junk" in x and len(o) else
-                 np.empty(0, dtype=np.int64) for x, o in zip(g, oks)]
+        oks, junks, nok = labelled_lists(g, len(images))         # unique, in range: the meaning np.in1d gives them
         pos, off = index.positions(s_local, [np.concatenate([o, j]) for o, j in zip(oks, junks)])
         pos = pos.cpu().numpy()
         pl = [pos[off[q]:off[q] + len(oks[q])] for q in range(len(g))]
         jl = [pos[off[q] + len(oks[q]):off[q + 1]] for q in range(len(g))]
-        return map_from_positions(pl, jl, [len(o) for o in oks], kappas)
+        return map_from_positions(pl, jl, nok, kappas)
 
     result = _evaluate(dataset, gnd, [1, 5, 10], one_map)
     if lap:

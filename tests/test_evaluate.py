@@ -113,3 +113,30 @@ def test_compute_map_property_random_rankings():
         np.testing.assert_allclose(aps, want, rtol=0, atol=1e-12, equal_nan=True)
 
     check()
+
+
+def test_sort_free_route_with_repeated_and_foreign_ids(monkeypatch):
+    """A ground-truth list may repeat an id or name an id that is not a database row (user-supplied TSV
+    datasets).  The reference's np.in1d gives every rank position once and ignores foreign ids, while its
+    normaliser stays len(ok) as listed (evaluate.py:80-81,101): the sort-free route (positions from the
+    scores, CirDatasetAp's default) must return the same APs as compute_map on the ranking."""
+    import torch
+    import fake_ops
+    fake_ops.install(monkeypatch)
+    rng = np.random.default_rng(3)
+    n, nq = 40, 4
+    sc = rng.standard_normal((nq, n)).astype(np.float32)
+    rk = np.argsort(-sc, axis=1, kind="stable").T                                   # [N,Q]
+    gnd = [{"ok": [3, 3, 7, 9], "junk": [1, 2]},
+           {"ok": [4, 5], "junk": [5, 6, 6]},
+           {"ok": [8, n + 5, 11], "junk": [n, 0, -1]},                               # foreign ids on both lists
+           {"ok": [], "junk": [1]}]
+    want = O.compute_map(rk, gnd, [1, 5, 10])
+    got_ranking = E.compute_map(rk, gnd, [1, 5, 10])
+    got_scores = E.compute_map_from_scores(torch.from_numpy(sc), gnd, [1, 5, 10])
+    for a, b, c in zip(want, got_ranking, got_scores):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(c))
+    oks, junks, nok = E.labelled_lists(gnd, n)
+    assert [o.tolist() for o in oks] == [[3, 7, 9], [4, 5], [8, 11], []] and nok == [4, 2, 3, 0]
+    assert [j.tolist() for j in junks] == [[1, 2], [5, 6], [0], []]

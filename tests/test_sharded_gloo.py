@@ -98,7 +98,11 @@ def _worker(rank, world, port, n, nq, d, out_dir, chunks, exchange=None):
 
 
 @pytest.mark.parametrize("world,n,nq,chunks,exchange", [(2, 301, 7, 0, None), (3, 100, 2, 0, None), (2, 301, 7, 3, None),
-                                                        (3, 101, 5, 2, None), (3, 101, 5, 2, "allgather")])
+                                                        (3, 101, 5, 2, None), (3, 101, 5, 2, "allgather"),
+                                                        # the node's shapes: 70 queries over 4 and 8 ranks (uneven: 8.75 per rank),
+                                                        # shards of 8-9 rows against k = 9, fewer queries than ranks (idle sorters)
+                                                        (4, 203, 70, 0, None), (8, 71, 70, 0, None), (8, 203, 70, 2, None),
+                                                        (4, 101, 3, 0, "allgather")])
 def test_sharded_equals_single_process(tmp_path, world, n, nq, chunks, exchange):
     """chunks > 0: every shard is cut into row chunks whose all-to-alls are in flight together
     (the overlap pipeline used for big shards); exchange="allgather": the fallback taken when the
