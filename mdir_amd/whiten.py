@@ -28,31 +28,27 @@ def whitenapply(X, m, P, dimensions=None, device="cuda"):
 
 
 # ---------------------------------------------------------------------------
-# learning: the D x D products run on the GPU through the same
-# similarity kernel (rows of the left operand are the "database", rows of the right one the
-# "queries"); the small dense factorisations stay on the host, as in the reference.
+# learning.  The reference does all of it in float64 (whiten.py:37-53 on float64
+# descriptors): the low-variance directions of a 2048-d covariance sit below fp32 noise, so the two D x D Gram
+# matrices and the projection are float64 here too -- plain library GEMMs (rocBLAS dgemm on the f64 MFMA through
+# torch.matmul; the fp32 chain kernel of the hot path is NOT used for this offline step).  The small dense
+# factorisations stay on the host, as in the reference.
 # ---------------------------------------------------------------------------
 
-def _as_dev(a, device):
-    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=torch.device(device))
+def _as_f64(a, device):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=torch.device(device))
 
 
 def gram(A, device="cuda"):
-    """``A @ A.T`` for ``A [D,n]`` (fp32, k-ordered chain): the ``np.dot(df, df.T)`` of
-    ``whiten.py:42,46`` and the ``np.dot(Xc, Xc.T)`` of ``:22``."""
-    Ad = _as_dev(A, device)
-    shard = ops.DescriptorIndex(Ad, "ND")                       # D "database rows" of length n
-    out = shard.scores(Ad, "ND").cpu().numpy()                  # [D,D], symmetric by construction
-    shard.close()
-    return out
+    """``A @ A.T`` for ``A [D,n]`` in float64: the ``np.dot(df, df.T)`` of ``whiten.py:42,46`` and the
+    ``np.dot(Xc, Xc.T)`` of ``:22``."""
+    Ad = _as_f64(A, device)
+    return (Ad @ Ad.t()).cpu().numpy()
 
 
 def project(P, X, m, device="cuda"):
-    """``np.dot(P, X - m)`` for ``X [D,N]``: returns ``[D_out, N]`` (``whiten.py:45``)."""
-    shard = ops.DescriptorIndex(_as_dev(P, device), "ND")
-    y = shard.scores(_as_dev(X, device), "DN", center=_as_dev(np.asarray(m).reshape(-1), device))    # [N, D_out]
-    shard.close()
-    return np.ascontiguousarray(y.cpu().numpy().T)
+    """``np.dot(P, X - m)`` for ``X [D,N]`` in float64: returns ``[D_out, N]`` (``whiten.py:45``)."""
+    return (_as_f64(P, device) @ (_as_f64(X, device) - _as_f64(np.asarray(m).reshape(-1, 1), device))).cpu().numpy()
 
 
 def cholesky(S):

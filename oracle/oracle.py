@@ -320,6 +320,100 @@ def compute_map_and_print(dataset, rk, gnd, kappas=(1, 5, 10)):
     return None
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Rows SURVEY.md section 8 marks "next" (f1-f3) and the image loader (a1); pinned by tests/golden g12-g15
+# ---------------------------------------------------------------------------------------------------------
+
+def cholesky_bumped(S):
+    """``cholesky`` of cirtorch/utils/whiten.py:55-70: retry with 1e-10, 1e-9, ... added to the diagonal until S is
+    positive definite (the reference also prints a line per retry)."""
+    alpha = 0
+    while True:
+        try:
+            return np.linalg.cholesky(S + alpha * np.eye(*S.shape))
+        except np.linalg.LinAlgError:
+            alpha = 1e-10 if alpha == 0 else alpha * 10
+
+
+def whitenlearn(X, qidxs, pidxs):
+    """cirtorch/utils/whiten.py:37-53: ``(m [D,1], P [D,D])`` from matching pairs, float64 throughout."""
+    m = X[:, qidxs].mean(axis=1, keepdims=True)
+    df = X[:, qidxs] - X[:, pidxs]
+    S = np.dot(df, df.T) / df.shape[1]
+    P = np.linalg.inv(cholesky_bumped(S))
+    df = np.dot(P, X - m)
+    D = np.dot(df, df.T)
+    eigval, eigvec = np.linalg.eig(D)
+    eigvec = eigvec[:, eigval.argsort()[::-1]]
+    return m, np.dot(eigvec.T, P)
+
+
+def pcawhitenlearn(X, shrink=None):
+    """cirtorch/utils/whiten.py:14-35: PCA whitening without annotations, optional eigenvalue shrinkage."""
+    N = X.shape[1]
+    m = X.mean(axis=1, keepdims=True)
+    Xc = X - m
+    Xcov = np.dot(Xc, Xc.T)
+    Xcov = (Xcov + Xcov.T) / (2 * N)
+    eigval, eigvec = np.linalg.eig(Xcov)
+    order = eigval.argsort()[::-1]
+    eigval, eigvec = eigval[order], eigvec[:, order]
+    if shrink:
+        b = eigval[shrink - 1]
+        eigval = (1 - b) * eigval + b
+    return m, np.dot(np.linalg.inv(np.sqrt(np.diag(eigval))), eigvec.T)
+
+
+def hard_negatives(qvecs, poolvecs, idxs2images, clusters, qidxs, nnum):
+    """The selection of cirtorch/datasets/traindataset.py:242-270: scores = poolvecs^T qvecs, sorted descending per
+    query; walk the ranking taking pool images of clusters not seen yet (the query's own cluster counts as seen)
+    until ``nnum`` are found; the l2 distance of each pick is ``sqrt(sum((q - p + 1e-6)^2))``."""
+    sc = np.dot(poolvecs.T, qvecs)                             # [P,Q]
+    order = np.argsort(-sc, axis=0, kind="stable")
+    nidxs, ndist = [], []
+    for q in range(len(qidxs)):
+        seen, picks, r = [clusters[qidxs[q]]], [], 0
+        while len(picks) < nnum:
+            col = order[r, q]
+            img = int(idxs2images[col])
+            if clusters[img] not in seen:
+                picks.append(img)
+                seen.append(clusters[img])
+                ndist.append(float(np.sqrt(np.sum((qvecs[:, q] - poolvecs[:, col] + np.float32(1e-6)) ** 2, dtype=np.float32))))
+            r += 1
+        nidxs.append(picks)
+    return nidxs, ndist
+
+
+def embedding_output(nimages, rows):
+    """``EmbeddingOutput`` of mdir/components/data/output.py:117-139: ``rows`` = per image a 1-D descriptor or None
+    (unreadable); float64 ``[N,D]`` with NaN rows; ``[]`` when nothing was ever added."""
+    out = None
+    for i, v in enumerate(rows):
+        if v is None:
+            out[i, :] = np.nan                                 # like the reference: needs a readable image before it
+            continue
+        if out is None:
+            out = np.zeros((nimages, len(v)))
+        out[i, :] = np.asarray(v)
+    return out if out is not None else []
+
+
+def load_image(path, imsize=None, bbx=None):
+    """``ImagesFromList.__getitem__`` of cirtorch/datasets/genericdataset.py:44-70 without the transform: RGB decode
+    (datahelpers.py:24-31), crop to ``bbx = (x1,y1,x2,y2)`` if given, then ``thumbnail((imsize, imsize))`` with the
+    filter Pillow called ANTIALIAS until 9.5 and LANCZOS since (datahelpers.py:48-50): aspect-preserving, never
+    enlarges.  Returns uint8 ``[H,W,3]``."""
+    from PIL import Image
+    with open(path, "rb") as f:
+        img = Image.open(f).convert("RGB")
+    if bbx:
+        img = img.crop(bbx)
+    if imsize is not None:
+        img.thumbnail((imsize, imsize), Image.LANCZOS)
+    return np.asarray(img).copy()
+
+
 def nanmean_metric(per_query):
     """The number eval.py prints: nan-filtered mean of the per-query rows
     (``mdir/tools/eventprocessor.py:101-115``)."""

@@ -334,9 +334,142 @@ def main():
                                 if False else _jsonable(c["over"]), "result": _jsonable(c["result"])}
                                for c in overlay],
                    "list_merge_raises": list_err, "three_way": three, "metadata": meta_out}, f, indent=1)
+    make_next_rows()
     print("golden fixtures written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-28s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))
+
+
+def make_next_rows():
+    """G12-G15: the rows SURVEY.md section 8 marks "next" (f1 mining, f2 embedding output, f3 whitening learning) and the
+    image loader (a1).  Same rule: the reference is imported and RUN; only inputs and its outputs are stored."""
+    import io
+    from PIL import Image
+    # ---- G12 whitening learning (cirtorch/utils/whiten.py:14-70) ------------------------------------------------
+    from cirtorch.utils.whiten import cholesky, pcawhitenlearn, whitenlearn
+    rng = np.random.default_rng(12)
+    D, N, npairs = 24, 300, 140
+    basis = np.linalg.qr(rng.standard_normal((D, D)))[0] * np.geomspace(2.0, 0.2, D)
+    X = basis @ rng.standard_normal((D, N))
+    X /= np.linalg.norm(X, axis=0, keepdims=True)                     # [D,N] float64 unit columns
+    qidxs = rng.choice(N, npairs, replace=False)
+    pidxs = rng.choice(N, npairs, replace=False)
+    X[:, pidxs] = X[:, qidxs] + 0.15 * rng.standard_normal((D, npairs))      # matching pairs are close
+    X /= np.linalg.norm(X, axis=0, keepdims=True)
+    m_lw, P_lw = whitenlearn(X.copy(), qidxs, pidxs)
+    m_pca, P_pca = pcawhitenlearn(X.copy())
+    _, P_shr = pcawhitenlearn(X.copy(), shrink=8)
+    S_sing = np.ones((3, 3))
+    with open(os.devnull, "w") as sink:
+        old, sys.stdout = sys.stdout, sink
+        try:
+            L_sing = cholesky(S_sing)
+        finally:
+            sys.stdout = old
+    S_pd = np.cov(rng.standard_normal((5, 40)))
+    np.savez_compressed(os.path.join(HERE, "g12_whitenlearn.npz"), X=X, qidxs=qidxs, pidxs=pidxs, m_lw=m_lw, P_lw=P_lw,
+                        m_pca=m_pca, P_pca=np.real(P_pca), P_pca_shrink8=np.real(P_shr), S_singular=S_sing, L_singular=L_sing,
+                        S_pd=S_pd, L_pd=cholesky(S_pd))
+
+    # ---- G13 hard-negative selection (cirtorch/datasets/traindataset.py:178-271) -----------------------------------
+    import torch.nn as nn
+    from cirtorch.datasets.traindataset import TuplesDataset
+    rng = np.random.default_rng(13)
+    nimg, nclusters, dim = 90, 12, 16
+    tmp = tempfile.mkdtemp()
+    proto = rng.integers(0, 255, (nclusters, 12, 16, 3))
+    clusters = rng.integers(0, nclusters, nimg).tolist()
+    images = []
+    for i in range(nimg):
+        arr = np.clip(0.6 * proto[clusters[i]] + 0.4 * rng.integers(0, 255, (12, 16, 3)), 0, 255).astype(np.uint8)
+        path = os.path.join(tmp, "im%03d.png" % i)
+        Image.fromarray(np.kron(arr, np.ones((4, 4, 1), dtype=np.uint8))).save(path)
+        images.append(path)
+
+    class ToyNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(5)
+            self.conv = nn.Conv2d(3, dim // 4, 5, stride=3)
+            self.meta = {"out_channels": dim}
+
+        def forward(self, x):
+            v = torch.relu(self.conv(x - 0.5))
+            v = nn.functional.adaptive_avg_pool2d(v, 2).flatten(1)          # [1, dim]: 4 channels x 2 x 2 cells
+            v = v - v.mean(dim=1, keepdim=True)
+            return (v / v.norm(dim=1, keepdim=True)).t()
+
+    to_tensor = lambda img: torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255.0
+    ds = object.__new__(TuplesDataset)
+    pairs = [(a, b) for a in range(nimg) for b in range(nimg) if a < b and clusters[a] == clusters[b]][:60]
+    ds.name, ds.mode, ds.imsize, ds.transform, ds.print_freq = "toy", "train", None, to_tensor, 1000
+    ds.images, ds.clusters = images, clusters
+    ds.qpool, ds.ppool = [a for a, _ in pairs], [b for _, b in pairs]
+    ds.qsize, ds.poolsize, ds.nnum = 14, 50, 4
+    drawn = []
+    real_randperm = torch.randperm
+    torch.randperm = lambda n: drawn.append(real_randperm(n)) or drawn[-1]
+    torch.manual_seed(77)
+    net = ToyNet()
+    torch.manual_seed(77)
+    with open(os.devnull, "w") as sink:
+        old, sys.stdout = sys.stdout, sink
+        try:
+            stats = ds.create_epoch_tuples(net, device=torch.device("cpu"))
+        finally:
+            sys.stdout = old
+            torch.randperm = real_randperm
+    idxs2images = drawn[1][:ds.poolsize].numpy()
+    with torch.no_grad():
+        describe = lambda ids: torch.cat([net(to_tensor(Image.open(images[i]).convert("RGB"))[None]) for i in ids], dim=1)
+        qvecs, poolvecs = describe(ds.qidxs), describe(idxs2images.tolist())
+    np.savez_compressed(os.path.join(HERE, "g13_mining.npz"), qvecs=qvecs.numpy(), poolvecs=poolvecs.numpy(),
+                        idxs2images=idxs2images, clusters=np.array(clusters), qidxs=np.array(ds.qidxs), pidxs=np.array(ds.pidxs),
+                        nnum=np.int64(ds.nnum), nidxs=np.array([[int(x) for x in row] for row in ds.nidxs]),
+                        ndist=np.array(stats["average_negative_distance"]))
+
+    # ---- G14 EmbeddingOutput (mdir/components/data/output.py:117-139) --------------------------------------------------
+    from mdir.components.data.output import EmbeddingOutput
+    rng = np.random.default_rng(14)
+    names = ["a.jpg", "b.jpg", "c.jpg", "d.jpg"]
+    vec = rng.standard_normal((4, 6)).astype(np.float32)
+    out = EmbeddingOutput((names,), {})
+    out.add(0, object(), torch.from_numpy(vec[0]))
+    out.add(1, None, None)                              # unreadable image
+    out.add(2, object(), torch.from_numpy(vec[2]))
+    out.add(3, object(), torch.from_numpy(vec[3]))
+    res_names, res = out.postprocess()
+    boxes = [None, (1, 2, 3, 4), None, None]
+    out_b = EmbeddingOutput((names, boxes), {}, bbxs=True)
+    empty = EmbeddingOutput((names,), {}).postprocess()
+    np.savez_compressed(os.path.join(HERE, "g14_embedding_output.npz"), vec=vec, result=res, result_dtype=str(res.dtype),
+                        names=np.array(res_names), preprocess_bbxs=np.array([repr(out_b.preprocess())]),
+                        empty_second=np.array([repr(empty[1])]))
+
+    # ---- G15 image loader (cirtorch/datasets/genericdataset.py:44-70, datahelpers.py:24-50) ---------------------------
+    # Pillow >= 10 has no Image.ANTIALIAS; it was an alias of LANCZOS (Pillow 2.7 - 9.5), restored here for the reference
+    Image.ANTIALIAS = Image.LANCZOS
+    from cirtorch.datasets.genericdataset import ImagesFromList
+    rng = np.random.default_rng(15)
+    g15 = {}
+    files = {}
+    for name, (h, w) in (("landscape", (150, 221)), ("portrait", (203, 97)), ("small", (40, 30))):
+        yy, xx = np.mgrid[0:h, 0:w]
+        arr = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx * 7 + yy * 13) % 256)], axis=2)
+        arr = np.clip(arr + rng.integers(-20, 20, arr.shape), 0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(arr).save(buf, format="PNG")
+        files[name] = buf.getvalue()
+        g15["file_" + name] = np.frombuffer(files[name], dtype=np.uint8)
+        with open(os.path.join(tmp, name + ".png"), "wb") as f:
+            f.write(files[name])
+    cases = [("landscape", 64, None), ("landscape", 64, (10, 20, 200, 140)), ("portrait", 64, None), ("portrait", 100, (5, 5, 90, 60)),
+             ("small", 64, None), ("landscape", None, (0, 0, 17, 9))]
+    for ci, (name, imsize, bbx) in enumerate(cases):
+        dsl = ImagesFromList(root=tmp, images=[name + ".png"], imsize=imsize, bbxs=[bbx], transform=lambda im: np.asarray(im).copy())
+        g15["case%d_out" % ci] = dsl[0]
+        g15["case%d_spec" % ci] = np.array([repr((name, imsize, bbx))])
+    np.savez_compressed(os.path.join(HERE, "g15_loader.npz"), **g15)
 
 
 def _jsonable(o):

@@ -244,12 +244,17 @@ def test_full_size_shards_equal_whole(big):
         assert bool((cnt[off[qi]:off[qi + 1]] == inv[qi][ids_t[off[qi]:off[qi + 1]]]).all())
 
 
-def test_hard_negative_mining_on_gpu():
-    """f1 (traindataset.py:242-270): pool 20 000 x 300 queries; selections equal the reference's
-    torch.mm + torch.sort + walk restated on the CPU."""
+def test_hard_negative_mining_on_gpu(golden):
+    """f1 on the device (mdx_scores + mdx_topk + the walk): golden G13 = the reference's create_epoch_tuples on a toy
+    pool, then a mining-sized problem against the oracle restatement that G13 pins."""
     from mdir_amd.mining import search_hard_negatives
-    from test_host_api import _reference_mining
-    rng = np.random.default_rng(4)
+    g = golden("g13_mining.npz")
+    for prefix in (None, 3):
+        nidxs, ndist = search_hard_negatives(dev(g["qvecs"]), dev(g["poolvecs"]), g["idxs2images"], g["clusters"].tolist(),
+                                             g["qidxs"].tolist(), int(g["nnum"]), prefix=prefix)
+        assert nidxs == g["nidxs"].tolist()
+        np.testing.assert_allclose(ndist, g["ndist"], rtol=1e-5)
+    rng = np.random.default_rng(9)
     D, P, Q, nimg = 512, 20000, 300, 60000
     pool = rng.standard_normal((P, D)).astype(np.float32)
     pool /= np.linalg.norm(pool, axis=1, keepdims=True)
@@ -260,18 +265,21 @@ def test_hard_negative_mining_on_gpu():
     qidxs = rng.choice(nimg, Q, replace=False).tolist()
     qvecs, poolvecs = np.ascontiguousarray(qv.T), np.ascontiguousarray(pool.T)
     got, gd = search_hard_negatives(dev(qvecs), dev(poolvecs), idxs2images, clusters, qidxs, 5)
-    want, wd = _reference_mining(torch.from_numpy(qvecs), torch.from_numpy(poolvecs), idxs2images, clusters, qidxs, 5)
+    want, wd = O.hard_negatives(qvecs, poolvecs, idxs2images, clusters, qidxs, 5)
     assert got == want
     np.testing.assert_allclose(gd, wd, rtol=1e-4)
 
 
-def test_infer_and_whitening_learning_on_gpu(tmp_path):
-    """f2 + f3 on the device: infer stage -> float64 embeddings (NaN row for a missing file);
-    whitenlearn on them whitens the matching-pair differences; gram is the exact k-chain."""
+def test_infer_and_whitening_learning_on_gpu(tmp_path, golden):
+    """f2 + f3 on the device.  infer stage -> float64 embeddings, NaN row for a missing file, every other row equal to
+    extract_vectors of the same network (EmbeddingOutput itself is pinned by golden G14 in the CPU suite);
+    whitenlearn / pcawhitenlearn on the device reproduce the reference's (m, P) of golden G12."""
     from mdir_amd import stages
+    from mdir_amd.datasets import initialize_transforms
     from mdir_amd.network import CirNetwork, SingleNetwork
-    from mdir_amd.networks import init_network
-    from mdir_amd.whiten import gram, whitenlearn
+    from mdir_amd.networks import extract_vectors, init_network
+    from mdir_amd.stages import EmbeddingOutput
+    from mdir_amd.whiten import pcawhitenlearn, whitenlearn
     from test_host_api import _write_images
     rng = np.random.default_rng(3)
     names = ["im%02d" % i for i in range(12)]
@@ -293,21 +301,41 @@ def test_infer_and_whitening_learning_on_gpu(tmp_path):
     import os
     os.environ["MDIR_AMD_WORKERS"] = "2"
     meta, imgs_out, vecs = stages.infer(params, (images,))
-    assert vecs.shape == (13, 256) and vecs.dtype == np.float64 and np.isnan(vecs[5]).all()
+    assert imgs_out == images and vecs.shape == (13, 256) and vecs.dtype == np.float64 and np.isnan(vecs[5]).all()
     good = np.delete(vecs, 5, axis=0)
     np.testing.assert_allclose(np.linalg.norm(good, axis=1), 1.0, atol=1e-5)
+    tr = initialize_transforms("pil2np | totensor | normalize", net.network_params.runtime["data"]["mean_std"])
+    gpu_net = stages.load_network(params["network"], DEV).eval()
+    with torch.no_grad():
+        want = extract_vectors(gpu_net, [str(tmp_path / "imgs" / (n + ".jpg")) for n in names], 224, tr, device=DEV).numpy()
+    np.testing.assert_allclose(good, want.T, rtol=0, atol=2e-6)
+    # EmbeddingOutput fed with DEVICE tensors gives the golden matrix
+    g14 = golden("g14_embedding_output.npz")
+    out = EmbeddingOutput(([str(x) for x in g14["names"]],), {})
+    for i in (0, 2, 3):
+        out.add(i, True, dev(g14["vec"][i]))
+    out.add(1, None, None)
+    np.testing.assert_array_equal(out.postprocess()[1], g14["result"])
 
+    g = golden("g12_whitenlearn.npz")
+    up = lambda a, b: a * np.sign(np.sum(a * b, axis=1, keepdims=True))
+    m, P = whitenlearn(g["X"], g["qidxs"], g["pidxs"])                   # device = "cuda": float64 GEMMs on the GPU
+    np.testing.assert_allclose(m, g["m_lw"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(up(P, g["P_lw"]), g["P_lw"], rtol=1e-7, atol=1e-9)
+    m2, P2 = pcawhitenlearn(g["X"], shrink=8)
+    np.testing.assert_allclose(up(np.real(P2), g["P_pca_shrink8"]), g["P_pca_shrink8"], rtol=1e-7, atol=1e-9)
+    # a retrieval-sized problem: the learned projection whitens the matching-pair differences
     rng = np.random.default_rng(0)
-    D, N, npairs = 64, 3000, 1000
-    basis = np.linalg.qr(rng.standard_normal((D, D)))[0] * np.geomspace(3.0, 0.2, D)
-    X = (basis @ rng.standard_normal((D, N))).astype(np.float32)
+    D, N, npairs = 256, 6000, 2500
+    basis = np.linalg.qr(rng.standard_normal((D, D)))[0] * np.geomspace(3.0, 0.05, D)
+    X = basis @ rng.standard_normal((D, N))
     X /= np.linalg.norm(X, axis=0, keepdims=True)
     qidxs, pidxs = rng.choice(N, npairs, replace=False), rng.choice(N, npairs, replace=False)
-    A = np.ascontiguousarray(X[:, :777])
-    np.testing.assert_array_equal(gram(A), OC.gemm_nt_chain(A, A))
     m, P = whitenlearn(X, qidxs, pidxs)
+    mo, Po = O.whitenlearn(X, qidxs, pidxs)                              # pinned by G12
+    np.testing.assert_allclose(up(P, Po), Po, rtol=1e-5, atol=1e-7)
     dfw = P @ (X[:, qidxs] - X[:, pidxs])
-    np.testing.assert_allclose(dfw @ dfw.T / npairs, np.eye(D), atol=5e-3)
+    np.testing.assert_allclose(dfw @ dfw.T / npairs, np.eye(D), atol=1e-8)
 
 
 def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):

@@ -398,22 +398,15 @@ def test_checkpoint_roundtrip_and_validate_tree(fops, tmp_path, monkeypatch):
 
 # ------------------------------------------------------------------ f1: hard-negative mining
 
-def _reference_mining(qvecs, poolvecs, idxs2images, clusters, qidxs, nnum):
-    """The statement sequence of traindataset.py:242-270 restated with torch on CPU."""
-    scores = torch.mm(poolvecs.t(), qvecs)
-    scores, ranks = torch.sort(scores, dim=0, descending=True)
-    nidxs_all, nd = [], []
-    for q in range(len(qidxs)):
-        seen, nidxs, r = [clusters[qidxs[q]]], [], 0
-        while len(nidxs) < nnum:
-            potential = int(idxs2images[ranks[r, q]])
-            if clusters[potential] not in seen:
-                nidxs.append(potential)
-                seen.append(clusters[potential])
-                nd.append(float(torch.pow(qvecs[:, q] - poolvecs[:, ranks[r, q]] + 1e-6, 2).sum(dim=0).sqrt()))
-            r += 1
-        nidxs_all.append(nidxs)
-    return nidxs_all, nd
+def test_hard_negative_search_golden(fops, golden):
+    """Golden G13: the reference's create_epoch_tuples (traindataset.py:178-271) run on a toy pool."""
+    from mdir_amd.mining import search_hard_negatives
+    g = golden("g13_mining.npz")
+    for prefix in (None, 3):                                    # 3 forces the prefix-doubling path
+        nidxs, ndist = search_hard_negatives(torch.from_numpy(g["qvecs"]), torch.from_numpy(g["poolvecs"]), g["idxs2images"],
+                                             g["clusters"].tolist(), g["qidxs"].tolist(), int(g["nnum"]), prefix=prefix)
+        assert nidxs == g["nidxs"].tolist()
+        np.testing.assert_allclose(ndist, g["ndist"], rtol=1e-5)
 
 
 def test_hard_negative_search_matches_reference_statements(fops):
@@ -430,7 +423,7 @@ def test_hard_negative_search_matches_reference_statements(fops):
     qvecs, poolvecs = torch.from_numpy(np.ascontiguousarray(qv.T)), torch.from_numpy(np.ascontiguousarray(pool.T))
     for nnum, prefix in ((5, None), (3, 4), (0, None)):     # prefix 4 forces the doubling path
         got, gd = search_hard_negatives(qvecs, poolvecs, idxs2images, clusters, qidxs, nnum, prefix=prefix)
-        want, wd = _reference_mining(qvecs, poolvecs, idxs2images, clusters, qidxs, nnum)
+        want, wd = O.hard_negatives(qvecs.numpy(), poolvecs.numpy(), idxs2images, clusters, qidxs, nnum)   # pinned by G13
         assert got == want
         np.testing.assert_allclose(gd, wd, rtol=1e-5)
     with pytest.raises(IndexError):
@@ -479,56 +472,32 @@ def test_infer_stage_embedding_output(fops, tmp_path, monkeypatch):
 
 # ------------------------------------------------------------------ f3: whitening learning
 
-def _reference_whitenlearn(X, qidxs, pidxs):
-    """whiten.py:37-53 restated with numpy only."""
-    m = X[:, qidxs].mean(axis=1, keepdims=True)
-    df = X[:, qidxs] - X[:, pidxs]
-    S = np.dot(df, df.T) / df.shape[1]
-    alpha = 0                                              # whiten.py:55-70: bump the diagonal until PD
-    while True:
-        try:
-            L = np.linalg.cholesky(S + alpha * np.eye(*S.shape))
-            break
-        except np.linalg.LinAlgError:
-            alpha = 1e-10 if alpha == 0 else alpha * 10
-    P = np.linalg.inv(L)
-    df = np.dot(P, X - m)
-    D = np.dot(df, df.T)
-    eigval, eigvec = np.linalg.eig(D)
-    eigvec = eigvec[:, eigval.argsort()[::-1]]
-    return m, np.dot(eigvec.T, P)
-
-
-def test_whitening_learning(fops):
+def test_whitening_learning(fops, golden):
+    """Golden G12: the reference's whitenlearn / pcawhitenlearn / cholesky (cirtorch/utils/whiten.py:14-70) on float64
+    descriptors; rows of P are eigenvector-derived, hence compared up to sign."""
     from mdir_amd.whiten import cholesky, gram, pcawhitenlearn, project, whitenapply, whitenlearn
-    rng = np.random.default_rng(0)
-    D, N, npairs = 24, 400, 150
-    basis = np.linalg.qr(rng.standard_normal((D, D)))[0] * np.geomspace(3.0, 0.2, D)
-    X = (basis @ rng.standard_normal((D, N))).astype(np.float32)
-    X /= np.linalg.norm(X, axis=0, keepdims=True)
-    qidxs, pidxs = rng.choice(N, npairs, replace=False), rng.choice(N, npairs, replace=False)
-    A = X[:, :50]
-    np.testing.assert_allclose(gram(A, "cpu"), A @ A.T, rtol=1e-5, atol=1e-6)
-    Pm, mm = rng.standard_normal((D, D)).astype(np.float32), rng.standard_normal((D, 1)).astype(np.float32)
-    np.testing.assert_allclose(project(Pm, X, mm, "cpu"), Pm @ (X - mm), rtol=1e-4, atol=1e-5)
-    m, P = whitenlearn(X, qidxs, pidxs, device="cpu")
-    mr, Pr = _reference_whitenlearn(X, qidxs, pidxs)
-    np.testing.assert_allclose(m, mr, rtol=1e-6)
-    sign = np.sign(np.sum(P * Pr, axis=1, keepdims=True))       # eigenvectors are defined up to sign
-    np.testing.assert_allclose(P * sign, Pr, rtol=2e-2, atol=2e-3)
-    # the learned projection whitens the pair differences (their covariance becomes the identity)
-    dfw = P @ (X[:, qidxs] - X[:, pidxs])
-    np.testing.assert_allclose(dfw @ dfw.T / npairs, np.eye(D), atol=5e-3)
-    # and retrieval with it agrees with retrieval with the reference's P
-    a = whitenapply(X, m, P.astype(np.float32), device="cpu")
-    b = whitenapply(X, mr, Pr.astype(np.float32), device="cpu")
-    np.testing.assert_allclose(a.T @ a, b.T @ b, atol=2e-3)
+    g = golden("g12_whitenlearn.npz")
+    X = g["X"]
+    up = lambda a, b: a * np.sign(np.sum(a * b, axis=1, keepdims=True))
+    m, P = whitenlearn(X, g["qidxs"], g["pidxs"], device="cpu")
+    np.testing.assert_allclose(m, g["m_lw"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(up(P, g["P_lw"]), g["P_lw"], rtol=1e-7, atol=1e-9)
     m2, P2 = pcawhitenlearn(X, device="cpu")
-    Xw = P2 @ (X - m2)
-    np.testing.assert_allclose(Xw @ Xw.T / N, np.eye(D), atol=5e-3)
-    S = np.ones((3, 3))                                          # singular: needs the diagonal bump
-    L = cholesky(S)
-    assert np.allclose(L @ L.T, S, atol=1e-6)
+    np.testing.assert_allclose(m2, g["m_pca"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(up(np.real(P2), g["P_pca"]), g["P_pca"], rtol=1e-7, atol=1e-9)
+    _, P3 = pcawhitenlearn(X, shrink=8, device="cpu")
+    np.testing.assert_allclose(up(np.real(P3), g["P_pca_shrink8"]), g["P_pca_shrink8"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_array_equal(cholesky(g["S_singular"]), g["L_singular"])
+    np.testing.assert_array_equal(cholesky(g["S_pd"]), g["L_pd"])
+    A = X[:, :50]
+    np.testing.assert_allclose(gram(A, "cpu"), A @ A.T, rtol=1e-13, atol=1e-15)
+    rng = np.random.default_rng(0)
+    Pm, mm = rng.standard_normal((24, 24)), rng.standard_normal((24, 1))
+    np.testing.assert_allclose(project(Pm, X, mm, "cpu"), Pm @ (X - mm), rtol=1e-12, atol=1e-13)
+    # retrieval with the learned whitening = retrieval with the reference's (fp32 apply path)
+    a = whitenapply(X.astype(np.float32), m, P.astype(np.float32), device="cpu")
+    b = whitenapply(X.astype(np.float32), g["m_lw"], g["P_lw"].astype(np.float32), device="cpu")
+    np.testing.assert_allclose(a.T @ a, b.T @ b, atol=2e-5)
 
 
 # ------------------------------------------------------------------ f2: embed stage
@@ -660,3 +629,35 @@ def test_batches_of_equal_sized_images_equal_single_images(fops):
             np.testing.assert_allclose(wrapped[b].numpy(), chain(one, net).numpy(), rtol=0, atol=2e-6)
             np.testing.assert_allclose(raw[b].numpy(), plain(one, net).reshape(-1).numpy(), rtol=0, atol=1e-6)
         assert extract_ss(net, x[:1]).shape == (256,) and chain(x[:1], net).shape == (64,)      # batch 1: the reference's shapes
+
+
+def test_image_loader_golden(golden, tmp_path):
+    """Golden G15: the reference's ImagesFromList.__getitem__ (genericdataset.py:44-70: decode, crop to the box,
+    thumbnail with the ANTIALIAS = LANCZOS filter) on three images x six (size, box) cases, pixel for pixel."""
+    from mdir_amd.datasets import ImagesFromList
+    g = golden("g15_loader.npz")
+    for name in ("landscape", "portrait", "small"):
+        (tmp_path / (name + ".png")).write_bytes(g["file_" + name].tobytes())
+    for ci in range(6):
+        name, imsize, bbx = eval(str(g["case%d_spec" % ci][0]))
+        ds = ImagesFromList(root=str(tmp_path), images=[name + ".png"], imsize=imsize, bbxs=[bbx],
+                            transform=lambda im: np.asarray(im).copy())
+        np.testing.assert_array_equal(ds[0], g["case%d_out" % ci])
+
+
+def test_embedding_output_golden(golden):
+    """Golden G14: the reference's EmbeddingOutput (output.py:117-139): float64 [N,D], NaN row for an unreadable image."""
+    from mdir_amd.stages import EmbeddingOutput
+    g = golden("g14_embedding_output.npz")
+    names = [str(x) for x in g["names"]]
+    out = EmbeddingOutput((names,), {})
+    out.add(0, object(), torch.from_numpy(g["vec"][0]))
+    out.add(1, None, None)
+    out.add(2, object(), torch.from_numpy(g["vec"][2]))
+    out.add(3, object(), torch.from_numpy(g["vec"][3]))
+    res_names, res = out.postprocess()
+    assert res_names == names and res.dtype == np.float64
+    np.testing.assert_array_equal(res, g["result"])
+    with_boxes = EmbeddingOutput((names, [None, (1, 2, 3, 4), None, None]), {}, bbxs=True)
+    assert repr(with_boxes.preprocess()) == str(g["preprocess_bbxs"][0])
+    assert EmbeddingOutput((names,), {}).postprocess()[1] == []

@@ -177,3 +177,52 @@ def test_g11_nanmean_metric():
     meta = json.load(open(os.path.join(GOLDEN, "g11_scenario.json")))["metadata"]
     aps = [0.5, float("nan"), 0.25, 1.0]
     assert O.nanmean_metric(aps) == meta["roxford5k/validation/score:ap_medium_avg.4"][0]
+
+
+# ------------------------------------------------------------------ rows marked "next" (f1-f3) and the loader (a1)
+
+def _rows_up_to_sign(a, b):
+    """Rows of eigenvector-derived matrices are defined up to sign."""
+    sign = np.sign(np.sum(a * b, axis=1, keepdims=True))
+    return a * sign
+
+
+def test_g12_whitening_learning(golden):
+    g = golden("g12_whitenlearn.npz")
+    m, P = O.whitenlearn(g["X"], g["qidxs"], g["pidxs"])
+    np.testing.assert_allclose(m, g["m_lw"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(_rows_up_to_sign(P, g["P_lw"]), g["P_lw"], rtol=1e-9, atol=1e-10)
+    m2, P2 = O.pcawhitenlearn(g["X"])
+    np.testing.assert_allclose(m2, g["m_pca"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(_rows_up_to_sign(np.real(P2), g["P_pca"]), g["P_pca"], rtol=1e-8, atol=1e-9)
+    _, P3 = O.pcawhitenlearn(g["X"], shrink=8)
+    np.testing.assert_allclose(_rows_up_to_sign(np.real(P3), g["P_pca_shrink8"]), g["P_pca_shrink8"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_array_equal(O.cholesky_bumped(g["S_singular"]), g["L_singular"])      # needed the diagonal bump
+    np.testing.assert_array_equal(O.cholesky_bumped(g["S_pd"]), g["L_pd"])
+
+
+def test_g13_hard_negative_selection(golden):
+    g = golden("g13_mining.npz")
+    nidxs, ndist = O.hard_negatives(g["qvecs"], g["poolvecs"], g["idxs2images"], g["clusters"].tolist(), g["qidxs"].tolist(),
+                                    int(g["nnum"]))
+    assert nidxs == g["nidxs"].tolist()
+    np.testing.assert_allclose(ndist, g["ndist"], rtol=1e-5)
+
+
+def test_g14_embedding_output(golden):
+    g = golden("g14_embedding_output.npz")
+    got = O.embedding_output(4, [g["vec"][0], None, g["vec"][2], g["vec"][3]])
+    assert got.dtype == np.float64 == np.dtype(str(g["result_dtype"]))
+    np.testing.assert_array_equal(got, g["result"])
+    assert O.embedding_output(4, []) == [] and g["empty_second"][0] == "[]"
+
+
+def test_g15_image_loader(golden, tmp_path):
+    g = golden("g15_loader.npz")
+    for name in ("landscape", "portrait", "small"):
+        (tmp_path / (name + ".png")).write_bytes(g["file_" + name].tobytes())
+    ncases = sum(1 for k in g.files if k.endswith("_spec"))
+    assert ncases == 6
+    for ci in range(ncases):
+        name, imsize, bbx = eval(str(g["case%d_spec" % ci][0]))
+        np.testing.assert_array_equal(O.load_image(str(tmp_path / (name + ".png")), imsize, bbx), g["case%d_out" % ci])
