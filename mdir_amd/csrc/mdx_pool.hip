@@ -14,7 +14,7 @@ namespace mdx {
 
 // x^p for x >= eps > 0.  Exact products for the exponents that occur untrained
 // (p = 1, 2, 3, layers/pooling.py:38); exp2(p*log2 x) through the hardware
-// transcendental units otherwise (relative error ~1e-6, tests/test_gpu_pool.py).
+// transcendental units otherwise (relative error ~1e-6; tests/test_gpu_kernels.py::test_pool_l2n_golden, rtol 1e-5).
 template <int MODE>
 __device__ __forceinline__ float pow_pos(float x, float p)
 {

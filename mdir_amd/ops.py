@@ -24,6 +24,28 @@ def _stream():
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
+class _Here:
+    """No-op context: the tensor's device is already the current one (the common case; a real
+    ``torch.cuda.device`` guard costs a few microseconds per launch, and the trunk epilogue launches ~100 times per image)."""
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_HERE = _Here()
+
+
+def _on(t):
+    """Context in which ``t``'s device is current, so that ``_stream()`` and the launch use the device the pointers
+    live on (a caller may pass ``device=cuda:1`` without ``set_device``; the reference's torch ops follow the tensor)."""
+    idx = t.device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _HERE
+    return torch.cuda.device(idx)
+
+
 def _dev(t, dtype, what):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError("%s must be a CUDA/ROCm tensor: the MI355X path has no CPU fallback" % what)
@@ -60,9 +82,10 @@ def pool_l2n(feat, kind="gem", p=3.0, pool_eps=1e-6, l2n_eps=1e-6):
     fp = _dev(feat, torch.float32, "feature map")
     B, C, H, W = feat.shape
     out = torch.empty((B, C), dtype=torch.float32, device=feat.device)
-    check(_lib.lib().mdx_pool_l2n(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps),
-                                  -1.0 if l2n_eps is None else float(l2n_eps), _vp(out.data_ptr()),
-                                  _stream()), "mdx_pool_l2n")
+    with _on(feat):
+        check(_lib.lib().mdx_pool_l2n(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps),
+                                      -1.0 if l2n_eps is None else float(l2n_eps), _vp(out.data_ptr()),
+                                      _stream()), "mdx_pool_l2n")
     return out
 
 
@@ -74,7 +97,8 @@ def l2n_rows_(x, bias=None, eps=1e-6):
     bp = _dev(bias, torch.float32, "bias") if bias is not None else None
     if bias is not None and bias.numel() != x.shape[1]:
         raise ValueError("bias length %d != D %d" % (bias.numel(), x.shape[1]))
-    check(_lib.lib().mdx_l2n_rows(xp, x.shape[0], x.shape[1], bp, float(eps), _stream()), "mdx_l2n_rows")
+    with _on(x):
+        check(_lib.lib().mdx_l2n_rows(xp, x.shape[0], x.shape[1], bp, float(eps), _stream()), "mdx_l2n_rows")
     return x
 
 
@@ -92,8 +116,9 @@ def ms_aggregate(vecs, msp=1.0):
             raise ValueError("scale %d has %d elements, expected %d" % (i, v.numel(), D))
         ptrs[i] = _dev(v, torch.float32, "scale descriptor").value
     out = torch.empty(D, dtype=torch.float32, device=flat[0].device)
-    check(_lib.lib().mdx_ms_aggregate(ptrs, len(flat), D, float(msp), _vp(out.data_ptr()), _stream()),
-          "mdx_ms_aggregate")
+    with _on(flat[0]):
+        check(_lib.lib().mdx_ms_aggregate(ptrs, len(flat), D, float(msp), _vp(out.data_ptr()), _stream()),
+              "mdx_ms_aggregate")
     return out
 
 
@@ -109,8 +134,9 @@ def u8_to_chw(images, mean, std):
     if images.numel() == 0:
         return out
     arr = ctypes.c_float * c
-    check(_lib.lib().mdx_u8_to_chw(images.data_ptr(), b, h, w, c, arr(*[float(v) for v in mean]),
-                                   arr(*[float(v) for v in std]), out.data_ptr(), _stream()), "mdx_u8_to_chw")
+    with _on(images):
+        check(_lib.lib().mdx_u8_to_chw(images.data_ptr(), b, h, w, c, arr(*[float(v) for v in mean]),
+                                       arr(*[float(v) for v in std]), out.data_ptr(), _stream()), "mdx_u8_to_chw")
     return out
 
 
@@ -139,8 +165,9 @@ def bn_act_(x, running_mean, running_var, weight=None, bias=None, eps=1e-5, resi
         rp = residual.data_ptr()
     if x.numel() == 0:
         return x
-    check(_lib.lib().mdx_bn_act(x.data_ptr(), rp, n, c, h * w, ptrs[0], ptrs[1], ptrs[2], ptrs[3], float(eps),
-                                1 if relu else 0, _stream()), "mdx_bn_act")
+    with _on(x):
+        check(_lib.lib().mdx_bn_act(x.data_ptr(), rp, n, c, h * w, ptrs[0], ptrs[1], ptrs[2], ptrs[3], float(eps),
+                                    1 if relu else 0, _stream()), "mdx_bn_act")
     return x
 
 

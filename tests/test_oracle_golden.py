@@ -155,19 +155,47 @@ def test_rank_of_matches_full_ranking():
         np.testing.assert_array_equal(crk[q], rk[:, q])
 
 
+def _fma32(a, b, c):
+    """fl32(a*b + c) with ONE rounding, computed exactly: rational arithmetic, then the nearest float32
+    (numpy rounds a python float to float32 correctly, and the exact rational is turned into the nearest
+    double first only when that double is already exact enough -- so round directly from the rational)."""
+    from fractions import Fraction
+    exact = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+    if exact == 0:
+        return np.float32(0.0)
+    # nearest float32 of a rational: scale to an integer significand of 24 bits, round half to even
+    sign = -1 if exact < 0 else 1
+    mag = abs(exact)
+    e = mag.numerator.bit_length() - mag.denominator.bit_length()
+    if Fraction(2) ** e > mag:
+        e -= 1                                                  # 2^e <= mag < 2^(e+1)
+    e = max(e, -126)                                            # subnormal range keeps the exponent of 2^-126
+    scaled = mag / Fraction(2) ** (e - 23)                      # significand in [2^23, 2^24) (or below, if subnormal)
+    n, rem = divmod(scaled.numerator, scaled.denominator)
+    twice = 2 * rem
+    if twice > scaled.denominator or (twice == scaled.denominator and n % 2 == 1):
+        n += 1
+    return np.float32(sign * float(Fraction(n) * Fraction(2) ** (e - 23)))
+
+
 def test_chain_is_sequential_fma():
-    """oracle/chain.c really is the k-ascending fused chain (checked in float64 emulation)."""
+    """oracle/chain.c really is the k-ascending chain of fused multiply-adds, one rounding per term.  Checked against an
+    EXACT fma (rational arithmetic, correctly rounded to float32) -- a float64 emulation can double-round."""
     rng = np.random.default_rng(6)
     d, n, q = 37, 9, 3
     vecs = rng.standard_normal((d, n)).astype(np.float32)
     qv = rng.standard_normal((d, q)).astype(np.float32)
+    vecs[:, 0] *= np.float32(1e-20)                              # products in the subnormal range too
     got = OC.scores_chain(vecs, qv)
     for j in range(q):
         for i in range(n):
             acc = np.float32(0)
-            for k in range(d):  # fma: exact product + acc in float64 (53 bits hold 24x24+align), one rounding
-                acc = np.float32(np.float64(qv[k, j]) * np.float64(vecs[k, i]) + np.float64(acc))
-            assert got[j, i] == acc
+            for k in range(d):
+                acc = _fma32(qv[k, j], vecs[k, i], acc)
+            assert got[j, i] == acc, (j, i, got[j, i], acc)
+    # the rounding helper itself: halfway cases go to even, and it agrees with numpy where no tie is involved
+    assert _fma32(np.float32(1.0), np.float32(1.0), np.float32(2.0 ** -24)) == np.float32(1.0)
+    assert _fma32(np.float32(1.0), np.float32(1.0 + 2.0 ** -23), np.float32(2.0 ** -24)) == np.float32(1.0 + 2.0 ** -22)
     a = rng.standard_normal((5, d)).astype(np.float32)
     b = rng.standard_normal((4, d)).astype(np.float32)
     np.testing.assert_array_equal(OC.gemm_nt_chain(a, b), OC.scores_chain(b.T.copy(), a.T.copy()))
