@@ -1,3 +1,13 @@
 """mdir_amd -- MI355X-native descriptor extraction and ranking (the hot path of
 jenicek/mdir + cirtorch) behind the reference's operator API.  See DESIGN.md."""
-__version__ = "0.1.0"
+import os
+
+__version__ = "0.2.0"
+
+# MIOpen's default find mode answers the FIRST convolution call of every new (layer, input shape) with a search whose
+# candidates include its naive reference kernels: 4.2 s for one ResNet101 pass on a new image size from empty caches
+# (73 % of the GPU time of a whole benchmark run in round 1).  FAST mode (2) takes the find-db / heuristic answer:
+# 0.8 s for the same pass and the same steady state (tools/miopen_probe.sh, fresh user db and kernel cache per mode:
+# default 4.25 s, NORMAL 4.11, FAST 0.78, HYBRID 4.17, naive solver switched off 1.29).  An image list has dozens of
+# sizes, each at three scales, so this is what extraction wants; an explicit setting of the user wins.
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")

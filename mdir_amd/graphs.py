@@ -57,9 +57,15 @@ class _Entry:
 class ShapeGraphs:
     """``fn``: tensor -> tensor (or list/tuple of tensors) with no host synchronisation inside."""
 
+    # Capturing a graph of a ResNet101 pyramid costs ~0.2 s and a replay saves ~6 ms per image against eager batched
+    # launches (tools/bench_extract.py --list), so a capture only pays for itself after ~35 images of that shape.
+    PAYOFF_IMAGES = int(os.environ.get("MDIR_AMD_GRAPH_PAYOFF", "32"))
+
     def __init__(self, fn, warmup=1, max_graphs=None):
         self.fn = fn
         self.warmup = warmup
+        self.upcoming = None               # images of the current shape still to come, if the caller knows (else None)
+        self.captures = 0
         self.max_graphs = max_graphs or int(os.environ.get("MDIR_AMD_MAX_GRAPHS", "32"))
         self.graphs = collections.OrderedDict()
         self.seen = collections.Counter()
@@ -73,6 +79,8 @@ class ShapeGraphs:
             self.seen[key] += 1
             if key in self.refused or self.seen[key] <= self.warmup:
                 return self.fn(x)
+            if self.upcoming is not None and self.upcoming < self.PAYOFF_IMAGES:
+                return self.fn(x)                     # too few images of this shape left for a capture to pay off
             entry = self._capture(x, key)
             if entry is None:
                 return self.fn(x)
@@ -102,4 +110,5 @@ class ShapeGraphs:
             warnings.warn("hipGraph capture refused for input shape %s (%s); staying eager for it" % (key[0], err))
             return None
         self.graphs[key] = entry
+        self.captures += 1
         return entry

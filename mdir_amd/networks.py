@@ -206,16 +206,26 @@ class ShapeOrder:
     WINDOW = 4096
 
     def __init__(self, images, bbxs):
-        self.images, self.bbxs, self.emitted = images, bbxs, []
+        self.images, self.bbxs, self.emitted, self.upcoming = images, bbxs, [], []
 
     def __len__(self):
         return len(self.images)
 
     def __iter__(self):
-        self.emitted = []
+        self.emitted, self.upcoming = [], []          # upcoming[k]: images of the same size from item k to the end of its run
         for lo in range(0, len(self.images), self.WINDOW):
-            for i in _same_shape_order(self.images, self.bbxs, lo, min(len(self.images), lo + self.WINDOW)):
+            hi = min(len(self.images), lo + self.WINDOW)
+            keys = {i: _shape_key(self.images, self.bbxs, i) for i in range(lo, hi)}
+            order = sorted(range(lo, hi), key=lambda i: (keys[i], i))
+            run_end = len(order)
+            left = [0] * len(order)
+            for k in range(len(order) - 1, -1, -1):
+                if k + 1 < len(order) and keys[order[k + 1]] != keys[order[k]]:
+                    run_end = k + 1
+                left[k] = run_end - k
+            for k, i in enumerate(order):
                 self.emitted.append(i)
+                self.upcoming.append(left[k])
                 yield i
 
 
@@ -246,12 +256,16 @@ def batched_loop(loader, order, device, describe, store, missing=None, progress=
     buf = []
 
     def flush():
+        if hasattr(describe, "upcoming"):
+            # how many images of this size are still to come (the sampler ordered them): a graph is only captured
+            # when enough replays will follow (ShapeGraphs.PAYOFF_IMAGES)
+            describe.upcoming = buf[0][2] if buf and buf[0][2] is not None else None
         if len(buf) == bmax and bmax > 1:
-            rows = describe(torch.cat([t for _, t in buf], dim=0))
-            for (i, _), row in zip(buf, rows):
+            rows = describe(torch.cat([t for _, t, _ in buf], dim=0))
+            for (i, _, _), row in zip(buf, rows):
                 store(i, row)
         else:
-            for i, t in buf:
+            for i, t, _ in buf:
                 store(i, describe(t))
         buf.clear()
 
@@ -263,7 +277,7 @@ def batched_loop(loader, order, device, describe, store, missing=None, progress=
             item = item.to(device, non_blocking=True)
             if buf and buf[0][1].shape != item.shape:
                 flush()
-            buf.append((i, item))
+            buf.append((i, item, order.upcoming[done] if getattr(order, "upcoming", None) else None))
             if len(buf) == bmax:
                 flush()
         if progress:

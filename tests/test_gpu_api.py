@@ -365,6 +365,7 @@ def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
         orig(self, *a, **k)
         made.append(self)
     monkeypatch.setattr(ShapeGraphs, "__init__", spy)
+    monkeypatch.setattr(ShapeGraphs, "PAYOFF_IMAGES", 0)      # capture even for a dozen images (default: only when >= 32 follow)
     monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
     from mdir_amd.networks import _same_shape_order
     assert _same_shape_order(paths, None) == [0, 5, 10, 15, 1, 2, 3, 4, 6, 7, 8, 9, 11, 12, 13, 14]      # equal sizes consecutive

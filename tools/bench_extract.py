@@ -141,5 +141,116 @@ def measure(args):
             "hipgraph_replays": getattr(describe, "replays", 0)}
 
 
+# rOxford-like sizes (W, H): longer side 1024 after the thumbnail, the usual camera aspect ratios, both orientations
+LIST_SHAPES = [(1024, 768), (1024, 683), (1024, 681), (1024, 685), (1024, 576), (1024, 819), (1024, 640), (1024, 724),
+               (768, 1024), (683, 1024), (681, 1024), (685, 1024), (576, 1024), (819, 1024), (640, 1024), (724, 1024)]
+
+
+def _write_jpegs(folder, shapes, per_shape, seed=5):
+    """JPEG files of the given sizes (smooth blobs + grain, so that they decode like photographs), shuffled."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    paths = []
+    for si, (w, h) in enumerate(shapes):
+        for k in range(per_shape):
+            low = rng.integers(0, 255, (h // 32 + 1, w // 32 + 1, 3)).astype(np.float32)
+            img = np.kron(low, np.ones((32, 32, 1), dtype=np.float32))[:h, :w]
+            img = np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+            path = os.path.join(folder, "s%02d_%03d.jpg" % (si, k))
+            Image.fromarray(img).save(path, format="JPEG", quality=90)
+            paths.append(path)
+    return [paths[i] for i in rng.permutation(len(paths))]
+
+
+def _conv_flops(net, scales, h, w):
+    """Multiply-add x 2 of the trunk's convolutions for one image at the given pyramid scales (hooks on an eager pass)."""
+    total = [0]
+
+    def hook(mod, inp, out):
+        k = mod.kernel_size[0] * mod.kernel_size[1] * (mod.in_channels // mod.groups)
+        total[0] += 2 * k * out.numel()
+
+    handles = [m.register_forward_hook(hook) for m in net.features.modules() if isinstance(m, torch.nn.Conv2d)]
+    dev = next(net.parameters()).device
+    with torch.no_grad():
+        for s in scales:
+            net.features(torch.zeros(1, 3, int(h * s), int(w * s), device=dev))
+    for hd in handles:
+        hd.remove()
+    return float(total[0])
+
+
+def measure_list(arch="resnet101", workers=8, short=4, mid=40, long=64):
+    """Descriptors/sec of ``extract_vectors_device`` on an image LIST: 16 sizes, JPEG files through the real loader
+    (decode + thumbnail in worker processes, uint8 over PCIe, /255-mean-std on the GPU), 3 scales + learned whitening
+    through the wrapper chain.  The FIRST list of the process (``short`` images per size) pays for what a new size costs
+    (MIOpen picks and loads its kernels); two later lists (``mid`` / ``long`` per size, both long enough for a graph per
+    size: one eager batch, one capture, replays) differ only in replays, which gives the steady state."""
+    import tempfile
+    from mdir_amd.datasets import ImagesFromList, initialize_transforms
+    from mdir_amd.network import CirNetwork, SingleNetwork
+    from mdir_amd.networks import extract_vectors_device, init_network
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(3)
+    model = init_network({"architecture": arch, "pooling": "gem", "whitening": False, "pretrained": False})
+    D = model.meta["outputdim"]
+    model.meta["in_channels"], model.meta["out_channels"] = 3, D
+    rng = np.random.default_rng(2)
+    q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    wh = {"P": (q * rng.uniform(0.5, 2.0, (1, D))).T.copy(), "m": rng.normal(0, 0.01, (D, 1))}
+    model_params = {"architecture": "cirnet", "cir_architecture": arch, "local_whitening": False, "pooling": "gem",
+                    "regional": False, "whitening": False, "pretrained": False}
+    runtime = {"wrappers": {"train": "", "eval": {"0_cirwhiten": {"whitening": wh, "dimensions": None}, "1_cirmultiscale": {"scales": True}}},
+               "data": {"transforms": "pil2np | totensor | normalize"}}
+    net = CirNetwork(model.to(dev), SingleNetwork.NetworkParams(model_params, runtime), dev, frozen=True).eval()
+    transform = initialize_transforms("pil2np | totensor | normalize", net.network_params.runtime["data"]["mean_std"])
+    out = {}
+    with tempfile.TemporaryDirectory() as folder:
+        lists = {}
+        files = _write_jpegs(folder, LIST_SHAPES, long)                      # shuffled; "sSS_KKK.jpg" = size SS, copy KKK
+        for n in (short, mid, long):
+            lists[n] = [f for f in files if int(os.path.basename(f)[4:7]) < n]
+        times = {}
+        # cold: the first list of the process meets every (size, scale, batch) for the first time -- MIOpen picks and
+        # loads its kernels there; warm: the same sizes again (new graphs are captured, MIOpen already knows the shapes)
+        for tag, paths in (("cold", lists[short]), ("warm_short", lists[short]), ("warm_mid", lists[mid]), ("warm_long", lists[long])):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                vecs = extract_vectors_device(net, paths, 1024, transform, device=dev, num_workers=workers, print_freq=10 ** 9)
+            torch.cuda.synchronize()
+            times[tag] = time.perf_counter() - t0
+            assert vecs.shape == (len(paths), D) and bool(torch.isfinite(vecs).all())
+        # loader alone (decode + thumbnail + uint8 tensor, no GPU work) on the long list
+        from mdir_amd.datasets import ToUint8HWC
+        loader = torch.utils.data.DataLoader(ImagesFromList("", lists[long], imsize=1024, transform=ToUint8HWC()), batch_size=1,
+                                             num_workers=workers)
+        t0 = time.perf_counter()
+        for _ in loader:
+            pass
+        t_loader = time.perf_counter() - t0
+    ns, nm, nl = short * len(LIST_SHAPES), mid * len(LIST_SHAPES), long * len(LIST_SHAPES)
+    steady = (times["warm_long"] - times["warm_mid"]) / (nl - nm)           # s per image once its size has a graph
+    first = (times["cold"] - times["warm_short"]) / len(LIST_SHAPES)        # extra s per size the process has never seen
+    flops = np.mean([_conv_flops(model, [1, 2 ** -0.5, 0.5], h, w) for w, h in LIST_SHAPES[:1] + LIST_SHAPES[4:5] + LIST_SHAPES[8:9]])
+    return {"value": round(1.0 / steady, 2), "unit": "descriptors/s",
+            "what": "steady state of extract_vectors_device on a list of %d JPEG sizes (%s, 3 scales + whitening), %d loader "
+                    "workers: (t[%d images] - t[%d images]) / %d, both lists after the process has seen every size once and both "
+                    "long enough for one graph per size" % (len(LIST_SHAPES), arch, workers, nl, nm, nl - nm),
+            "ms_per_image_steady": round(1e3 * steady, 3),
+            "first_occurrence_s_per_size": round(first, 3),
+            "whole_list_descriptors_per_s": {"cold_%d_images" % ns: round(ns / times["cold"], 2),
+                                             "warm_%d_images_eager_batches" % ns: round(ns / times["warm_short"], 2),
+                                             "warm_%d_images" % nm: round(nm / times["warm_mid"], 2),
+                                             "warm_%d_images" % nl: round(nl / times["warm_long"], 2)},
+            "graph_capture_and_first_batches_s_per_size": round((times["warm_mid"] - nm * steady) / len(LIST_SHAPES), 3),
+            "loader_only_images_per_s": round(nl / t_loader, 1),
+            "trunk_conv_tflops_at_steady_state": round(flops / steady / 1e12, 2), "trunk_conv_gflop_per_image": round(flops / 1e9, 1),
+            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--list":
+        print(json.dumps(measure_list(*(sys.argv[2:3] or ["resnet101"]))))
+    else:
+        main()
