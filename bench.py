@@ -385,6 +385,7 @@ def main():
                                                      "chain, fp32; JPEG files of 16 sizes (longer side 1024) through the loader",
                                               tail_ms_per_image_mdx=rs["tail_ms_per_image_mdx"],
                                               tail_ms_per_image_torch_ops=rs["tail_ms_per_image_torch_ops"],
+                                              roofline_tail=rs["roofline_tail"],
                                               resident_single_shape_descriptors_per_s=rs["value"],
                                               resident_single_shape_backbone_ms_per_image=rs["backbone_ms_per_image"])
         else:

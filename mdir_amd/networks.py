@@ -296,6 +296,9 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     if num_workers is None:
         num_workers = int(os.environ.get("MDIR_AMD_WORKERS", "8"))
     describe = (lambda x: extract_ss(net, x)) if len(ms) == 1 else (lambda x: extract_ms(net, x, ms, msp))
+    # a network whose wrapper chain ends in a whitening (mdir's CirNetwork with 0_cirwhiten): whiten all rows at the end
+    chain = getattr(net, "wrappers", {}).get(getattr(net, "stage", None)) if isinstance(getattr(net, "wrappers", None), dict) else None
+    final_whitening = chain.defer_final_whitening() if hasattr(chain, "defer_final_whitening") else None
     tail = transform.device_tail() if hasattr(transform, "device_tail") and _gpu_preprocess(device) else None
     if tail is not None:
         # workers ship uint8 pixels (a quarter of the bytes through shared memory, the pinned copy
@@ -323,11 +326,18 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
         if done % print_freq == 0 or done == len(images):
             print("\r>>>> {}/{} done...".format(done, len(images)), end="")
 
-    with torch.no_grad():
-        batched_loop(loader, order, device, describe, store, progress=progress,
-                     batches=getattr(net, "supports_batches", False))
-        print("")
+    try:
+        with torch.no_grad():
+            batched_loop(loader, order, device, describe, store, progress=progress,
+                         batches=getattr(net, "supports_batches", False))
+            print("")
+    finally:
+        if final_whitening is not None:
+            chain.restore_whitening(final_whitening)
     vecs = state["vecs"]
+    if final_whitening is not None and vecs is not None:
+        with torch.no_grad():                  # ONE pass over P for the whole list (blocks bound the fp32 [n,d] temporaries)
+            vecs = torch.cat([final_whitening.whiten_rows(vecs[i:i + 65536]) for i in range(0, vecs.shape[0], 65536)], dim=0)
     return vecs
 
 

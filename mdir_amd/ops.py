@@ -73,19 +73,44 @@ def _workspace(nbytes, device):
 
 # ------------------------------------------------------------------ extraction
 
+_TICKETS = {}           # device index -> [uint32 scratch of the fused pooling kernel (zero between launches), cursor]
+_TICKET_WORDS = 1 << 16
+
+
+def _tickets(device, count):
+    """``count`` zeroed uint32 words for one ``mdx_pool_l2n_fused`` launch.  Every launch gets the NEXT words of a ring
+    (64 K words per device), so launches that run concurrently -- the pyramid scales on their own HIP streams, branches
+    of one captured graph -- never share a word; a kernel leaves its words zero, so the ring never needs clearing.
+    (A captured graph keeps replaying on the words it was captured with; replays of one graph do not overlap.)"""
+    slot = _TICKETS.get(device.index)
+    if slot is None:
+        slot = _TICKETS[device.index] = [torch.zeros(_TICKET_WORDS, dtype=torch.int32, device=device), 0]
+    if slot[1] + count > _TICKET_WORDS:
+        slot[1] = 0
+    start = slot[1]
+    slot[1] += count
+    return slot[0].data_ptr() + 4 * start
+
+
 def pool_l2n(feat, kind="gem", p=3.0, pool_eps=1e-6, l2n_eps=1e-6):
     """[B,C,H,W] feature maps -> [B,C] pooled (+ L2-normalised unless l2n_eps is None).
 
-    ``self.norm(self.pool(o))`` of cirtorch/networks/imageretrievalnet.py:108."""
+    ``self.norm(self.pool(o))`` of cirtorch/networks/imageretrievalnet.py:108; with the normalisation it is ONE launch
+    (``mdx_pool_l2n_fused``: the workgroup that finishes an image last normalises it)."""
     if feat.dim() != 4:
         raise ValueError("feature map must be [B,C,H,W]")
     fp = _dev(feat, torch.float32, "feature map")
     B, C, H, W = feat.shape
     out = torch.empty((B, C), dtype=torch.float32, device=feat.device)
     with _on(feat):
-        check(_lib.lib().mdx_pool_l2n(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps),
-                                      -1.0 if l2n_eps is None else float(l2n_eps), _vp(out.data_ptr()),
-                                      _stream()), "mdx_pool_l2n")
+        if l2n_eps is None or B >= 65536 or B > _TICKET_WORDS:
+            check(_lib.lib().mdx_pool_l2n(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps),
+                                          -1.0 if l2n_eps is None else float(l2n_eps), _vp(out.data_ptr()),
+                                          _stream()), "mdx_pool_l2n")
+        else:
+            check(_lib.lib().mdx_pool_l2n_fused(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps), float(l2n_eps),
+                                                _vp(out.data_ptr()), _vp(_tickets(feat.device, B)), _stream()),
+                  "mdx_pool_l2n_fused")
     return out
 
 
@@ -119,6 +144,24 @@ def ms_aggregate(vecs, msp=1.0):
     with _on(flat[0]):
         check(_lib.lib().mdx_ms_aggregate(ptrs, len(flat), D, float(msp), _vp(out.data_ptr()), _stream()),
               "mdx_ms_aggregate")
+    return out
+
+
+def ms_aggregate_batch(mats, msp=1.0):
+    """Per-scale descriptor MATRICES (list of ``[B,D]`` tensors, one row per image) -> aggregated ``[B,D]`` in one
+    launch (``mdx_ms_aggregate_batch``)."""
+    if not 1 <= len(mats) <= 8:
+        raise ValueError("1..8 scales supported, got %d" % len(mats))
+    B, D = mats[0].shape
+    ptrs = (ctypes.c_void_p * len(mats))()
+    for i, v in enumerate(mats):
+        if tuple(v.shape) != (B, D):
+            raise ValueError("scale %d is %s, expected %s" % (i, tuple(v.shape), (B, D)))
+        ptrs[i] = _dev(v, torch.float32, "scale descriptors").value
+    out = torch.empty((B, D), dtype=torch.float32, device=mats[0].device)
+    with _on(mats[0]):
+        check(_lib.lib().mdx_ms_aggregate_batch(ptrs, len(mats), B, D, float(msp), _vp(out.data_ptr()), _stream()),
+              "mdx_ms_aggregate_batch")
     return out
 
 

@@ -54,6 +54,22 @@ class Compose(object):
             out = step.postprocess(out, model, meta)
         return out
 
+    def defer_final_whitening(self):
+        """If the step applied LAST to a descriptor is a whitening (``0_cirwhiten`` of eval.yml: post-processing runs in
+        reverse order), switch it off in this chain and return it: a caller that collects many descriptors
+        (``extract_vectors_device``) then whitens the finished ``[N,D]`` matrix ONCE -- one pass over ``P`` instead of
+        one per batch of 4 images.  Row for row the same arithmetic (every row is its own k-ordered chain).  Returns
+        ``None`` when there is nothing to defer; ``restore_whitening`` puts the step back."""
+        if self.wrappers and isinstance(self.wrappers[0], CirtorchWhiten) and not self.wrappers[0].skip:
+            self.wrappers[0].skip = True
+            return self.wrappers[0]
+        return None
+
+    @staticmethod
+    def restore_whitening(step):
+        if step is not None:
+            step.skip = False
+
     def __repr__(self):
         body = "".join("\n    %s" % w for w in self.wrappers)
         return "%s([%s])" % (type(self).__name__, body + "\n" if body else "")
@@ -100,8 +116,7 @@ class CirMultiscaleAggregation(Wrapper):
     def aggregate_tensor(tensor, nscales, outputdim, msp):
         assert len(tensor) == nscales, "%s != %s" % (len(tensor), nscales)
         if tensor[0].dim() == 2 and tensor[0].shape[0] > 1 and tensor[0].shape[1] == outputdim:
-            rows = [t.contiguous() for t in tensor]            # batch: S x [B,D], aggregated image by image
-            return torch.stack([ops.ms_aggregate([t[b] for t in rows], msp) for b in range(rows[0].shape[0])])
+            return ops.ms_aggregate_batch([t.contiguous() for t in tensor], msp)       # batch: S x [B,D] -> [B,D], one launch
         flat = [t.reshape(-1).contiguous() for t in tensor]
         assert all(t.numel() == outputdim for t in flat)
         return ops.ms_aggregate(flat, msp)
@@ -134,6 +149,7 @@ class CirtorchWhiten(Wrapper):
         self.dimensions = dimensions or P.shape[0]
         self.shard = ops.DescriptorIndex(P[:self.dimensions].contiguous(), "ND")   # resident, re-tiled once
         self.P = P
+        self.skip = False                  # Compose.defer_final_whitening: the caller whitens all rows at the end
 
     def whiten_rows(self, vecs_nd):
         """``[n, D]`` device descriptors -> ``[n, d]`` whitened rows (batched form)."""
@@ -141,6 +157,8 @@ class CirtorchWhiten(Wrapper):
         return ops.l2n_rows_(y, eps=1e-6)
 
     def postprocess(self, tensor, model, _meta):
+        if self.skip:
+            return tensor
         if isinstance(tensor, list):
             return [self.postprocess(t, model, _meta) for t in tensor]
         if tensor.dim() == 2 and tensor.shape[0] > 1 and tensor.shape[1] == self.P.shape[1]:

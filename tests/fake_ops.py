@@ -33,6 +33,11 @@ def ms_aggregate(vecs, msp=1.0):
     return torch.from_numpy(O.ms_aggregate(np.stack([v.detach().numpy().reshape(-1) for v in vecs]), msp))
 
 
+def ms_aggregate_batch(mats, msp=1.0):
+    st = np.stack([m.detach().numpy() for m in mats])            # [S,B,D]
+    return torch.from_numpy(np.stack([O.ms_aggregate(st[:, b], msp) for b in range(st.shape[1])]))
+
+
 class DescriptorIndex:
     def __init__(self, vecs, layout="DN", row_offset=0):
         v = vecs.detach().numpy()
@@ -96,7 +101,7 @@ def rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, off_t):
     return cnt
 
 
-NAMES = ("pool_l2n", "l2n_rows_", "ms_aggregate", "DescriptorIndex", "rank_full", "topk", "rank_of",
+NAMES = ("pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "DescriptorIndex", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 
