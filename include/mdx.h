@@ -69,12 +69,6 @@ const char *mdx_last_error(void);
 int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float p,
                  float pool_eps, float l2n_eps, float *out, void *stream);
 
-/* mdx_pool_l2n with l2n_eps >= 0 as ONE launch: the workgroup that finishes an image last normalises it.
- *   tickets: B uint32 words of device scratch, ZERO before the first use; the kernel leaves them zero again, so
- *   the same words serve the next call on the same stream (calls that may run concurrently need their own). */
-int mdx_pool_l2n_fused(const float *feat, int B, int C, int H, int W, int kind, float p, float pool_eps,
-                       float l2n_eps, float *out, uint32_t *tickets, void *stream);
-
 /* In place: x[r,:] = (x[r,:] + bias) / (||x[r,:] + bias||_2 + eps) for R rows of
  * length D; bias may be NULL.  LF.l2n (functional.py:130-131); with bias it is the
  * tail of the in-network whitening `self.norm(self.whiten(o))`

@@ -47,7 +47,6 @@ def _declare(lib):
         "mdx_abi_version": (i32, []),
         "mdx_last_error": (ctypes.c_char_p, []),
         "mdx_pool_l2n": (i32, [p, i32, i32, i32, i32, i32, f32, f32, f32, p, p]),
-        "mdx_pool_l2n_fused": (i32, [p, i32, i32, i32, i32, i32, f32, f32, f32, p, p, p]),
         "mdx_l2n_rows": (i32, [p, i64, i64, p, f32, p]),
         "mdx_ms_aggregate": (i32, [pp, i32, i64, f32, p, p]),
         "mdx_ms_aggregate_batch": (i32, [pp, i32, i64, i64, f32, p, p]),
@@ -72,7 +71,7 @@ def _declare(lib):
     return sig
 
 
-EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_pool_l2n", "mdx_pool_l2n_fused", "mdx_l2n_rows", "mdx_ms_aggregate",
+EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
            "mdx_ms_aggregate_batch", "mdx_bn_act", "mdx_u8_to_chw",
            "mdx_index_create", "mdx_index_create_ex", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
            "mdx_scores", "mdx_rank_workspace", "mdx_rank_full", "mdx_topk", "mdx_rank_of",

@@ -73,44 +73,19 @@ def _workspace(nbytes, device):
 
 # ------------------------------------------------------------------ extraction
 
-_TICKETS = {}           # device index -> [uint32 scratch of the fused pooling kernel (zero between launches), cursor]
-_TICKET_WORDS = 1 << 16
-
-
-def _tickets(device, count):
-    """``count`` zeroed uint32 words for one ``mdx_pool_l2n_fused`` launch.  Every launch gets the NEXT words of a ring
-    (64 K words per device), so launches that run concurrently -- the pyramid scales on their own HIP streams, branches
-    of one captured graph -- never share a word; a kernel leaves its words zero, so the ring never needs clearing.
-    (A captured graph keeps replaying on the words it was captured with; replays of one graph do not overlap.)"""
-    slot = _TICKETS.get(device.index)
-    if slot is None:
-        slot = _TICKETS[device.index] = [torch.zeros(_TICKET_WORDS, dtype=torch.int32, device=device), 0]
-    if slot[1] + count > _TICKET_WORDS:
-        slot[1] = 0
-    start = slot[1]
-    slot[1] += count
-    return slot[0].data_ptr() + 4 * start
-
-
 def pool_l2n(feat, kind="gem", p=3.0, pool_eps=1e-6, l2n_eps=1e-6):
     """[B,C,H,W] feature maps -> [B,C] pooled (+ L2-normalised unless l2n_eps is None).
 
-    ``self.norm(self.pool(o))`` of cirtorch/networks/imageretrievalnet.py:108; with the normalisation it is ONE launch
-    (``mdx_pool_l2n_fused``: the workgroup that finishes an image last normalises it)."""
+    ``self.norm(self.pool(o))`` of cirtorch/networks/imageretrievalnet.py:108."""
     if feat.dim() != 4:
         raise ValueError("feature map must be [B,C,H,W]")
     fp = _dev(feat, torch.float32, "feature map")
     B, C, H, W = feat.shape
     out = torch.empty((B, C), dtype=torch.float32, device=feat.device)
     with _on(feat):
-        if l2n_eps is None or B >= 65536 or B > _TICKET_WORDS:
-            check(_lib.lib().mdx_pool_l2n(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps),
-                                          -1.0 if l2n_eps is None else float(l2n_eps), _vp(out.data_ptr()),
-                                          _stream()), "mdx_pool_l2n")
-        else:
-            check(_lib.lib().mdx_pool_l2n_fused(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps), float(l2n_eps),
-                                                _vp(out.data_ptr()), _vp(_tickets(feat.device, B)), _stream()),
-                  "mdx_pool_l2n_fused")
+        check(_lib.lib().mdx_pool_l2n(fp, B, C, H, W, POOL_KINDS[kind], float(p), float(pool_eps),
+                                      -1.0 if l2n_eps is None else float(l2n_eps), _vp(out.data_ptr()),
+                                      _stream()), "mdx_pool_l2n")
     return out
 
 

@@ -285,43 +285,6 @@ def test_ms_aggregate_batch_golden(ops, golden):
         np.testing.assert_array_equal(got[1], ops.ms_aggregate([dev(other[s]) for s in range(S)], msp).cpu().numpy())
 
 
-def test_fused_pool_l2n_hand_off_under_load(ops):
-    """mdx_pool_l2n_fused: the workgroup that finishes an image LAST normalises it, reading the other workgroups'
-    pooled values through an agent-scope release / acquire.  Screen as the MI355X guide asks (uneven load, the reading
-    CU's L1 warm, every word checked): many launches on three HIP streams at once with a competing GEMM, each result
-    bit for bit equal to the two-launch form (pool, then mdx_l2n_rows) and within 1e-5 of the oracle."""
-    rng = np.random.default_rng(21)
-    streams = [torch.cuda.Stream() for _ in range(3)]
-    bg = torch.cuda.Stream()
-    junk = torch.randn(2048, 2048, device=DEV)
-    for it in range(40):
-        B, C = int(rng.integers(1, 7)), int(rng.choice([5, 64, 256, 2048]))
-        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
-        x = np.maximum(rng.standard_normal((B, C, H, W)), 0).astype(np.float32)
-        if it % 7 == 0:
-            x[0] = 0.0                                                  # zero map: eps keeps the row finite
-        p = float(rng.choice([3.0, 2.92, 1.0]))
-        xd = dev(x)
-        want = ops.pool_l2n(xd, "gem", p, l2n_eps=None)
-        ops.l2n_rows_(want, eps=1e-6)                                   # two launches
-        torch.cuda.synchronize()
-        outs = []
-        with torch.cuda.stream(bg):
-            _ = junk @ junk
-        for rep in range(3):
-            for st in streams:
-                with torch.cuda.stream(st):
-                    _ = xd.sum()                                        # warms L1 / L2 with the inputs on whatever CU
-                    outs.append(ops.pool_l2n(xd, "gem", p))             # fused
-        torch.cuda.synchronize()
-        for o in outs:
-            np.testing.assert_array_equal(o.cpu().numpy(), want.cpu().numpy())
-        np.testing.assert_allclose(want.cpu().numpy(), O.l2n(O.gem(x, p)), rtol=1e-5, atol=1e-7)
-    from mdir_amd import ops as real_ops
-    ring = real_ops._TICKETS[torch.cuda.current_device()][0]
-    assert int(ring.abs().sum()) == 0                                   # every launch re-armed its ticket words
-
-
 def test_whiten_golden(ops, golden):
     """CirtorchWhiten.postprocess as index-of-P x centred descriptors (wrapper.py:193-195)."""
     g = golden("g5_whiten.npz")

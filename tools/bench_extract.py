@@ -111,7 +111,7 @@ def measure(args):
         t_backbone = timeit(lambda: trunk(imgs[0])) if trunk.graphs else t_backbone_eager
         p = net.pool.p_value()
 
-        def tail_mdx():     # per image: three fused pool+L2N launches and the aggregation; the whitening is applied to the
+        def tail_mdx():     # per image: pool + L2N of the three maps and the batched aggregation; the whitening is applied to the
             per = [ops.pool_l2n(f, "gem", p, 1e-6, 1e-6) for f in feats]          # finished [N,D] matrix (timed below)
             return ops.ms_aggregate_batch(per, p)
 
@@ -152,7 +152,7 @@ def measure(args):
             "tail_ms_per_image_torch_ops": round(t_tail_torch, 4),
             "roofline_tail": {"bound": "hbm", "bytes_per_image": tail_bytes, "achieved": round(tail_bytes / (t_tail * 1e-3) / 1e9, 1),
                               "peak": 8000.0, "unit": "GB/s", "frac": round(tail_bytes / (t_tail * 1e-3) / 1e9 / 8000.0, 4),
-                              "what": "3 x fused GeM+L2N (one launch each), batched aggregation, whitening of the finished [N,D] "
+                              "what": "3 x GeM + L2N (two launches each), batched aggregation (one launch), whitening of the finished [N,D] "
                                       "matrix / N; a batch-1 image is four short dependent launches (eager: ~10 us of host time each; a graph "
                                       "replay of just these four costs its fixed ~15 us): launch latency, not bandwidth, bounds it"},
             "tail_max_abs_diff_vs_torch_ops": err, "dtype": "f32", "data": "synthetic",
