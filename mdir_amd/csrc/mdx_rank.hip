@@ -25,12 +25,6 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;   // elements per workgroup
 constexpr int SUB_TILE = 64 * SORT_ITEMS;      // elements per wave
 constexpr int RADIX = 256;
 
-__device__ __forceinline__ uint32_t load_key(const float *scores, const uint32_t *keys, int64_t i,
-                                             bool first)
-{
-    return first ? desc_key(scores[i]) : keys[i];
-}
-
 // ascending bitonic sort of buf[0..P) (P a power of two) by all threads of the workgroup
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t *buf, int P, int tid, int nthreads)
 {
@@ -48,72 +42,95 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t *buf, int P, int tid, 
         }
 }
 
-// per-tile digit histogram -> block_hist[q][b][digit].  One workgroup takes HIST_TILES
-// consecutive tiles: all their loads are issued before the first LDS atomic, so that a
-// short-lived workgroup still keeps enough bytes in flight.
-#ifndef MDX_HIST_TILES
-#define MDX_HIST_TILES 1
-#endif
-constexpr int HIST_TILES = MDX_HIST_TILES;
+// What a pass reads and writes.  A pass only needs the key bits it has not consumed yet, and ids of a database of
+// n <= 2^24 rows fit 24 bits, so between passes an element is NOT (key word, id word) but
+//      w = (key bits 24..31 : id)   one word, the same in every packed format, and
+//      h = the middle key bits still to come: bits 8..23 (FMT_A, a u16) after pass 0, bits 16..23 (FMT_B, a u8)
+//          after pass 1, nothing (FMT_C) after pass 2.
+// Per element the four passes then move 4+6, 6+5, 5+4, 4+8 bytes instead of 4+8, 8+8, 8+8, 8+8 and their
+// histograms read 4, 2, 1, 4 bytes instead of 4 x 4: 53 bytes instead of 76.  FMT_KV (key word, id word) is the
+// layout for n > 2^24.  Rows of the intermediate arrays start at multiples of `stride` (a multiple of 256 elements),
+// so that their wide loads are aligned; the scores keep their own row length n.
+enum { FMT_SCORES = 0, FMT_KV = 1, FMT_A = 2, FMT_B = 3, FMT_C = 4, FMT_RANKS = 5 };
 
+// per-tile digit histogram -> block_hist[q][b][digit].  A histogram does not care which lane counts which
+// element, so a lane takes consecutive elements with one wide load: 4 scores / key words (16 bytes,
+// dword-aligned for the scores: rows of an odd length start anywhere), or 8 of the u16 / u8 middle parts.
+// It matters for pass 0, whose input comes from HBM (112 -> ~60 us).
+//
 // LDS sub-histograms are selected by LANE (not by wave): when a digit is concentrated in a few
 // values (the top byte of cosine scores: sign + 7 exponent bits) at most 64/HIST_COPIES lanes of
 // one ds_add hit the same address.  Row stride RADIX+1 keeps the copies in different banks.
 constexpr int HIST_COPIES = 8;
 
-template <bool FIRST>
+template <int SRC>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__restrict__ scores,
-                                                                 const uint32_t *__restrict__ keys,
-                                                                 int64_t n, int nblk, int shift,
+                                                                 const void *__restrict__ src, int64_t n,
+                                                                 int64_t stride, int nblk, int shift,
                                                                  uint32_t *__restrict__ block_hist)
 {
-    __shared__ uint32_t h[HIST_TILES][HIST_COPIES][RADIX + 1];
+    static_assert(SORT_ITEMS == 8, "a lane takes 8 elements of a tile");
+    constexpr bool FIRST = SRC == FMT_SCORES;
+    __shared__ uint32_t h[HIST_COPIES][RADIX + 1];
     const int tid = threadIdx.x, copy = tid & (HIST_COPIES - 1);
     // pass 0 reads the scores newest rows first (the similarity kernel has just written them: the tail of its
     // output is still in the Infinity Cache) and leaves the head cached for the scatter, which then runs forward
     const int64_t q = FIRST ? (int64_t)gridDim.y - 1 - blockIdx.y : (int64_t)blockIdx.y;
-    const int64_t b0 = (FIRST ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x) * HIST_TILES;
-    for (int e = tid; e < HIST_TILES * HIST_COPIES * (RADIX + 1); e += SORT_THREADS) (&h[0][0][0])[e] = 0;
-    const int64_t base = q * n;
-    uint32_t k[HIST_TILES][SORT_ITEMS];
-    // A histogram does not care which lane counts which element, so a lane takes 4 consecutive elements with one
-    // 16-byte load (dword-aligned: rows of an odd length start anywhere): a quarter of the memory requests.  It
-    // matters for pass 0, whose input comes from HBM (112 -> ~60 us); later passes find theirs in the caches.
-    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    constexpr int VEC = SORT_ITEMS / 4;
+    const int64_t b0 = FIRST ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x;
+    for (int e = tid; e < HIST_COPIES * (RADIX + 1); e += SORT_THREADS) (&h[0][0])[e] = 0;
+    uint32_t d[SORT_ITEMS];
+    int64_t first[2];           // element index of d[0] and of d[4]
+    if (SRC == FMT_A || SRC == FMT_B) {
+        const int64_t i = b0 * SORT_TILE + tid * 8;
+        first[0] = i;
+        first[1] = i + 4;
+        if (SRC == FMT_A) {
+            typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+            u16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (i < n) w = *(const u16x8 *)((const uint16_t *)src + q * stride + i);      // rows are padded to the stride
 #pragma unroll
-    for (int t = 0; t < HIST_TILES; ++t)
+            for (int j = 0; j < 8; ++j) d[j] = w[j] & 255u;
+        } else {
+            typedef uint8_t u8x8 __attribute__((ext_vector_type(8)));
+            u8x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (i < n) w = *(const u8x8 *)((const uint8_t *)src + q * stride + i);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const int64_t i = (b0 + t) * SORT_TILE + (v * SORT_THREADS + tid) * 4;
-            u32x4u w = {0u, 0u, 0u, 0u};
-            if (i + 3 < n) {
-                w = *(const u32x4u *)(FIRST ? (const uint32_t *)scores + base + i : keys + base + i);
-            } else {
+            for (int j = 0; j < 8; ++j) d[j] = w[j];
+        }
+    } else {
+        typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const uint32_t *p = FIRST ? (const uint32_t *)scores + q * n : (const uint32_t *)src + q * stride;
+        u32x4u w[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            first[v] = b0 * SORT_TILE + (v * SORT_THREADS + tid) * 4;
+            w[v] = u32x4u{0u, 0u, 0u, 0u};
+        }
+        if ((b0 + 1) * SORT_TILE <= n) {        // whole tile (uniform branch): both loads in flight together
+#pragma unroll
+            for (int v = 0; v < 2; ++v) w[v] = *(const u32x4u *)(p + first[v]);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (i + j < n) w[j] = FIRST ? ((const uint32_t *)scores)[base + i + j] : keys[base + i + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) k[t][v * 4 + j] = FIRST ? desc_key(__uint_as_float(w[j])) : w[j];
+                    if (first[v] + j < n) w[v][j] = p[first[v] + j];
         }
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[v * 4 + j] = ((FIRST ? desc_key(__uint_as_float(w[v][j])) : w[v][j]) >> shift) & 255u;
+    }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < HIST_TILES; ++t)
-#pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = (b0 + t) * SORT_TILE + ((r / 4) * SORT_THREADS + tid) * 4 + (r % 4);
-            if (i < n) atomicAdd(&h[t][copy][(k[t][r] >> shift) & 255u], 1u);
-        }
+    for (int r = 0; r < SORT_ITEMS; ++r)
+        if (first[r / 4] + (r % 4) < n) atomicAdd(&h[copy][d[r]], 1u);
     __syncthreads();
-    for (int e = tid; e < HIST_TILES * RADIX; e += SORT_THREADS) {
-        const int t = e / RADIX, d = e % RADIX;
-        if (b0 + t < nblk) {
-            uint32_t tot = 0;
+    for (int e = tid; e < RADIX; e += SORT_THREADS) {
+        uint32_t tot = 0;
 #pragma unroll
-            for (int w = 0; w < HIST_COPIES; ++w) tot += h[t][w][d];
-            block_hist[(q * nblk + b0 + t) * RADIX + d] = tot;
-        }
+        for (int w = 0; w < HIST_COPIES; ++w) tot += h[w][e];
+        block_hist[(q * nblk + b0) * RADIX + e] = tot;
     }
 }
 
@@ -166,18 +183,17 @@ __global__ __launch_bounds__(SCAN_GROUPS * SCAN_DIGITS) void sort_scan_kernel(ui
 // same digit, lower lane first) and keeps a running per-digit count in LDS.  The
 // tile is then put in digit order in LDS, so that consecutive lanes write
 // consecutive global addresses inside each digit run (coalesced scatter).
-//
-// PACK (ids fit 24 bits, i.e. n <= 2^24): after three passes only the top key byte is still needed, so pass 2
-// (PACK = 1) writes ONE word per element, (top key byte : id), and the last pass (PACK = 2) reads one word:
-// 8 of the 76 bytes per element of the four passes are not moved at all.
-template <bool FIRST, bool LAST, int PACK = 0>
+// IN / OUT: the formats above (w_* = key words or packed words, h_* = id words or middle key bits).
+template <int IN, int OUT>
 __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAVES) / 4)) void sort_scatter_kernel(
-    const float *__restrict__ scores, const uint32_t *__restrict__ keys_in,
-    const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, int64_t *__restrict__ ranks, float *__restrict__ top_scores,
-    int64_t n, int nblk, int shift, const uint32_t *__restrict__ block_hist,
-    const uint32_t *__restrict__ digit_tot, int64_t id_offset, int64_t klimit)
+    const float *__restrict__ scores, const uint32_t *__restrict__ w_in, const void *__restrict__ h_in,
+    uint32_t *__restrict__ w_out, void *__restrict__ h_out, int64_t *__restrict__ ranks,
+    float *__restrict__ top_scores, int64_t n, int64_t stride, int nblk, int shift,
+    const uint32_t *__restrict__ block_hist, const uint32_t *__restrict__ digit_tot, int64_t id_offset,
+    int64_t klimit)
 {
+    constexpr bool FIRST = IN == FMT_SCORES, LAST = OUT == FMT_RANKS;
+    constexpr bool VAL_IN_KEY = IN == FMT_C;        // the id is the low 24 bits of the word the digit comes from
     __shared__ uint32_t dtot[RADIX];        // per-query digit totals -> digit bases (scanned below)
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];     // per-wave digit counts, then tile-local offsets
     __shared__ uint32_t gdelta[RADIX];      // global position of a digit run minus its tile offset
@@ -200,10 +216,14 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
     for (int e = tid; e < SORT_WAVES * RADIX; e += SORT_THREADS) (&wcnt[0][0])[e] = 0;
     __syncthreads();
 
-    const int64_t base = q * n;
+    // Everything per element is 32-bit and tile-local: row and tile starts are folded into uniform (scalar) pointers.
+    // The kernel is bound by its VALU instruction count (measured: ~130 of ~200 us per pass do not depend on the
+    // bytes moved), so 64-bit per-lane address arithmetic and per-element range checks are what there is to save.
+    const int64_t base = q * n;                 // row of the scores
+    const int64_t row = q * stride;             // row of the intermediate arrays
     const int64_t tile0 = b * SORT_TILE;
-    const int64_t sub0 = tile0 + wave * SUB_TILE;
     const int tile_n = (int)((n - tile0) < SORT_TILE ? (n - tile0) : SORT_TILE);
+    const int sub = wave * SUB_TILE + lane;     // this lane's element of round 0, tile-local
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS], pos[SORT_ITEMS];
     // global start of every digit run of this tile + the query's digit totals: requested first,
     // parked in LDS once the key loads are in flight (no register held across the ranking)
@@ -217,61 +237,80 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         // go through LDS (skey is free until the tile is staged) to reach the (wave, round, lane) order the ranking
         // is defined on.  Later passes find their input in the caches, where the same detour costs 6-30 us per pass.
         typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const uint32_t *src = (const uint32_t *)scores + base + tile0;
+        if (tile_n == SORT_TILE) {      // whole tile (uniform branch): both loads in flight together
+            u32x4u w[SORT_ITEMS / 4];
 #pragma unroll
-        for (int v = 0; v < SORT_ITEMS / 4; ++v) {
-            const int e = (v * SORT_THREADS + tid) * 4;             // element of the tile
-            const int64_t i = tile0 + e;
-            u32x4u w = {0u, 0u, 0u, 0u};
-            if (i + 3 < n) {
-                w = *(const u32x4u *)((const uint32_t *)scores + base + i);
-            } else {
+            for (int v = 0; v < SORT_ITEMS / 4; ++v) w[v] = *(const u32x4u *)(src + (v * SORT_THREADS + tid) * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (i + j < n) w[j] = ((const uint32_t *)scores)[base + i + j];
-            }
+            for (int v = 0; v < SORT_ITEMS / 4; ++v)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) skey[e + j] = desc_key(__uint_as_float(w[j]));
+                for (int j = 0; j < 4; ++j) skey[(v * SORT_THREADS + tid) * 4 + j] = desc_key(__uint_as_float(w[v][j]));
+        } else {
+            for (int e = tid; e < tile_n; e += SORT_THREADS) skey[e] = desc_key(__uint_as_float(src[e]));
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = sub0 + r * 64 + lane;
-            key[r] = i < n ? skey[wave * SUB_TILE + r * 64 + lane] : 0xFFFFFFFFu;
-            val[r] = (uint32_t)i;
+            key[r] = (sub + r * 64) < tile_n ? skey[sub + r * 64] : 0xFFFFFFFFu;
+            val[r] = (uint32_t)tile0 + (uint32_t)(sub + r * 64);
         }
     } else {
+        // every lane loads (past the end of the row: the row's last element again) and all loads are issued before
+        // the first use: a load under `if (i < n)` makes the compiler wait for each one in turn
+        const uint32_t *wt = w_in + row + tile0;
+        const uint8_t *ht = (const uint8_t *)h_in + (row + tile0) * (IN == FMT_KV ? 4 : IN == FMT_A ? 2 : 1);
+        uint32_t w[SORT_ITEMS], hh[SORT_ITEMS];
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = sub0 + r * 64 + lane;
-            const bool valid = i < n;
-            key[r] = valid ? keys_in[base + i] : 0xFFFFFFFFu;
-            val[r] = PACK == 2 ? (key[r] & 0x00FFFFFFu) : (valid ? vals_in[base + i] : 0u);
+            const int e = min(sub + r * 64, tile_n - 1);
+            w[r] = wt[e];
+            hh[r] = 0;
+            if (IN == FMT_KV) hh[r] = ((const uint32_t *)ht)[e];
+            if (IN == FMT_A) hh[r] = ((const uint16_t *)ht)[e];
+            if (IN == FMT_B) hh[r] = ht[e];
+        }
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const bool valid = (sub + r * 64) < tile_n;
+            if (IN == FMT_KV) {
+                key[r] = valid ? w[r] : 0xFFFFFFFFu;
+                val[r] = hh[r];
+            } else {
+                const uint32_t k = IN == FMT_C ? w[r] : ((w[r] & 0xFF000000u) | (hh[r] << (IN == FMT_A ? 8 : 16)));
+                key[r] = valid ? k : 0xFFFFFFFFu;
+                val[r] = w[r] & 0x00FFFFFFu;
+            }
         }
     }
     if (tid < RADIX) {
         gdelta[tid] = gbase;
         dtot[tid] = qtot;
     }
+    uint32_t *mycnt = wcnt[wave];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
-        const bool valid = (sub0 + r * 64 + lane) < n;
+        const bool valid = (sub + r * 64) < tile_n;
         const uint32_t d = (key[r] >> shift) & 255u;
-        // match-any on the 8 digit bits, as two 32-bit halves: per bit one sign-extract (0 / ~0),
-        // one compare (the ballot) and xnor + and per half
-        const uint64_t vmask = __ballot(valid);
-        uint32_t plo = (uint32_t)vmask, phi = (uint32_t)(vmask >> 32);
+        // match-any on the 8 digit bits: `dlo/dhi` collect the lanes that differ from this one in some bit.  Per bit:
+        // one sign-extract (0 / ~0), one compare (= the ballot, lands in SGPRs) and one three-input bit-op per half,
+        // acc | (ballot ^ sel).  Lanes past the end of the row carry digit 255 and take part; they are masked below.
+        uint32_t dlo = 0, dhi = 0;
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
-            const int32_t sel = (int32_t)(d << (31 - bit)) >> 31;       // ~0 where the bit is set
-            const uint64_t m = __ballot(valid && sel != 0);
-            plo &= ~((uint32_t)m ^ (uint32_t)sel);
-            phi &= ~((uint32_t)(m >> 32) ^ (uint32_t)sel);
+            int32_t sel = __builtin_amdgcn_sbfe((int32_t)d, bit, 1);
+            asm("" : "+v"(sel));            // compare THIS register (else: a second shift of d per bit)
+            const uint64_t m = __builtin_amdgcn_ballot_w64(sel < 0);
+            dlo = __builtin_amdgcn_bitop3_b32(dlo, (uint32_t)m, (uint32_t)sel, 0xF6);
+            dhi = __builtin_amdgcn_bitop3_b32(dhi, (uint32_t)(m >> 32), (uint32_t)sel, 0xF6);
         }
+        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+        const uint32_t plo = (uint32_t)vmask & ~dlo, phi = (uint32_t)(vmask >> 32) & ~dhi;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
         const uint32_t cnt = __popc(plo) + __popc(phi);
-        const uint32_t old = wcnt[wave][d];
+        const uint32_t old = mycnt[d];
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) wcnt[wave][d] = old + cnt;
+        if (valid && rank == 0) mycnt[d] = old + cnt;
         __builtin_amdgcn_wave_barrier();
         pos[r] = old + rank;
     }
@@ -315,30 +354,39 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
-        const bool valid = (sub0 + r * 64 + lane) < n;
-        if (!valid) continue;
+        if ((sub + r * 64) >= tile_n) continue;
         const uint32_t d = (key[r] >> shift) & 255u;
-        const uint32_t lp = scan[d] + wcnt[wave][d] + pos[r];
+        const uint32_t lp = scan[d] + mycnt[d] + pos[r];
         skey[lp] = key[r];
-        if (PACK != 2) sval[lp] = val[r];
+        if (!VAL_IN_KEY) sval[lp] = val[r];
     }
     __syncthreads();
+    // Offsets from the row start fit 32 bits in the packed formats (n <= 2^24 elements of at most 8 bytes): scalar
+    // row pointer + 32-bit lane offset, no 64-bit arithmetic per element.
+    constexpr bool OFF32 = IN == FMT_C;         // (the last pass of the packed formats)
+    char *const wrow = (char *)(w_out + row), *const hrow = (char *)h_out + row * (OUT == FMT_KV ? 4 : OUT == FMT_A ? 2 : 1);
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int i = r * SORT_THREADS + tid;
         if (i >= tile_n) continue;
-        const uint32_t k = skey[i], v = PACK == 2 ? (k & 0x00FFFFFFu) : sval[i];
-        const int64_t dst = (int64_t)(uint32_t)(gdelta[(k >> shift) & 255u] + (uint32_t)i);
+        const uint32_t k = skey[i], v = VAL_IN_KEY ? (k & 0x00FFFFFFu) : sval[i];
+        const uint32_t dst32 = gdelta[(k >> shift) & 255u] + (uint32_t)i;
         if (LAST) {
+            const int64_t dst = (int64_t)dst32;
             if (dst < klimit) {
-                if (ranks) ranks[q * klimit + dst] = (int64_t)v + id_offset;
+                if (ranks) {
+                    if (OFF32) *(int64_t *)((char *)(ranks + q * klimit) + (dst32 << 3)) = (int64_t)v + id_offset;
+                    else ranks[q * klimit + dst] = (int64_t)v + id_offset;
+                }
                 if (top_scores) top_scores[q * klimit + dst] = scores[base + v];
             }
-        } else if (PACK == 1) {
-            keys_out[base + dst] = (k & 0xFF000000u) | v;
+        } else if (OUT == FMT_KV) {
+            w_out[row + (int64_t)dst32] = k;
+            ((uint32_t *)h_out)[row + (int64_t)dst32] = v;
         } else {
-            keys_out[base + dst] = k;
-            vals_out[base + dst] = v;
+            *(uint32_t *)(wrow + (dst32 << 2)) = (k & 0xFF000000u) | v;
+            if (OUT == FMT_A) *(uint16_t *)(hrow + (dst32 << 1)) = (uint16_t)(k >> 8);
+            if (OUT == FMT_B) *(uint8_t *)(hrow + dst32) = (uint8_t)(k >> 16);
         }
     }
 }
@@ -449,22 +497,24 @@ __global__ void gather_scores_kernel(const float *__restrict__ scores, int64_t n
 }
 
 struct RankWs {
-    uint32_t *keys[2];
-    uint32_t *vals[2];
+    uint32_t *w[2];             // key words (FMT_KV) or packed words (FMT_A/B/C), ping-pong
+    void *h[2];                 // id words (FMT_KV); h[0] also holds the u16 middles (FMT_A), h[1] the u8 ones (FMT_B)
     uint32_t *block_hist;
     uint32_t *digit_tot;
     int nblk;
+    int64_t stride;             // row stride of w / h, elements
 };
 
 static int64_t carve(RankWs *ws, char *base, int64_t n, int64_t nq)
 {
     const int64_t nblk = ceil_div(n, SORT_TILE);
-    const int64_t elems = round_up(n * nq * 4, 256);
+    const int64_t stride = round_up(n, 256);
+    const int64_t elems = stride * nq * 4;
     int64_t off = 0;
     for (int i = 0; i < 2; ++i) {
-        if (ws) ws->keys[i] = (uint32_t *)(base + off);
+        if (ws) ws->w[i] = (uint32_t *)(base + off);
         off += elems;
-        if (ws) ws->vals[i] = (uint32_t *)(base + off);
+        if (ws) ws->h[i] = (void *)(base + off);
         off += elems;
     }
     if (ws) ws->block_hist = (uint32_t *)(base + off);
@@ -472,7 +522,27 @@ static int64_t carve(RankWs *ws, char *base, int64_t n, int64_t nq)
     if (ws) ws->digit_tot = (uint32_t *)(base + off);
     off += round_up(nq * RADIX * 4, 256);
     if (ws) ws->nblk = (int)nblk;
+    if (ws) ws->stride = stride;
     return off;
+}
+
+template <int IN, int OUT>
+static void sort_pass(const RankWs &ws, const float *scores, int64_t n, int64_t nq, int pass, int64_t id_offset,
+                      int64_t *ranks, float *top_scores, int64_t klimit, hipStream_t s)
+{
+    const int shift = 8 * pass;
+    const uint32_t *w_in = pass == 0 ? nullptr : ws.w[(pass - 1) & 1];
+    const void *h_in = pass == 0 ? nullptr : ws.h[(pass - 1) & 1];
+    const dim3 grid((unsigned)ws.nblk, (unsigned)nq), blk(SORT_THREADS);
+    // the histogram reads only the array the digit of this pass lives in
+    const void *digits = (IN == FMT_A || IN == FMT_B) ? h_in : (const void *)w_in;
+    hipLaunchKernelGGL(sort_hist_kernel<IN>, grid, blk, 0, s, scores, digits, n, ws.stride, ws.nblk, shift,
+                       ws.block_hist);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX / SCAN_DIGITS, (unsigned)nq), dim3(SCAN_GROUPS * SCAN_DIGITS), 0, s,
+                       ws.block_hist, ws.nblk, ws.digit_tot);
+    hipLaunchKernelGGL((sort_scatter_kernel<IN, OUT>), grid, blk, 0, s, scores, w_in, h_in, ws.w[pass & 1],
+                       ws.h[pass & 1], ranks, top_scores, n, ws.stride, ws.nblk, shift, ws.block_hist, ws.digit_tot,
+                       id_offset, klimit);
 }
 
 static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offset, int64_t *ranks,
@@ -491,44 +561,20 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
     }
     RankWs ws;
     carve(&ws, (char *)workspace, n, nq);
-    const dim3 grid((unsigned)ws.nblk, (unsigned)nq), blk(SORT_THREADS);
-    const bool pack = n <= (1ll << 24);         // ids fit 24 bits: (top key byte : id) in one word between passes 2 and 3
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 8 * pass;
-        const uint32_t *kin = pass == 0 ? nullptr : ws.keys[(pass - 1) & 1];
-        const uint32_t *vin = pass == 0 ? nullptr : ws.vals[(pass - 1) & 1];
-        uint32_t *kout = ws.keys[pass & 1], *vout = ws.vals[pass & 1];
-        const dim3 hgrid((unsigned)ceil_div(ws.nblk, HIST_TILES), (unsigned)nq);
-        if (pass == 0)
-            hipLaunchKernelGGL(sort_hist_kernel<true>, hgrid, blk, 0, s, scores, kin, n, ws.nblk, shift,
-                               ws.block_hist);
-        else
-            hipLaunchKernelGGL(sort_hist_kernel<false>, hgrid, blk, 0, s, scores, kin, n, ws.nblk,
-                               shift, ws.block_hist);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX / SCAN_DIGITS, (unsigned)nq), dim3(SCAN_GROUPS * SCAN_DIGITS), 0, s,
-                           ws.block_hist, ws.nblk, ws.digit_tot);
-        if (pass == 0)
-            hipLaunchKernelGGL((sort_scatter_kernel<true, false>), grid, blk, 0, s, scores, kin, vin,
-                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
-                               ws.digit_tot, id_offset, klimit);
-        else if (pass == 1 || (pass == 2 && !pack))
-            hipLaunchKernelGGL((sort_scatter_kernel<false, false>), grid, blk, 0, s, scores, kin, vin,
-                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
-                               ws.digit_tot, id_offset, klimit);
-        else if (pass == 2)
-            hipLaunchKernelGGL((sort_scatter_kernel<false, false, 1>), grid, blk, 0, s, scores, kin, vin,
-                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
-                               ws.digit_tot, id_offset, klimit);
-        else if (pack)
-            hipLaunchKernelGGL((sort_scatter_kernel<false, true, 2>), grid, blk, 0, s, scores, kin, vin,
-                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
-                               ws.digit_tot, id_offset, klimit);
-        else
-            hipLaunchKernelGGL((sort_scatter_kernel<false, true>), grid, blk, 0, s, scores, kin, vin,
-                               kout, vout, ranks, top_scores, n, ws.nblk, shift, ws.block_hist,
-                               ws.digit_tot, id_offset, klimit);
-        MDX_LAUNCH_CHECK();
+    // MDX_SORT_NO_PACK=1: the (key word, id word) layout also for small n (tests run both)
+    static const bool no_pack = getenv("MDX_SORT_NO_PACK") && atoi(getenv("MDX_SORT_NO_PACK")) != 0;
+    if (n <= (1ll << 24) && !no_pack) {
+        sort_pass<FMT_SCORES, FMT_A>(ws, scores, n, nq, 0, id_offset, ranks, top_scores, klimit, s);
+        sort_pass<FMT_A, FMT_B>(ws, scores, n, nq, 1, id_offset, ranks, top_scores, klimit, s);
+        sort_pass<FMT_B, FMT_C>(ws, scores, n, nq, 2, id_offset, ranks, top_scores, klimit, s);
+        sort_pass<FMT_C, FMT_RANKS>(ws, scores, n, nq, 3, id_offset, ranks, top_scores, klimit, s);
+    } else {
+        sort_pass<FMT_SCORES, FMT_KV>(ws, scores, n, nq, 0, id_offset, ranks, top_scores, klimit, s);
+        sort_pass<FMT_KV, FMT_KV>(ws, scores, n, nq, 1, id_offset, ranks, top_scores, klimit, s);
+        sort_pass<FMT_KV, FMT_KV>(ws, scores, n, nq, 2, id_offset, ranks, top_scores, klimit, s);
+        sort_pass<FMT_KV, FMT_RANKS>(ws, scores, n, nq, 3, id_offset, ranks, top_scores, klimit, s);
     }
+    MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
 
