@@ -206,6 +206,11 @@ def measure_list(arch="resnet101", workers=8, short=4, mid=40, long=64):
     size: one eager batch, one capture, replays) differ only in replays, which gives the steady state."""
     import tempfile
     from mdir_amd.datasets import ImagesFromList, initialize_transforms
+    from mdir_amd.graphs import ShapeGraphs
+    # both warm lists must be long enough per size for the capture to be made (ShapeGraphs.PAYOFF_IMAGES): only then
+    # is their difference pure replay time
+    mid = max(mid, ShapeGraphs.PAYOFF_IMAGES + 8)
+    long = max(long, mid + 24)
     from mdir_amd.network import CirNetwork, SingleNetwork
     from mdir_amd.networks import extract_vectors_device, init_network
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -225,9 +230,10 @@ def measure_list(arch="resnet101", workers=8, short=4, mid=40, long=64):
     out = {}
     with tempfile.TemporaryDirectory() as folder:
         lists = {}
-        files = _write_jpegs(folder, LIST_SHAPES, long)                      # shuffled; "sSS_KKK.jpg" = size SS, copy KKK
+        uniq = 8                                                             # distinct files per size; longer lists repeat them
+        files = _write_jpegs(folder, LIST_SHAPES, uniq)                      # shuffled; "sSS_KKK.jpg" = size SS, copy KKK
         for n in (short, mid, long):
-            lists[n] = [f for f in files if int(os.path.basename(f)[4:7]) < n]
+            lists[n] = [f for r in range(-(-n // uniq)) for f in files if r * uniq + int(os.path.basename(f)[4:7]) < n]
         times = {}
         # cold: the first list of the process meets every (size, scale, batch) for the first time -- MIOpen picks and
         # loads its kernels there; warm: the same sizes again (new graphs are captured, MIOpen already knows the shapes)
