@@ -69,6 +69,21 @@ const char *mdx_last_error(void);
 int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float p,
                  float pool_eps, float l2n_eps, float *out, void *stream);
 
+/* The S feature maps of one image pyramid (or of a batch of B equal-sized images), pooled by ONE launch:
+ *   feats[s] [B,C,H[s],W[s]] row-major  ->  pooled [S,B,C]   (no normalisation)
+ * Replaces the S calls of `self.pool(o)` (imageretrievalnet.py:108; LF.gem / LF.mac / LF.spoc,
+ * functional.py:11-22) that CirMultiscaleAggregation (mdir/components/data/wrapper.py:104-107) and extract_ms
+ * (imageretrievalnet.py:315-318) cause, one per scale.  Per plane the arithmetic of mdx_pool_l2n. */
+int mdx_pool_multi(const float *const *feats, int S, int B, int C, const int *H, const int *W, int kind,
+                   float p, float pool_eps, float *pooled, void *stream);
+
+/* Descriptor tail of a pyramid in ONE launch:  pooled [S,B,D] -> out [B,D]
+ *   per scale  v_s = pooled[s,b,:] / (||pooled[s,b,:]||_2 + l2n_eps)          LF.l2n, functional.py:130-131
+ *   then       out = (sum_s v_s^msp / S)^(1/msp);  out /= ||out||_2 (no eps)  wrapper.py:112-117, imageretrievalnet.py:319-322
+ * Bit-identical to mdx_l2n_rows on every scale followed by mdx_ms_aggregate_batch. */
+int mdx_l2n_aggregate(const float *pooled, int S, int64_t B, int64_t D, float l2n_eps, float msp, float *out,
+                      void *stream);
+
 /* In place: x[r,:] = (x[r,:] + bias) / (||x[r,:] + bias||_2 + eps) for R rows of
  * length D; bias may be NULL.  LF.l2n (functional.py:130-131); with bias it is the
  * tail of the in-network whitening `self.norm(self.whiten(o))`

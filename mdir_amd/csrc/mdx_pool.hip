@@ -31,17 +31,13 @@ __device__ __forceinline__ float pool_elem(float x, float p, float eps)
     return x;
 }
 
+// one wave reduces one (image, channel) plane; every lane returns the pooled value
 template <int KIND, int MODE>
-__global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ feat, int64_t planes,
-                                                   int HW, float p, float inv_p, float eps,
-                                                   float *__restrict__ out)
+__device__ __forceinline__ float pool_plane(const float *__restrict__ src, bool wide, int HW, float p, float inv_p, float eps,
+                                            int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (plane >= planes) return;
-    const float *src = feat + plane * HW;
     float acc = KIND == MDX_POOL_MAC ? -INFINITY : 0.0f;
-    if ((HW & 3) == 0 && ((uintptr_t)feat & 15) == 0) {
+    if (wide) {
         const float4 *s4 = (const float4 *)src;
         const int n4 = HW >> 2;
         for (int i = lane; i < n4; i += 64) {
@@ -59,12 +55,47 @@ __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ fea
         }
     }
     acc = KIND == MDX_POOL_MAC ? wave_max(acc) : wave_sum(acc);
-    if (lane == 0) {
-        float r = acc;
-        if (KIND != MDX_POOL_MAC) r = acc / (float)HW;
-        if (KIND == MDX_POOL_GEM && MODE != 1) r = powf(r, inv_p);
-        out[plane] = r;
-    }
+    float r = acc;
+    if (KIND != MDX_POOL_MAC) r = acc / (float)HW;
+    if (KIND == MDX_POOL_GEM && MODE != 1) r = powf(r, inv_p);
+    return r;
+}
+
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ feat, int64_t planes,
+                                                   int HW, float p, float inv_p, float eps,
+                                                   float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const bool wide = (HW & 3) == 0 && ((uintptr_t)feat & 15) == 0;
+    const float r = pool_plane<KIND, MODE>(feat + plane * HW, wide, HW, p, inv_p, eps, lane);
+    if (lane == 0) out[plane] = r;
+}
+
+// The S feature maps of an image pyramid ([B,C,H_s,W_s] each) pooled by ONE launch: plane index -> (scale, image,
+// channel); out [S,B,C].  Same per-plane arithmetic as pool_kernel.
+struct PoolMaps {
+    const float *feat[8];
+    int hw[8];
+    int64_t first[9];           // first plane of scale s; first[S] = all planes
+};
+
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256) void pool_multi_kernel(PoolMaps maps, int S, float p, float inv_p, float eps,
+                                                         float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= maps.first[S]) return;
+    int s = 0;
+    while (s + 1 < S && plane >= maps.first[s + 1]) ++s;
+    const float *feat = maps.feat[s];
+    const int HW = maps.hw[s];
+    const bool wide = (HW & 3) == 0 && ((uintptr_t)feat & 15) == 0;
+    const float r = pool_plane<KIND, MODE>(feat + (plane - maps.first[s]) * HW, wide, HW, p, inv_p, eps, lane);
+    if (lane == 0) out[plane] = r;
 }
 
 // (A single-launch form of pool + L2N -- the workgroup that finishes an image last normalises it, hand-off through
@@ -151,6 +182,72 @@ __global__ __launch_bounds__(1024) void ms_aggregate_batch_kernel(ScalePtrs sp, 
     for (int64_t k = tid; k < D; k += 1024) dst[k] = dst[k] / nrm;
 }
 
+// pooled [S,B,D] -> out [B,D]: L2N of every scale's row (eps added to the norm), power mean over the scales, plain
+// renormalisation -- l2n_rows_kernel x S and ms_aggregate_batch_kernel in one launch, one workgroup per image.  The
+// sums run in the order of those two kernels (the norms over 256 threads, the rest over 1024), so the result is
+// bit-identical to the separate launches.
+__global__ __launch_bounds__(1024) void l2n_aggregate_kernel(const float *__restrict__ pooled, int S, int64_t B, int64_t D,
+                                                             float eps, float msp, float inv_msp, float *__restrict__ out)
+{
+    __shared__ float npart[8][4];
+    __shared__ float part[16];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    if (tid < 256) {
+        for (int s = 0; s < S; ++s) {
+            const float *row = pooled + ((int64_t)s * B + b) * D;
+            float ss = 0.0f;
+            for (int64_t k = tid; k < D; k += 256) {
+                const float v = row[k];
+                ss += v * v;
+            }
+            ss = wave_sum(ss);
+            if ((tid & 63) == 0) npart[s][tid >> 6] = ss;
+        }
+    }
+    __syncthreads();
+    float den[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        den[s] = s < S ? sqrtf((npart[s][0] + npart[s][1]) + (npart[s][2] + npart[s][3])) + eps : 1.0f;
+    float *dst = out + b * D;
+    float ss = 0.0f;
+    for (int64_t k = tid; k < D; k += 1024) {
+        float a = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s < S) {
+                const float v = pooled[((int64_t)s * B + b) * D + k] / den[s];
+                a += (msp == 1.0f) ? v : powf(v, msp);
+            }
+        a = a / (float)S;
+        if (msp != 1.0f) a = powf(a, inv_msp);
+        dst[k] = a;
+        ss += a * a;
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += part[w];
+    const float nrm = sqrtf(tot);
+    for (int64_t k = tid; k < D; k += 1024) dst[k] = dst[k] / nrm;
+}
+
+template <int KIND>
+static void launch_pool_multi(int mode, const PoolMaps &maps, int S, float p, float eps, float *out, hipStream_t s)
+{
+    const dim3 grid((unsigned)ceil_div(maps.first[S], 4)), blk(256);
+    const float inv_p = 1.0f / p;
+    switch (mode) {
+        case 1: hipLaunchKernelGGL((pool_multi_kernel<KIND, 1>), grid, blk, 0, s, maps, S, p, inv_p, eps, out); break;
+        case 2: hipLaunchKernelGGL((pool_multi_kernel<KIND, 2>), grid, blk, 0, s, maps, S, p, inv_p, eps, out); break;
+        case 3: hipLaunchKernelGGL((pool_multi_kernel<KIND, 3>), grid, blk, 0, s, maps, S, p, inv_p, eps, out); break;
+        default: hipLaunchKernelGGL((pool_multi_kernel<KIND, 0>), grid, blk, 0, s, maps, S, p, inv_p, eps, out); break;
+    }
+}
+
 template <int KIND>
 static void launch_pool(int mode, const float *feat, int64_t planes, int HW, float p, float eps,
                         float *out, hipStream_t s)
@@ -204,6 +301,53 @@ int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float 
     }
     MDX_LAUNCH_CHECK();
     if (l2n_eps >= 0.0f) return mdx_l2n_rows(out, B, C, nullptr, l2n_eps, stream);
+    return MDX_OK;
+}
+
+int mdx_pool_multi(const float *const *feats, int S, int B, int C, const int *H, const int *W, int kind, float p,
+                   float pool_eps, float *pooled, void *stream)
+{
+    MDX_CHECK_ARG(feats && H && W && pooled, "mdx_pool_multi: NULL pointer");
+    MDX_CHECK_ARG(S >= 1 && S <= 8, "mdx_pool_multi: S=%d not in 1..8", S);
+    MDX_CHECK_ARG(B > 0 && C > 0, "mdx_pool_multi: bad batch/channels [%d,%d]", B, C);
+    PoolMaps maps;
+    maps.first[0] = 0;
+    for (int s = 0; s < 8; ++s) {
+        maps.feat[s] = s < S ? feats[s] : nullptr;
+        maps.hw[s] = 0;
+        if (s < S) {
+            MDX_CHECK_ARG(feats[s], "mdx_pool_multi: map %d is NULL", s);
+            MDX_CHECK_ARG(H[s] > 0 && W[s] > 0 && (int64_t)H[s] * W[s] < (1ll << 31), "mdx_pool_multi: bad map size %d x %d", H[s], W[s]);
+            maps.hw[s] = H[s] * W[s];
+        }
+        maps.first[s + 1] = maps.first[s] + (s < S ? (int64_t)B * C : 0);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+        case MDX_POOL_GEM: {
+            MDX_CHECK_ARG(p > 0.0f && pool_eps > 0.0f, "mdx_pool_multi: gem needs p > 0 and eps > 0");
+            const int mode = p == 1.0f ? 1 : p == 2.0f ? 2 : p == 3.0f ? 3 : 0;
+            launch_pool_multi<MDX_POOL_GEM>(mode, maps, S, p, pool_eps, pooled, st);
+            break;
+        }
+        case MDX_POOL_MAC: launch_pool_multi<MDX_POOL_MAC>(1, maps, S, 1.0f, 0.0f, pooled, st); break;
+        case MDX_POOL_SPOC: launch_pool_multi<MDX_POOL_SPOC>(1, maps, S, 1.0f, 0.0f, pooled, st); break;
+        default: MDX_CHECK_ARG(false, "mdx_pool_multi: unknown pooling kind %d", kind);
+    }
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+int mdx_l2n_aggregate(const float *pooled, int S, int64_t B, int64_t D, float l2n_eps, float msp, float *out,
+                      void *stream)
+{
+    MDX_CHECK_ARG(pooled && out, "mdx_l2n_aggregate: NULL pointer");
+    MDX_CHECK_ARG(S >= 1 && S <= 8, "mdx_l2n_aggregate: S=%d not in 1..8", S);
+    MDX_CHECK_ARG(D > 0 && B > 0 && B < (1ll << 31), "mdx_l2n_aggregate: B=%lld D=%lld", (long long)B, (long long)D);
+    MDX_CHECK_ARG(msp > 0.0f && l2n_eps >= 0.0f, "mdx_l2n_aggregate: msp=%g eps=%g", (double)msp, (double)l2n_eps);
+    hipLaunchKernelGGL(l2n_aggregate_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, pooled, S, B, D, l2n_eps,
+                       msp, 1.0f / msp, out);
+    MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
 

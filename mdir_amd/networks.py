@@ -68,6 +68,14 @@ class ImageRetrievalNet(nn.Module):
             o = ops.l2n_rows_(y, bias=bias, eps=self.norm.eps)
         return o.permute(1, 0)
 
+    def fusable_tail(self):
+        """``(kind, p, eps)`` of the pooling when everything after ``features`` is pooling + L2N (no local / in-network
+        whitening, a pooling the library knows): the scales of a pyramid can then share one pooling launch
+        (``mdx_pool_multi``) and one ``mdx_l2n_aggregate``.  ``None`` otherwise."""
+        if self.lwhiten is not None or self.whiten is not None:
+            return None
+        return pool_kind(self.pool)
+
     def meta_repr(self):
         lines = ["  (meta): dict( "]
         for key in ("architecture", "local_whitening", "pooling", "regional", "whitening"):
@@ -166,6 +174,11 @@ def extract_ms(net, input, ms, msp):
     """One image, several scales -> device vector ``[D]`` (imageretrievalnet.py:309-324)."""
     pyramid = [input if s == 1 else F.interpolate(input, scale_factor=s, mode="bilinear", align_corners=False)
                for s in ms]
+    spec = net.fusable_tail() if hasattr(net, "fusable_tail") and os.environ.get("MDIR_AMD_FUSED_TAIL", "1") != "0" else None
+    if spec is not None and 2 <= len(pyramid) <= 8:    # the whole tail in two launches, bit-identical to the route below
+        feats = parallel_map(lambda x: net.features(x).contiguous(), pyramid)
+        out = ops.l2n_aggregate(ops.pool_multi(feats, *spec), net.norm.eps, msp)
+        return out if input.shape[0] > 1 else out.reshape(-1)
     per_scale = parallel_map(lambda x: _rows(net, x).contiguous(), pyramid)           # one stream per scale
     agg = [ops.ms_aggregate([rows[b] for rows in per_scale], msp) for b in range(input.shape[0])]
     return torch.stack(agg) if input.shape[0] > 1 else agg[0]

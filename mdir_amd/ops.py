@@ -140,6 +140,42 @@ def ms_aggregate_batch(mats, msp=1.0):
     return out
 
 
+def pool_multi(feats, kind="gem", p=3.0, pool_eps=1e-6):
+    """The feature maps of one pyramid (list of ``[B,C,H_s,W_s]``, same B and C) -> pooled ``[S,B,C]`` in ONE launch
+    (``mdx_pool_multi``); no normalisation."""
+    if not 1 <= len(feats) <= 8:
+        raise ValueError("1..8 scales supported, got %d" % len(feats))
+    if feats[0].dim() != 4:
+        raise ValueError("feature maps must be [B,C,H,W]")
+    B, C = feats[0].shape[:2]
+    S = len(feats)
+    ptrs = (ctypes.c_void_p * S)()
+    hs, ws = (ctypes.c_int * S)(), (ctypes.c_int * S)()
+    for i, f in enumerate(feats):
+        if f.dim() != 4 or tuple(f.shape[:2]) != (B, C):
+            raise ValueError("map %d is %s, expected [%d,%d,H,W]" % (i, tuple(f.shape), B, C))
+        ptrs[i] = _dev(f, torch.float32, "feature map").value
+        hs[i], ws[i] = f.shape[2], f.shape[3]
+    out = torch.empty((S, B, C), dtype=torch.float32, device=feats[0].device)
+    with _on(feats[0]):
+        check(_lib.lib().mdx_pool_multi(ptrs, S, B, C, hs, ws, POOL_KINDS[kind], float(p), float(pool_eps),
+                                        _vp(out.data_ptr()), _stream()), "mdx_pool_multi")
+    return out
+
+
+def l2n_aggregate(pooled, l2n_eps=1e-6, msp=1.0):
+    """Pooled ``[S,B,D]`` -> aggregated descriptors ``[B,D]`` in ONE launch (``mdx_l2n_aggregate``): L2N of every
+    scale's row, power mean over the scales, renormalisation."""
+    if pooled.dim() != 3 or not 1 <= pooled.shape[0] <= 8:
+        raise ValueError("pooled must be [S,B,D] with 1..8 scales")
+    S, B, D = pooled.shape
+    out = torch.empty((B, D), dtype=torch.float32, device=pooled.device)
+    with _on(pooled):
+        check(_lib.lib().mdx_l2n_aggregate(_dev(pooled, torch.float32, "pooled"), S, B, D, float(l2n_eps), float(msp),
+                                           _vp(out.data_ptr()), _stream()), "mdx_l2n_aggregate")
+    return out
+
+
 def u8_to_chw(images, mean, std):
     """uint8 ``[B,H,W,C]`` device images -> normalised fp32 ``[B,C,H,W]`` (``mdx_u8_to_chw``):
     ``(u / 255 - mean) / std``, the scenarios' ``pil2np | totensor | normalize``."""

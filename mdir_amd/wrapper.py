@@ -10,6 +10,7 @@ re-tiled ONCE into a resident shard instead of being re-read as a torch mat-vec 
 every image.  FakeBatch / CirFakeTupleBatch / ReflectPadMakeDivisible belong to
 training and the U-Net pre-networks and are out of scope.
 """
+import os
 import pickle
 
 import numpy as np
@@ -48,7 +49,14 @@ class Compose(object):
         for step in self.wrappers:
             tensor, meta = step.preprocess(tensor, model)
             pending.append((step, meta))
-        out = parallel_map(run, tensor) if isinstance(tensor, list) else run(tensor)
+        out = None
+        if isinstance(tensor, list) and pending and hasattr(pending[-1][0], "fused_tail"):
+            # pyramid -> descriptor with the whole tail in two launches (None: not applicable, take the general route)
+            out = pending[-1][0].fused_tail(tensor, inference, model, pending[-1][1], self.device)
+            if out is not None:
+                pending.pop()
+        if out is None:
+            out = parallel_map(run, tensor) if isinstance(tensor, list) else run(tensor)
         while pending:
             step, meta = pending.pop()
             out = step.postprocess(out, model, meta)
@@ -121,11 +129,29 @@ class CirMultiscaleAggregation(Wrapper):
         assert all(t.numel() == outputdim for t in flat)
         return ops.ms_aggregate(flat, msp)
 
-    def postprocess(self, tensor, model, waslist):
-        msp = 1
+    def _msp(self, model):
+        """Exponent of the power mean: the network's GeM ``p`` iff several scales, GeM pooling, no regional pooling and
+        no in-network whitening (wrapper.py:122-124), else 1."""
         if len(self.scales) > 1 and model.meta["pooling"] == "gem" and not model.meta["regional"] \
                 and not model.meta["whitening"]:
-            msp = model.pool.p_value() if hasattr(model.pool, "p_value") else model.pool.p.item()
+            return model.pool.p_value() if hasattr(model.pool, "p_value") else model.pool.p.item()
+        return 1
+
+    def fused_tail(self, pyramid, inference, model, waslist, device):
+        """``features`` of every scale, then the whole descriptor tail in TWO launches: ``mdx_pool_multi`` (all scales'
+        maps) and ``mdx_l2n_aggregate`` (per-scale L2N + power mean + renormalisation) instead of 2 launches per scale
+        + 1.  Only when the network is called directly and everything after its ``features`` is pooling + L2N
+        (``ImageRetrievalNet.fusable_tail``); bit-identical to the general route.  ``None`` otherwise."""
+        spec = model.fusable_tail() if inference is model and hasattr(model, "fusable_tail") else None
+        if spec is None or waslist or len(self.scales) < 2 or len(pyramid) != len(self.scales) \
+                or os.environ.get("MDIR_AMD_FUSED_TAIL", "1") == "0":
+            return None
+        feats = parallel_map(lambda x: model.features(x.to(device)).contiguous(), pyramid)
+        out = ops.l2n_aggregate(ops.pool_multi(feats, *spec), model.norm.eps, self._msp(model))
+        return out if out.shape[0] > 1 else out.reshape(-1)
+
+    def postprocess(self, tensor, model, waslist):
+        msp = self._msp(model)
         n = len(self.scales)
         if not waslist:
             return self.aggregate_tensor(tensor, n, model.meta["out_channels"], msp)

@@ -38,6 +38,15 @@ def ms_aggregate_batch(mats, msp=1.0):
     return torch.from_numpy(np.stack([O.ms_aggregate(st[:, b], msp) for b in range(st.shape[1])]))
 
 
+def pool_multi(feats, kind="gem", p=3.0, pool_eps=1e-6):
+    return torch.stack([pool_l2n(f, kind, p, pool_eps, l2n_eps=None) for f in feats])
+
+
+def l2n_aggregate(pooled, l2n_eps=1e-6, msp=1.0):
+    st = np.stack([O.l2n(pooled[s].detach().numpy(), l2n_eps) for s in range(pooled.shape[0])])     # [S,B,D]
+    return torch.from_numpy(np.stack([O.ms_aggregate(st[:, b], msp) for b in range(st.shape[1])]))
+
+
 class DescriptorIndex:
     def __init__(self, vecs, layout="DN", row_offset=0):
         v = vecs.detach().numpy()
@@ -101,7 +110,7 @@ def rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, off_t):
     return cnt
 
 
-NAMES = ("pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "DescriptorIndex", "rank_full", "topk", "rank_of",
+NAMES = ("pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "DescriptorIndex", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 

@@ -160,6 +160,32 @@ def test_pool_batch_and_zero_map(ops):
     assert not np.isnan(got).any()
 
 
+@pytest.mark.parametrize("B,C,sizes", [(1, 2048, [(24, 32), (17, 23), (12, 16)]), (4, 512, [(48, 64), (33, 45), (24, 32)]),
+                                       (3, 67, [(7, 5), (1, 1)]), (2, 256, [(6, 9)] * 8)])
+@pytest.mark.parametrize("kind,p", [("gem", 3.0), ("gem", 2.92), ("mac", 1.0), ("spoc", 1.0)])
+def test_pool_multi_l2n_aggregate_two_launch_tail(ops, B, C, sizes, kind, p):
+    """The two-launch descriptor tail (mdx_pool_multi + mdx_l2n_aggregate) of a pyramid: bit-identical to the launches
+    it replaces (mdx_pool_l2n per scale, mdx_ms_aggregate_batch) and equal to the oracle's gem -> l2n -> aggregate."""
+    maps = [sparse_map(20 + i, (B, C, h, w)) for i, (h, w) in enumerate(sizes)]
+    maps[0][B - 1] = 0.0                                            # an all-zero map: eps keeps its row finite
+    md = [dev(m) for m in maps]
+    pooled = ops.pool_multi(md, kind, p)
+    assert pooled.shape == (len(sizes), B, C)
+    for s_, m in enumerate(md):
+        np.testing.assert_array_equal(pooled[s_].cpu().numpy(), ops.pool_l2n(m, kind, p, l2n_eps=None).cpu().numpy())
+    msp = p if kind == "gem" else 1.0
+    got = ops.l2n_aggregate(pooled, 1e-6, msp).cpu().numpy()
+    want_launches = ops.ms_aggregate_batch([ops.pool_l2n(m, kind, p) for m in md], msp).cpu().numpy()
+    np.testing.assert_array_equal(got, want_launches)
+    pool = {"gem": lambda x: O.gem(x, p), "mac": O.mac, "spoc": O.spoc}[kind]
+    per = np.stack([O.l2n(pool(m)) for m in maps])                  # [S,B,C]
+    live = [b for b in range(B) if np.abs(per[:, b]).sum() > 0]     # 0/0 in the renormalisation of an all-zero image (as the reference)
+    want = np.stack([O.ms_aggregate(per[:, b], msp) for b in live])
+    np.testing.assert_allclose(got[live], want, rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        ops.pool_multi([md[0], md[0][:, :C - 1].contiguous()], kind, p)
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 48, 64), (2, 256, 17, 23), (1, 2048, 23, 17), (3, 5, 1, 1), (1, 7, 3, 5),
                                    (1, 64, 384, 512), (1, 2048, 24, 32)])
 def test_bn_act_vs_oracle_and_torch(ops, shape):

@@ -111,9 +111,11 @@ def measure(args):
         t_backbone = timeit(lambda: trunk(imgs[0])) if trunk.graphs else t_backbone_eager
         p = net.pool.p_value()
 
-        def tail_mdx():     # per image: pool + L2N of the three maps and the batched aggregation; the whitening is applied to the
-            per = [ops.pool_l2n(f, "gem", p, 1e-6, 1e-6) for f in feats]          # finished [N,D] matrix (timed below)
-            return ops.ms_aggregate_batch(per, p)
+        def tail_mdx():     # per image, as the wrapper chain runs it: ONE pooling launch over the three maps, ONE launch for the
+            return ops.l2n_aggregate(ops.pool_multi(feats, "gem", p, 1e-6), 1e-6, p)   # three L2Ns + the aggregation; the
+                                                                                   # whitening goes over the finished [N,D] matrix
+        def tail_mdx_r1():  # the seven launches this replaced (pool + L2N per scale, batched aggregation)
+            return ops.ms_aggregate_batch([ops.pool_l2n(f, "gem", p, 1e-6, 1e-6) for f in feats], p)
 
         rows = torch.cat([tail_mdx() for _ in range(args.images)], dim=0)          # [N,D] unwhitened descriptors
 
@@ -135,6 +137,8 @@ def measure(args):
 
         a, b = tail_whiten_all()[0].reshape(-1), tail_torch().reshape(-1)
         err = float((a - b).abs().max())
+        assert torch.equal(tail_mdx(), tail_mdx_r1())
+        t_tail_seven = timeit(tail_mdx_r1) + timeit(tail_whiten_all) / args.images
         t_tail_eager = timeit(tail_mdx) + timeit(tail_whiten_all) / args.images
         # as extraction runs it: inside a hipGraph replay (no Python / dispatcher time between the launches)
         tail_graph = ShapeGraphs(lambda x: tail_mdx(), warmup=1)
@@ -149,12 +153,12 @@ def measure(args):
             "ms_per_image": round(1e3 * total / args.images, 3),
             "backbone_ms_per_image": round(t_backbone, 3), "backbone_ms_per_image_eager_launches": round(t_backbone_eager, 3),
             "tail_ms_per_image_mdx": round(t_tail, 4), "tail_ms_per_image_mdx_as_its_own_graph_replay": round(t_tail_replay, 4),
-            "tail_ms_per_image_torch_ops": round(t_tail_torch, 4),
+            "tail_ms_per_image_torch_ops": round(t_tail_torch, 4), "tail_ms_per_image_seven_launches": round(t_tail_seven, 4),
             "roofline_tail": {"bound": "hbm", "bytes_per_image": tail_bytes, "achieved": round(tail_bytes / (t_tail * 1e-3) / 1e9, 1),
                               "peak": 8000.0, "unit": "GB/s", "frac": round(tail_bytes / (t_tail * 1e-3) / 1e9 / 8000.0, 4),
-                              "what": "3 x GeM + L2N (two launches each), batched aggregation (one launch), whitening of the finished [N,D] "
-                                      "matrix / N; a batch-1 image is four short dependent launches (eager: ~10 us of host time each; a graph "
-                                      "replay of just these four costs its fixed ~15 us): launch latency, not bandwidth, bounds it"},
+                              "what": "GeM of the three maps (one launch), their L2Ns + the aggregation (one launch), whitening of the "
+                                      "finished [N,D] matrix / N: two short dependent launches per image (or per batch of 4), so launch "
+                                      "latency, not bandwidth, bounds it"},
             "tail_max_abs_diff_vs_torch_ops": err, "dtype": "f32", "data": "synthetic",
             "hipgraph_replays": getattr(describe, "replays", 0)}
 
