@@ -173,6 +173,15 @@ int64_t mdx_rank_workspace(int64_t n, int64_t nq);
 int mdx_rank_full(const float *scores, int64_t n, int64_t nq, int64_t id_offset, int64_t *ranks,
                   void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The same ranking when row q of the scores lies in pieces: block g is a [nq, widths[g]] row-major matrix and
+ * row q of the problem is its rows q side by side, g = 0 .. nblocks-1 (<= 32), n = sum of the widths.  These are
+ * the peer blocks the multi-GPU exchange delivers ("all-gather of per-shard partial scores", BASELINE.json
+ * north_star): the first pass reads them in place, no re-blocked [nq, n] copy is made.  Workspace of
+ * mdx_rank_workspace(n, nq).  Ids are column positions in the concatenation + id_offset. */
+int mdx_rank_full_segments(const float *const *blocks, const int64_t *widths, int nblocks, int64_t nq,
+                           int64_t id_offset, int64_t *ranks, void *workspace, int64_t workspace_bytes,
+                           void *stream);
+
 /* First k entries of mdx_rank_full per query, with their scores:
  *   top_ids [nq,k] int64, top_scores [nq,k] fp32 (either may be NULL).
  * For k << n this is a radix SELECT (the k-th key found digit by digit from histograms, candidates

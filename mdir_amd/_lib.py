@@ -62,6 +62,7 @@ def _declare(lib):
         "mdx_scores": (i32, [p, p, i64, i32, p, p, p, i64, p]),
         "mdx_rank_workspace": (i64, [i64, i64]),
         "mdx_rank_full": (i32, [p, i64, i64, i64, p, p, i64, p]),
+        "mdx_rank_full_segments": (i32, [pp, pi64, i32, i64, i64, p, p, i64, p]),
         "mdx_topk": (i32, [p, i64, i64, i64, i64, p, p, p, i64, p]),
         "mdx_rank_of": (i32, [p, i64, i64, p, p, i64, p, p, p]),
         "mdx_gather_scores": (i32, [p, i64, i64, p, p, i64, p, p]),
@@ -76,7 +77,7 @@ def _declare(lib):
 EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
            "mdx_ms_aggregate_batch", "mdx_pool_multi", "mdx_l2n_aggregate", "mdx_bn_act", "mdx_u8_to_chw",
            "mdx_index_create", "mdx_index_create_ex", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
-           "mdx_scores", "mdx_rank_workspace", "mdx_rank_full", "mdx_topk", "mdx_rank_of",
+           "mdx_scores", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of",
            "mdx_gather_scores", "mdx_rank_count")
 
 

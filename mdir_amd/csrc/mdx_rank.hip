@@ -53,6 +53,29 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t *buf, int P, int tid, 
 // so that their wide loads are aligned; the scores keep their own row length n.
 enum { FMT_SCORES = 0, FMT_KV = 1, FMT_A = 2, FMT_B = 3, FMT_C = 4, FMT_RANKS = 5 };
 
+// Scores that arrive as column blocks (the peer blocks of the multi-GPU exchange: block g is a [nq, width_g] row-major
+// matrix, row q of the problem = its rows q side by side): pass 0 reads them where they lie instead of a re-blocked copy.
+constexpr int MAX_SEG = 32;
+struct SegTable {
+    const float *p[MAX_SEG];
+    int64_t start[MAX_SEG + 1];     // first column of block g; start[nseg] = n
+    int nseg;                       // 0: plain [nq, n] scores
+};
+
+__device__ __forceinline__ int seg_of(const SegTable &t, int64_t i)
+{
+    int g = 0;
+    while (g + 1 < t.nseg && i >= t.start[g + 1]) ++g;
+    return g;
+}
+
+// element i of row q
+__device__ __forceinline__ const float *seg_elem(const SegTable &t, int64_t q, int64_t i)
+{
+    const int g = seg_of(t, i);
+    return t.p[g] + q * (t.start[g + 1] - t.start[g]) + (i - t.start[g]);
+}
+
 // per-tile digit histogram -> block_hist[q][b][digit].  A histogram does not care which lane counts which
 // element, so a lane takes consecutive elements with one wide load: 4 scores / key words (16 bytes,
 // dword-aligned for the scores: rows of an odd length start anywhere), or 8 of the u16 / u8 middle parts.
@@ -67,7 +90,7 @@ template <int SRC>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__restrict__ scores,
                                                                  const void *__restrict__ src, int64_t n,
                                                                  int64_t stride, int nblk, int shift,
-                                                                 uint32_t *__restrict__ block_hist)
+                                                                 uint32_t *__restrict__ block_hist, SegTable seg)
 {
     static_assert(SORT_ITEMS == 8, "a lane takes 8 elements of a tile");
     constexpr bool FIRST = SRC == FMT_SCORES;
@@ -106,7 +129,20 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__
             first[v] = b0 * SORT_TILE + (v * SORT_THREADS + tid) * 4;
             w[v] = u32x4u{0u, 0u, 0u, 0u};
         }
-        if ((b0 + 1) * SORT_TILE <= n) {        // whole tile (uniform branch): both loads in flight together
+        bool straddles = false;                 // (uniform) the tile lies in two column blocks: element-wise below
+        if (FIRST && seg.nseg > 0) {
+            const int g = seg_of(seg, b0 * SORT_TILE);
+            const int64_t tile_end = (b0 + 1) * SORT_TILE < n ? (b0 + 1) * SORT_TILE : n;
+            straddles = tile_end > seg.start[g + 1];
+            p = (const uint32_t *)(seg.p[g] + q * (seg.start[g + 1] - seg.start[g]) - seg.start[g]);
+        }
+        if (straddles) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (first[v] + j < n) w[v][j] = *(const uint32_t *)seg_elem(seg, q, first[v] + j);
+        } else if ((b0 + 1) * SORT_TILE <= n) {        // whole tile (uniform branch): both loads in flight together
 #pragma unroll
             for (int v = 0; v < 2; ++v) w[v] = *(const u32x4u *)(p + first[v]);
         } else {
@@ -197,7 +233,7 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
     uint32_t *__restrict__ w_out, void *__restrict__ h_out, int64_t *__restrict__ ranks,
     float *__restrict__ top_scores, int64_t n, int64_t stride, int nblk, int shift,
     const uint32_t *__restrict__ block_hist, const uint32_t *__restrict__ digit_tot, int64_t id_offset,
-    int64_t klimit)
+    int64_t klimit, SegTable seg)
 {
     constexpr bool FIRST = IN == FMT_SCORES, LAST = OUT == FMT_RANKS;
     constexpr bool VAL_IN_KEY = IN == FMT_C;        // the id is the low 24 bits of the word the digit comes from
@@ -245,7 +281,15 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         // is defined on.  Later passes find their input in the caches, where the same detour costs 6-30 us per pass.
         typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
         const uint32_t *src = (const uint32_t *)scores + base + tile0;
-        if (tile_n == SORT_TILE) {      // whole tile (uniform branch): both loads in flight together
+        bool straddles = false;         // (uniform) the tile lies in two column blocks of segmented scores
+        if (seg.nseg > 0) {
+            const int g = seg_of(seg, tile0);
+            straddles = tile0 + tile_n > seg.start[g + 1];
+            src = (const uint32_t *)(seg.p[g] + q * (seg.start[g + 1] - seg.start[g]) + (tile0 - seg.start[g]));
+        }
+        if (straddles) {
+            for (int e = tid; e < tile_n; e += SORT_THREADS) skey[e] = desc_key(*seg_elem(seg, q, tile0 + e));
+        } else if (tile_n == SORT_TILE) {      // whole tile (uniform branch): both loads in flight together
             u32x4u w[SORT_ITEMS / 4];
 #pragma unroll
             for (int v = 0; v < SORT_ITEMS / 4; ++v) w[v] = *(const u32x4u *)(src + (v * SORT_THREADS + tid) * 4);
@@ -605,7 +649,7 @@ static bool atomic_rank_ok(hipStream_t s)
 
 template <int IN, int OUT>
 static void sort_pass(const RankWs &ws, const float *scores, int64_t n, int64_t nq, int pass, int64_t id_offset,
-                      int64_t *ranks, float *top_scores, int64_t klimit, bool arank, hipStream_t s)
+                      int64_t *ranks, float *top_scores, int64_t klimit, bool arank, const SegTable &seg, hipStream_t s)
 {
     const int shift = 8 * pass;
     const uint32_t *w_in = pass == 0 ? nullptr : ws.w[(pass - 1) & 1];
@@ -614,24 +658,27 @@ static void sort_pass(const RankWs &ws, const float *scores, int64_t n, int64_t 
     // the histogram reads only the array the digit of this pass lives in
     const void *digits = (IN == FMT_A || IN == FMT_B) ? h_in : (const void *)w_in;
     hipLaunchKernelGGL(sort_hist_kernel<IN>, grid, blk, 0, s, scores, digits, n, ws.stride, ws.nblk, shift,
-                       ws.block_hist);
+                       ws.block_hist, seg);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX / SCAN_DIGITS, (unsigned)nq), dim3(SCAN_GROUPS * SCAN_DIGITS), 0, s,
                        ws.block_hist, ws.nblk, ws.digit_tot);
     if (arank)
         hipLaunchKernelGGL((sort_scatter_kernel<IN, OUT, true>), grid, blk, 0, s, scores, w_in, h_in, ws.w[pass & 1],
                            ws.h[pass & 1], ranks, top_scores, n, ws.stride, ws.nblk, shift, ws.block_hist, ws.digit_tot,
-                           id_offset, klimit);
+                           id_offset, klimit, seg);
     else
         hipLaunchKernelGGL((sort_scatter_kernel<IN, OUT, false>), grid, blk, 0, s, scores, w_in, h_in, ws.w[pass & 1],
                            ws.h[pass & 1], ranks, top_scores, n, ws.stride, ws.nblk, shift, ws.block_hist, ws.digit_tot,
-                           id_offset, klimit);
+                           id_offset, klimit, seg);
 }
 
 static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offset, int64_t *ranks,
                      float *top_scores, int64_t klimit, void *workspace, int64_t workspace_bytes,
-                     hipStream_t s, const char *who)
+                     hipStream_t s, const char *who, const SegTable *segments = nullptr)
 {
-    MDX_CHECK_ARG(scores, "%s: NULL scores", who);
+    SegTable seg;
+    if (segments) seg = *segments;
+    else memset(&seg, 0, sizeof seg);
+    MDX_CHECK_ARG(scores || seg.nseg > 0, "%s: NULL scores", who);
     MDX_CHECK_ARG(n > 0 && nq > 0, "%s: n=%lld nq=%lld must be positive", who, (long long)n,
                   (long long)nq);
     MDX_CHECK_ARG(n < (1ll << 32) && nq < 65536, "%s: n or nq too large", who);
@@ -647,15 +694,15 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
     static const bool no_pack = getenv("MDX_SORT_NO_PACK") && atoi(getenv("MDX_SORT_NO_PACK")) != 0;
     const bool arank = atomic_rank_ok(s);
     if (n <= (1ll << 24) && !no_pack) {
-        sort_pass<FMT_SCORES, FMT_A>(ws, scores, n, nq, 0, id_offset, ranks, top_scores, klimit, arank, s);
-        sort_pass<FMT_A, FMT_B>(ws, scores, n, nq, 1, id_offset, ranks, top_scores, klimit, arank, s);
-        sort_pass<FMT_B, FMT_C>(ws, scores, n, nq, 2, id_offset, ranks, top_scores, klimit, arank, s);
-        sort_pass<FMT_C, FMT_RANKS>(ws, scores, n, nq, 3, id_offset, ranks, top_scores, klimit, arank, s);
+        sort_pass<FMT_SCORES, FMT_A>(ws, scores, n, nq, 0, id_offset, ranks, top_scores, klimit, arank, seg, s);
+        sort_pass<FMT_A, FMT_B>(ws, scores, n, nq, 1, id_offset, ranks, top_scores, klimit, arank, seg, s);
+        sort_pass<FMT_B, FMT_C>(ws, scores, n, nq, 2, id_offset, ranks, top_scores, klimit, arank, seg, s);
+        sort_pass<FMT_C, FMT_RANKS>(ws, scores, n, nq, 3, id_offset, ranks, top_scores, klimit, arank, seg, s);
     } else {
-        sort_pass<FMT_SCORES, FMT_KV>(ws, scores, n, nq, 0, id_offset, ranks, top_scores, klimit, arank, s);
-        sort_pass<FMT_KV, FMT_KV>(ws, scores, n, nq, 1, id_offset, ranks, top_scores, klimit, arank, s);
-        sort_pass<FMT_KV, FMT_KV>(ws, scores, n, nq, 2, id_offset, ranks, top_scores, klimit, arank, s);
-        sort_pass<FMT_KV, FMT_RANKS>(ws, scores, n, nq, 3, id_offset, ranks, top_scores, klimit, arank, s);
+        sort_pass<FMT_SCORES, FMT_KV>(ws, scores, n, nq, 0, id_offset, ranks, top_scores, klimit, arank, seg, s);
+        sort_pass<FMT_KV, FMT_KV>(ws, scores, n, nq, 1, id_offset, ranks, top_scores, klimit, arank, seg, s);
+        sort_pass<FMT_KV, FMT_KV>(ws, scores, n, nq, 2, id_offset, ranks, top_scores, klimit, arank, seg, s);
+        sort_pass<FMT_KV, FMT_RANKS>(ws, scores, n, nq, 3, id_offset, ranks, top_scores, klimit, arank, seg, s);
     }
     MDX_LAUNCH_CHECK();
     return MDX_OK;
@@ -1209,6 +1256,27 @@ int mdx_rank_full(const float *scores, int64_t n, int64_t nq, int64_t id_offset,
     MDX_CHECK_ARG(ranks, "mdx_rank_full: NULL ranks");
     return rank_impl(scores, n, nq, id_offset, ranks, nullptr, n, workspace, workspace_bytes,
                      (hipStream_t)stream, "mdx_rank_full");
+}
+
+int mdx_rank_full_segments(const float *const *blocks, const int64_t *widths, int nblocks, int64_t nq, int64_t id_offset,
+                           int64_t *ranks, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    MDX_CHECK_ARG(blocks && widths && ranks, "mdx_rank_full_segments: NULL pointer");
+    MDX_CHECK_ARG(nblocks >= 1 && nblocks <= MAX_SEG, "mdx_rank_full_segments: %d blocks, 1..%d supported", nblocks, MAX_SEG);
+    SegTable seg;
+    memset(&seg, 0, sizeof seg);
+    int64_t n = 0;
+    for (int g = 0; g < nblocks; ++g) {
+        MDX_CHECK_ARG(widths[g] >= 0 && (widths[g] == 0 || blocks[g]), "mdx_rank_full_segments: block %d is NULL or negative", g);
+        if (widths[g] == 0) continue;          // an empty shard contributes no columns
+        seg.p[seg.nseg] = blocks[g];
+        seg.start[seg.nseg] = n;
+        n += widths[g];
+        seg.start[++seg.nseg] = n;
+    }
+    MDX_CHECK_ARG(n > 0, "mdx_rank_full_segments: no columns");
+    return rank_impl(nullptr, n, nq, id_offset, ranks, nullptr, n, workspace, workspace_bytes, (hipStream_t)stream,
+                     "mdx_rank_full_segments", &seg);
 }
 
 int mdx_topk(const float *scores, int64_t n, int64_t nq, int64_t k, int64_t id_offset,

@@ -311,6 +311,34 @@ def rank_full(scores, id_offset=0, out=None, workspace=None):
     return out
 
 
+MAX_RANK_SEGMENTS = 32
+
+
+def rank_full_segments(blocks, id_offset=0, out=None, workspace=None):
+    """``rank_full`` of scores that lie in column blocks: ``blocks[g]`` is ``[nq, w_g]`` and row q of the problem is
+    the blocks' rows q side by side (the peer blocks of the multi-GPU exchange).  No concatenated copy is made:
+    the first pass of the sort reads the blocks in place (``mdx_rank_full_segments``)."""
+    if not 1 <= len(blocks) <= MAX_RANK_SEGMENTS:
+        raise ValueError("1..%d blocks supported, got %d" % (MAX_RANK_SEGMENTS, len(blocks)))
+    nq = blocks[0].shape[0]
+    ptrs = (ctypes.c_void_p * len(blocks))()
+    widths = (ctypes.c_int64 * len(blocks))()
+    for g, b in enumerate(blocks):
+        if b.dim() != 2 or b.shape[0] != nq:
+            raise ValueError("block %d is %s, expected [%d, w]" % (g, tuple(b.shape), nq))
+        ptrs[g] = _dev(b, torch.float32, "score block").value
+        widths[g] = b.shape[1]
+    n = sum(int(b.shape[1]) for b in blocks)
+    dev = blocks[0].device
+    ws = workspace if workspace is not None else _workspace(rank_workspace_bytes(n, nq), dev)
+    if out is None:
+        out = torch.empty((nq, n), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().mdx_rank_full_segments(ptrs, widths, len(blocks), nq, int(id_offset), _dev(out, torch.int64, "ranks"),
+                                                _vp(ws.data_ptr()), ws.numel(), _stream()), "mdx_rank_full_segments")
+    return out
+
+
 def topk(scores, k, id_offset=0, workspace=None):
     """(ids int64 [nq,k], scores fp32 [nq,k]) of the k best rows per query."""
     sp = _dev(scores, torch.float32, "scores")

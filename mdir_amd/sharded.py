@@ -37,6 +37,12 @@ class HipBackend:
         from . import ops
         return ops.rank_full(scores, id_offset)
 
+    def rank_full_segments(self, blocks, id_offset=0):
+        from . import ops
+        if len(blocks) > ops.MAX_RANK_SEGMENTS:
+            return ops.rank_full(torch.cat(blocks, dim=1), id_offset)
+        return ops.rank_full_segments(blocks, id_offset)
+
     def topk(self, scores, k, id_offset=0):
         from . import ops
         return ops.topk(scores, k, id_offset)
@@ -48,6 +54,20 @@ class HipBackend:
     def rank_count_(self, cnt, scores, id_offset, ref_scores, ref_ids, offsets):
         from . import ops
         return ops.rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, offsets)
+
+
+class BlockScores:
+    """``[Q_mine, N]`` similarities held as the column blocks the exchange delivered."""
+
+    def __init__(self, blocks):
+        self.blocks = blocks
+
+    @property
+    def shape(self):
+        return (self.blocks[0].shape[0], sum(int(b.shape[1]) for b in self.blocks))
+
+    def dense(self):
+        return self.blocks[0] if len(self.blocks) == 1 else torch.cat(self.blocks, dim=1)
 
 
 def shard_bounds(n_total, world, rank):
@@ -236,11 +256,18 @@ class ShardedIndex:
         return torch.cat(blocks, dim=1), (qlo, qhi)
 
     def exchanged_scores(self, queries, qlayout="DN"):
-        """Similarities of MY queries against ALL rows: per chunk, similarity kernel then
+        """Similarities of MY queries against ALL rows as one ``[Q_mine, N]`` matrix (``exchanged_blocks`` + one
+        concatenation)."""
+        blocks, bounds = self.exchanged_blocks(queries, qlayout)
+        return (blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1)), bounds
+
+    def exchanged_blocks(self, queries, qlayout="DN"):
+        """Similarities of MY queries against ALL rows, as the column blocks the exchange delivers (global row order:
+        peer-major, chunk-minor; block = ``[Q_mine, rows of that chunk]``): per chunk, similarity kernel then
         all-to-all, with chunk c's transfer overlapping chunk c+1's kernel."""
         if self.world == 1:
             s = self.local_scores(queries, qlayout)
-            return s, (0, s.shape[0])
+            return [s], (0, s.shape[0])
         pending, nq = [], None
         ev = self._events()
         if ev:
@@ -257,20 +284,26 @@ class ShardedIndex:
         if ev:
             ev[2].record()                                # the compute stream has waited for the last transfer
         # global row order: peer-major, chunk-minor
-        blocks = [per_chunk[c][r] for r in range(self.world) for c in range(self.chunks)]
-        return torch.cat(blocks, dim=1), (qlo, qhi)
+        return [per_chunk[c][r] for r in range(self.world) for c in range(self.chunks)], (qlo, qhi)
 
     def rank_queries(self, queries, qlayout="DN"):
-        """Exact full ranking, query-partitioned: returns ``(ranks [Q_mine, N] int64
-        with GLOBAL ids, scores [Q_mine, N], (qlo, qhi))``."""
-        s_mine, (qlo, qhi) = self.exchanged_scores(queries, qlayout)
+        """Exact full ranking, query-partitioned: returns ``(ranks [Q_mine, N] int64 with GLOBAL ids,
+        scores, (qlo, qhi))``.  The peer blocks of the exchange enter the sort as segments
+        (``mdx_rank_full_segments``): no re-blocked ``[Q_mine, N]`` copy is made on the way to the ranking.
+        ``scores`` is a :class:`BlockScores`: ``.blocks`` as delivered, ``.dense()`` the ``[Q_mine, N]`` matrix
+        (concatenated on demand)."""
+        blocks, (qlo, qhi) = self.exchanged_blocks(queries, qlayout)
         if qhi == qlo:
             ranks = torch.empty((0, self.n_total), dtype=torch.int64, device=self.device)
+        elif len(blocks) == 1:
+            ranks = self.backend.rank_full(blocks[0], 0)
+        elif hasattr(self.backend, "rank_full_segments"):
+            ranks = self.backend.rank_full_segments(blocks, 0)
         else:
-            ranks = self.backend.rank_full(s_mine, 0)
+            ranks = self.backend.rank_full(torch.cat(blocks, dim=1), 0)
         if self.phases:
             self.phases[3].record()
-        return ranks, s_mine, (qlo, qhi)
+        return ranks, BlockScores(blocks), (qlo, qhi)
 
     def _events(self):
         """Four events on the compute stream around the phases of ``rank_queries`` (GPU only)."""

@@ -242,6 +242,9 @@ def test_full_size_shards_equal_whole(big):
     inv.scatter_(1, rk, torch.arange(n, device=DEV)[None, :].expand(nq, n))
     for qi in range(nq):
         assert bool((cnt[off[qi]:off[qi + 1]] == inv[qi][ids_t[off[qi]:off[qi + 1]]]).all())
+    # what a rank of an 8-GPU job sorts: its 9 queries against the 8 peer blocks, read in place as segments
+    blocks = [sc[:9, lo:hi].contiguous() for lo, hi in (shard_bounds(n, 8, r) for r in range(8))]
+    assert bool((ops.rank_full_segments(blocks) == rk[:9]).all())
 
 
 def test_hard_negative_mining_on_gpu(golden):

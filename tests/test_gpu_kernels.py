@@ -92,6 +92,24 @@ def test_rank_full_bit_exact(ops, n, nq):
     np.testing.assert_array_equal(got, want + 1000)
 
 
+@pytest.mark.parametrize("widths", [[2500, 2493], [4096, 4096, 1], [1, 5000, 0, 3, 9000], [700] * 32, [4993],
+                                    [125625, 125624, 125624]])
+def test_rank_full_segments_equals_rank_full(ops, widths):
+    """Scores delivered as column blocks (the peer blocks of the multi-GPU exchange) enter the sort in place: same
+    ranking as the concatenated matrix, bit for bit -- blocks that end inside a sort tile, empty blocks, one block,
+    the maximum of 32, ties across block borders, NaN."""
+    rng = np.random.default_rng(sum(widths))
+    nq = 3
+    blocks = [(np.round(rng.standard_normal((nq, w)) * 50) / 50).astype(np.float32) for w in widths]
+    blocks[0][1, 0] = np.nan
+    whole = np.concatenate(blocks, axis=1)
+    got = ops.rank_full_segments([dev(b) for b in blocks], id_offset=11).cpu().numpy()
+    np.testing.assert_array_equal(got, OC.rank_full(whole) + 11)
+    np.testing.assert_array_equal(got, ops.rank_full(dev(whole), id_offset=11).cpu().numpy())
+    with pytest.raises(ValueError):
+        ops.rank_full_segments([dev(blocks[0])] * 33)
+
+
 def test_rank_tie_fixture(ops, golden):
     g = golden("g7_ranking.npz")
     ix = ops.DescriptorIndex(dev(g["tie_vecs"]), "DN")

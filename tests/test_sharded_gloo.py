@@ -36,6 +36,10 @@ class OracleBackend:
         from oracle import chain as OC
         return torch.from_numpy(OC.rank_full(scores.numpy()) + id_offset)
 
+    def rank_full_segments(self, blocks, id_offset=0):
+        assert len(blocks) > 1 and all(b.shape[0] == blocks[0].shape[0] for b in blocks)
+        return self.rank_full(torch.cat(blocks, dim=1), id_offset)
+
     def topk(self, scores, k, id_offset=0):
         from oracle import chain as OC
         rk = OC.rank_full(scores.numpy())[:, :k]
@@ -92,7 +96,7 @@ def _worker(rank, world, port, n, nq, d, out_dir, chunks, exchange=None):
                           __import__("oracle.chain", fromlist=["x"]).scores_chain(vecs, qvecs))      # all-gather form
     tk_ids, tk_vals = sh.topk_queries(torch.from_numpy(qvecs), 9, "DN")
     big_ids, _ = sh.topk_queries(torch.from_numpy(qvecs), n + 5, "DN")          # k beyond every shard and beyond N
-    np.savez(os.path.join(out_dir, "r%d.npz" % rank), ranks=rk.numpy(), scores=sc.numpy(), q=np.array([qlo, qhi]),
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), ranks=rk.numpy(), scores=sc.dense().numpy(), q=np.array([qlo, qhi]),
              pos=pos.numpy(), off=np.array(off), tk_ids=tk_ids.numpy(), tk_vals=tk_vals.numpy(), big_ids=big_ids.numpy())
     dist.destroy_process_group()
 
