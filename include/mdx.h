@@ -106,6 +106,19 @@ int mdx_bn_act(float *x, const float *residual, int64_t N, int64_t C, int64_t HW
 int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W, int C, const float *mean,
                   const float *std, float *out, void *stream);
 
+/* One pass of the image down-scaling, along the width (axis 1: [B,H,W,C] -> [B,H,out_len,C]) or the height
+ * (axis 0: -> [B,out_len,W,C]) of uint8 images:
+ *   dst[o] = clip8((2^21 + sum_{t < count[o]} src[first[o] + t] * k[o*ksize + t]) >> 22)
+ * = ImagingResampleHorizontal_8bpc / ImagingResampleVertical_8bpc of Pillow (src/libImaging/Resample.c), the
+ * arithmetic of `img.thumbnail((imsize, imsize), Image.ANTIALIAS)` in imresize
+ * (cirtorch/datasets/datahelpers.py:48-50) as called by ImagesFromList.__getitem__
+ * (cirtorch/datasets/genericdataset.py:63-64).  bounds int32 [out_len,2] = (first, count) and the fixed-point
+ * taps k int32 [out_len,ksize] (round(w * 2^22), Pillow's precompute_coeffs + normalize_coeffs_8bpc) are DEVICE
+ * arrays computed once per (source length, out_len) by the host (mdir_amd/resample.py).  Width pass first, then
+ * height, as Pillow orders them; the result equals Pillow's pixel for pixel. */
+int mdx_resample_u8(const uint8_t *src, int64_t B, int H, int W, int C, int axis, int out_len,
+                    const int32_t *bounds, const int32_t *k, int ksize, uint8_t *dst, void *stream);
+
 /* Multi-scale aggregation of S per-scale descriptors of one image:
  *   out[k] = v[k] / ||v||,  v[k] = (sum_s vecs[s][k]^msp / S)^(1/msp)     (no eps)
  * Replaces CirMultiscaleAggregation.aggregate_tensor

@@ -156,3 +156,62 @@ extern "C" int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Image down-scaling on the device: one pass (along the width or the height) of Pillow's separable resampling of
+// 8-bit images -- what `img.thumbnail((imsize, imsize), Image.ANTIALIAS)` of imresize runs
+// (cirtorch/datasets/datahelpers.py:48-50; Pillow src/libImaging/Resample.c ImagingResampleHorizontal_8bpc /
+// ImagingResampleVertical_8bpc) -- with the taps precomputed on the host in Pillow's fixed point (2^22):
+//     out = clip8((2^21 + sum_t src[first + t] * k[t]) >> 22)
+// Integer arithmetic, so the thumbnail is Pillow's pixel for pixel; the loader workers then only decode.
+// ---------------------------------------------------------------------------
+namespace mdx {
+
+template <int AXIS>
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int H,
+                                                          int W, int C, int out_len, const int32_t *__restrict__ bounds,
+                                                          const int32_t *__restrict__ k, int ksize, int64_t total)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int64_t base, stride;
+    int o;
+    if (AXIS == 1) {            // [B,H,W,C] -> [B,H,out,C]
+        const int c = (int)(idx % C);
+        const int64_t r = idx / C;
+        o = (int)(r % out_len);
+        base = (r / out_len) * W * C + c;
+        stride = C;
+    } else {                    // [B,H,W,C] -> [B,out,W,C]
+        const int64_t line = (int64_t)W * C;
+        const int64_t e = idx % line, r = idx / line;
+        o = (int)(r % out_len);
+        base = (r / out_len) * H * line + e;
+        stride = line;
+    }
+    const int first = bounds[2 * o], count = bounds[2 * o + 1];
+    const int32_t *kk = k + (int64_t)o * ksize;
+    const uint8_t *s = src + base + first * stride;
+    int32_t acc = 1 << 21;
+    for (int t = 0; t < count; ++t) acc += (int32_t)s[t * stride] * kk[t];
+    acc >>= 22;
+    dst[idx] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+}
+
+}  // namespace mdx
+
+extern "C" int mdx_resample_u8(const uint8_t *src, int64_t B, int H, int W, int C, int axis, int out_len,
+                               const int32_t *bounds, const int32_t *k, int ksize, uint8_t *dst, void *stream)
+{
+    MDX_CHECK_ARG(src && dst && bounds && k, "mdx_resample_u8: NULL pointer");
+    MDX_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C <= 4, "mdx_resample_u8: bad shape [%lld,%d,%d,%d]", (long long)B, H, W, C);
+    MDX_CHECK_ARG((axis == 0 || axis == 1) && out_len > 0 && ksize > 0, "mdx_resample_u8: axis=%d out=%d ksize=%d", axis, out_len, ksize);
+    const int64_t total = axis == 1 ? B * H * (int64_t)out_len * C : B * (int64_t)out_len * W * C;
+    const dim3 grid((unsigned)ceil_div(total, (int64_t)256)), blk(256);
+    if (axis == 1)
+        hipLaunchKernelGGL((mdx::resample_u8_kernel<1>), grid, blk, 0, (hipStream_t)stream, src, dst, H, W, C, out_len, bounds, k, ksize, total);
+    else
+        hipLaunchKernelGGL((mdx::resample_u8_kernel<0>), grid, blk, 0, (hipStream_t)stream, src, dst, H, W, C, out_len, bounds, k, ksize, total);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}

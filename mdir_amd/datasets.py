@@ -52,13 +52,18 @@ def imresize(img, imsize):
 
 
 class ImagesFromList(data.Dataset):
+    """``resize_on_device=True`` (not in the reference): the down-scaling to ``imsize`` is left to the consumer
+    (``mdir_amd.resample.DeviceThumbnail``, same pixels) for the images the device path covers; the others are
+    shrunk here as always."""
+
     def __init__(self, root, images, imsize=None, bbxs=None, transform=None, loader=default_loader,
-                 ignore_errors=False):
+                 ignore_errors=False, resize_on_device=False):
         images_fn = [os.path.join(root, images[i]) for i in range(len(images))]
         if len(images_fn) == 0:
             raise RuntimeError("Dataset contains 0 images!")
         self.root, self.images, self.imsize, self.images_fn = root, images, imsize, images_fn
         self.bbxs, self.transform, self.loader, self.ignore_errors = bbxs, transform, loader, ignore_errors
+        self.resize_on_device = resize_on_device
 
     def __getitem__(self, index):
         path = self.images_fn[index]
@@ -71,7 +76,12 @@ class ImagesFromList(data.Dataset):
         if self.bbxs and self.bbxs[index]:
             img = img.crop(self.bbxs[index])
         if self.imsize is not None:
-            img = imresize(img, self.imsize)
+            deferred = False
+            if self.resize_on_device:
+                from .resample import on_device
+                deferred = on_device(img.size[0], img.size[1], self.imsize) is not None
+            if not deferred:
+                img = imresize(img, self.imsize)
         if self.transform is not None:
             img = self.transform(img)
         return img

@@ -26,6 +26,7 @@ from .backbones import OUTPUT_DIM, TrunkSequential, build_features
 from .datasets import ImagesFromList, ToUint8HWC, get_data_root
 from .graphs import ShapeGraphs, graphs_enabled, parallel_map
 from .layers import POOLING, L2N, pool_kind
+from .resample import DeviceThumbnail
 
 
 class ImageRetrievalNet(nn.Module):
@@ -313,17 +314,22 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     chain = getattr(net, "wrappers", {}).get(getattr(net, "stage", None)) if isinstance(getattr(net, "wrappers", None), dict) else None
     final_whitening = chain.defer_final_whitening() if hasattr(chain, "defer_final_whitening") else None
     tail = transform.device_tail() if hasattr(transform, "device_tail") and _gpu_preprocess(device) else None
+    resize_on_device = False
     if tail is not None:
         # workers ship uint8 pixels (a quarter of the bytes through shared memory, the pinned copy
-        # and PCIe, and no float arithmetic on the host); /255, -mean, /std happen on the GPU
+        # and PCIe, and no float arithmetic on the host); /255, -mean, /std happen on the GPU -- and so does the
+        # LANCZOS down-scale to image_size (Pillow's integer arithmetic, mdx_resample_u8): the workers only decode
         transform, from_tensor = ToUint8HWC(), describe
-        describe = lambda u8: from_tensor(ops.u8_to_chw(u8, tail[0], tail[1]))
+        resize_on_device = image_size is not None and os.environ.get("MDIR_AMD_GPU_RESIZE", "1") != "0"
+        shrink = DeviceThumbnail(image_size) if resize_on_device else (lambda u8: u8)
+        describe = lambda u8: from_tensor(ops.u8_to_chw(shrink(u8), tail[0], tail[1]))
     order = _Sequential(len(images))
     if graphs_enabled(device):
         describe = ShapeGraphs(describe)      # per input shape: eager once, then one hipGraph replay per call
         order = ShapeOrder(images, bbxs)
     loader = torch.utils.data.DataLoader(
-        ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform),
+        ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform,
+                       resize_on_device=resize_on_device),
         batch_size=1, shuffle=False, sampler=order, num_workers=num_workers, pin_memory=True)
     state = {"vecs": None}
 

@@ -194,6 +194,26 @@ def u8_to_chw(images, mean, std):
     return out
 
 
+def resample_u8(images, axis, bounds, taps):
+    """One pass of Pillow's 8-bit resampling on uint8 ``[B,H,W,C]`` device images: along the width (``axis=1``) or the
+    height (``axis=0``), with device taps ``bounds`` int32 ``[out,2]`` and ``taps`` int32 ``[out,ksize]``
+    (``mdx_resample_u8``; the taps come from ``mdir_amd.resample``)."""
+    if not (images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.is_contiguous()):
+        raise ValueError("resample_u8 expects a contiguous uint8 [B,H,W,C] CUDA/ROCm tensor (no CPU fallback)")
+    if axis not in (0, 1):
+        raise ValueError("axis must be 0 (height) or 1 (width)")
+    b, h, w, c = images.shape
+    out_len, ksize = taps.shape
+    if tuple(bounds.shape) != (out_len, 2) or bounds.dtype != torch.int32 or taps.dtype != torch.int32 \
+            or bounds.device != images.device or taps.device != images.device:
+        raise ValueError("bounds / taps must be int32 [out,2] / [out,ksize] on the images' device")
+    out = torch.empty((b, h, out_len, c) if axis == 1 else (b, out_len, w, c), dtype=torch.uint8, device=images.device)
+    with _on(images):
+        check(_lib.lib().mdx_resample_u8(images.data_ptr(), b, h, w, c, axis, out_len, _dev(bounds, torch.int32, "bounds"),
+                                         _dev(taps, torch.int32, "taps"), ksize, out.data_ptr(), _stream()), "mdx_resample_u8")
+    return out
+
+
 def bn_act_(x, running_mean, running_var, weight=None, bias=None, eps=1e-5, residual=None, relu=True):
     """In place on a convolution output ``x [N,C,H,W]``: inference batch-norm, ``+ residual``, ReLU
     in one pass (``mdx_bn_act``); returns ``x``.  Called ~100 times per image by a launch-bound trunk,

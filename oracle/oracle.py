@@ -414,6 +414,98 @@ def load_image(path, imsize=None, bbx=None):
     return np.asarray(img).copy()
 
 
+# ---- Pillow's thumbnail, restated (third-party arithmetic the reference calls: datahelpers.py:48-50 -> Image.thumbnail,
+# Pillow 12.2 here; src/PIL/Image.py thumbnail/resize, src/libImaging/Resample.c).  Pinned against Pillow itself and,
+# through load_image, against golden G15 in tests/test_oracle_golden.py. ----------------------------------------------
+
+def thumbnail_size(width, height, imsize):
+    """Size ``Image.thumbnail((imsize, imsize))`` gives a ``width x height`` image, or ``None`` when it leaves the
+    image alone (it never enlarges): Image.py ``thumbnail.preserve_aspect_ratio``."""
+    import math
+
+    def round_aspect(number, key):
+        return max(min(math.floor(number), math.ceil(number), key=key), 1)
+
+    x = y = int(math.floor(imsize))
+    if x >= width and y >= height:
+        return None
+    aspect = width / height
+    if x / y >= aspect:
+        x = round_aspect(y * aspect, key=lambda n: abs(aspect - n / y))
+    else:
+        y = round_aspect(x / aspect, key=lambda n: 0 if n == 0 else abs(aspect - x / n))
+    return x, y
+
+
+def lanczos_taps(in_size, out_size, in0=0.0, in1=None):
+    """Fixed-point taps of Pillow's LANCZOS (support 3) resampling of ``in_size`` samples to ``out_size``:
+    ``(bounds int32 [out,2] = (first source index, count), k int32 [out, ksize])``, k = round(w * 2^22).
+    Resample.c ``precompute_coeffs`` + ``normalize_coeffs_8bpc``."""
+    import math
+    in1 = float(in_size) if in1 is None else in1
+    scale = (np.float32(in1) - np.float32(in0)).astype(np.float64) / out_size
+    filterscale = max(float(scale), 1.0)
+    support = 3.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+
+    def sinc(x):
+        if x == 0.0:
+            return 1.0
+        x = x * math.pi
+        return math.sin(x) / x
+
+    def lanczos(x):
+        return sinc(x) * sinc(x / 3) if -3.0 <= x < 3.0 else 0.0
+
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = in0 + (xx + 0.5) * float(scale)
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [lanczos((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def resample_u8(img, out_w, out_h):
+    """Pillow's two-pass LANCZOS ``resize((out_w, out_h))`` of a uint8 ``[H,W,C]`` image (whole-image box): horizontal
+    pass first, uint8 in between, ``clip8((2^21 + sum pixel * k) >> 22)`` (Resample.c ``ImagingResampleHorizontal_8bpc``
+    / ``Vertical_8bpc``)."""
+    img = np.asarray(img, dtype=np.uint8)
+    H, W, _ = img.shape
+
+    def one_pass(src, axis_len, out_len):        # resamples axis 0 of src [axis_len, ...]
+        bounds, kk = lanczos_taps(axis_len, out_len)
+        out = np.empty((out_len,) + src.shape[1:], dtype=np.uint8)
+        s64 = src.astype(np.int64)
+        for xx in range(out_len):
+            lo, cnt = bounds[xx]
+            acc = np.tensordot(kk[xx, :cnt].astype(np.int64), s64[lo:lo + cnt], axes=(0, 0)) + (1 << 21)
+            out[xx] = np.clip(acc >> 22, 0, 255)
+        return out
+
+    if out_w != W:
+        img = one_pass(img.transpose(1, 0, 2), W, out_w).transpose(1, 0, 2)
+    if out_h != H:
+        img = one_pass(img, H, out_h)
+    return np.ascontiguousarray(img)
+
+
+def thumbnail_u8(img, imsize):
+    """``Image.thumbnail((imsize, imsize), LANCZOS)`` of a uint8 ``[H,W,3]`` array for the cases the GPU path takes
+    (no integer pre-reduction, i.e. less than 4x down; no 100:1 strips): :func:`thumbnail_size` + :func:`resample_u8`."""
+    size = thumbnail_size(img.shape[1], img.shape[0], imsize)
+    return np.asarray(img).copy() if size is None else resample_u8(img, size[0], size[1])
+
+
 def nanmean_metric(per_query):
     """The number eval.py prints: nan-filtered mean of the per-query rows
     (``mdir/tools/eventprocessor.py:101-115``)."""

@@ -47,6 +47,15 @@ def l2n_aggregate(pooled, l2n_eps=1e-6, msp=1.0):
     return torch.from_numpy(np.stack([O.ms_aggregate(st[:, b], msp) for b in range(st.shape[1])]))
 
 
+def resample_u8(images, axis, bounds, taps):
+    x, b, k = images.numpy().astype(np.int64), bounds.numpy(), taps.numpy().astype(np.int64)
+    x = np.moveaxis(x, 2 if axis == 1 else 1, 0)                 # resampled axis first
+    out = np.empty((len(b),) + x.shape[1:], dtype=np.uint8)
+    for o, (lo, cnt) in enumerate(b):
+        out[o] = np.clip((np.tensordot(k[o, :cnt], x[lo:lo + cnt], axes=(0, 0)) + (1 << 21)) >> 22, 0, 255)
+    return torch.from_numpy(np.ascontiguousarray(np.moveaxis(out, 0, 2 if axis == 1 else 1)))
+
+
 class DescriptorIndex:
     def __init__(self, vecs, layout="DN", row_offset=0):
         v = vecs.detach().numpy()
@@ -110,7 +119,7 @@ def rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, off_t):
     return cnt
 
 
-NAMES = ("pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "DescriptorIndex", "rank_full", "topk", "rank_of",
+NAMES = ("pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 

@@ -247,6 +247,46 @@ def test_full_size_shards_equal_whole(big):
     assert bool((ops.rank_full_segments(blocks) == rk[:9]).all())
 
 
+def test_extraction_with_device_thumbnail_equals_host_thumbnail(tmp_path, monkeypatch):
+    """The loader's LANCZOS down-scale on the device (default) against the same list shrunk by Pillow in the workers
+    (MDIR_AMD_GPU_RESIZE=0): same pixels, hence the same descriptors; JPEG files of two orientations with a crop box,
+    batches and single images, graphs and eager."""
+    from PIL import Image
+    from mdir_amd import ops
+    from mdir_amd.datasets import initialize_transforms
+    from mdir_amd.graphs import ShapeGraphs
+    from mdir_amd.networks import extract_vectors_device, init_network
+    rng = np.random.default_rng(12)
+    paths, bbxs = [], []
+    for i in range(11):
+        w, h = (400, 300) if i % 3 else (300, 400)
+        low = rng.integers(0, 255, (h // 20 + 1, w // 20 + 1, 3)).astype(np.float32)
+        img = np.clip(np.kron(low, np.ones((20, 20, 1), dtype=np.float32))[:h, :w] + rng.normal(0, 10, (h, w, 3)), 0, 255)
+        p = str(tmp_path / ("im%d.jpg" % i))
+        Image.fromarray(img.astype(np.uint8)).save(p, quality=90)
+        paths.append(p)
+        bbxs.append((10, 20, 390, 280) if i == 4 else None)
+    torch.manual_seed(2)
+    net = init_network({"architecture": "resnet18", "pooling": "gem", "whitening": False, "pretrained": False}).to(DEV).eval()
+    tr = initialize_transforms("pil2np | totensor | normalize", [net.meta["mean"], net.meta["std"]])
+    monkeypatch.setattr(ShapeGraphs, "PAYOFF_IMAGES", 0)
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "2")
+    calls = []
+    real = ops.resample_u8
+    monkeypatch.setattr(ops, "resample_u8", lambda *a: (calls.append(a[1]), real(*a))[1])
+    on_dev = extract_vectors_device(net, paths, 224, tr, bbxs=bbxs, ms=[1, 0.5], msp=1.0, device=DEV)
+    assert calls.count(0) >= 3 and calls.count(1) >= 3                   # width and height passes ran (eager + captured)
+    ncalls = len(calls)
+    monkeypatch.setenv("MDIR_AMD_GPU_RESIZE", "0")
+    on_host = extract_vectors_device(net, paths, 224, tr, bbxs=bbxs, ms=[1, 0.5], msp=1.0, device=DEV)
+    assert len(calls) == ncalls
+    np.testing.assert_allclose(on_dev.cpu().numpy(), on_host.cpu().numpy(), rtol=0, atol=2e-6)    # MIOpen is not run-to-run bit-stable
+    monkeypatch.setenv("MDIR_AMD_GPU_RESIZE", "1")
+    monkeypatch.setenv("MDIR_AMD_GRAPHS", "0")
+    eager = extract_vectors_device(net, paths, 224, tr, bbxs=bbxs, ms=[1, 0.5], msp=1.0, device=DEV)
+    np.testing.assert_allclose(eager.cpu().numpy(), on_host.cpu().numpy(), rtol=0, atol=2e-6)
+
+
 def test_hard_negative_mining_on_gpu(golden):
     """f1 on the device (mdx_scores + mdx_topk + the walk): golden G13 = the reference's create_epoch_tuples on a toy
     pool, then a mining-sized problem against the oracle restatement that G13 pins."""

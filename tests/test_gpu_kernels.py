@@ -233,6 +233,27 @@ def test_bn_act_vs_oracle_and_torch(ops, shape):
         ops.bn_act_(dev(x), dev(mean[:-1]) if c > 1 else dev(np.zeros(2, np.float32)), dev(var))
 
 
+@pytest.mark.parametrize("w,h,imsize,batch", [(1600, 1200, 1024, 1), (1200, 1600, 1024, 2), (221, 150, 64, 3), (97, 203, 64, 1),
+                                              (1025, 700, 1024, 1), (2047, 33, 1024, 1), (640, 480, 362, 4), (3000, 2000, 1024, 1)])
+def test_device_thumbnail_is_pillow(ops, w, h, imsize, batch):
+    """mdx_resample_u8 (width pass, height pass) with the host's fixed-point LANCZOS taps = Pillow's
+    ``Image.thumbnail((imsize, imsize), LANCZOS)`` -- what the reference's imresize calls (datahelpers.py:48-50) --
+    pixel for pixel; also against the oracle's restatement."""
+    from PIL import Image
+    from mdir_amd.resample import DeviceThumbnail, on_device
+    rng = np.random.default_rng(w + h)
+    arr = rng.integers(0, 256, (batch, h, w, 3), dtype=np.uint8)
+    arr[0, : h // 2] = (arr[0, : h // 2] // 64) * 85                 # flat areas and hard edges (ringing is clipped at 0 / 255)
+    assert on_device(w, h, imsize) is not None
+    got = DeviceThumbnail(imsize)(torch.from_numpy(arr).to(DEV)).cpu().numpy()
+    for b in range(batch):
+        im = Image.fromarray(arr[b])
+        im.thumbnail((imsize, imsize), Image.LANCZOS)
+        np.testing.assert_array_equal(got[b], np.asarray(im))
+    if w * h < 10 ** 6:
+        np.testing.assert_array_equal(got[0], O.thumbnail_u8(arr[0], imsize))
+
+
 def test_u8_to_chw_matches_host_chain(ops):
     """mdx_u8_to_chw == `pil2np | totensor | normalize` bit for bit (RGB and single channel, odd sizes, batch)."""
     rng = np.random.default_rng(2)

@@ -645,6 +645,41 @@ def test_image_loader_golden(golden, tmp_path):
         np.testing.assert_array_equal(ds[0], g["case%d_out" % ci])
 
 
+def test_device_thumbnail_host_logic(fops, golden, tmp_path):
+    """The loader with ``resize_on_device`` + ``DeviceThumbnail`` (kernels replaced by the oracle): which images go to
+    the device, the size rule and the taps -- together they must give Pillow's thumbnail, and golden G15."""
+    from mdir_amd import resample as R
+    from mdir_amd.datasets import ImagesFromList, ToUint8HWC
+    rng = np.random.default_rng(8)
+    for _ in range(400):
+        w, h, imsize = int(rng.integers(1, 6000)), int(rng.integers(1, 6000)), int(rng.choice([64, 362, 1024]))
+        im = Image.new("L", (w, h))
+        im.thumbnail((imsize, imsize), Image.LANCZOS)
+        assert (R.thumbnail_size(w, h, imsize) or (w, h)) == im.size
+    assert R.on_device(1600, 1200, 1024) == (1024, 768) and R.on_device(1024, 768, 1024) is None
+    assert R.on_device(4096, 3072, 1024) is None                                                     # 4x: Pillow reduces first
+    assert R.on_device(4095, 3071, 1024) == R.thumbnail_size(4095, 3071, 1024) == (1024, 768)
+    assert R.on_device(5, 900, 300) is None                                                          # 100:1 strip
+    for w, h, imsize in [(221, 150, 64), (97, 203, 64), (640, 480, 362), (333, 1000, 500), (300, 200, 1024)]:
+        arr = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        got = R.DeviceThumbnail(imsize)(torch.from_numpy(arr)).numpy()
+        for b in range(2):
+            im = Image.fromarray(arr[b])
+            im.thumbnail((imsize, imsize), Image.LANCZOS)
+            np.testing.assert_array_equal(got[b], np.asarray(im))
+    g = golden("g15_loader.npz")
+    for name in ("landscape", "portrait", "small"):
+        (tmp_path / (name + ".png")).write_bytes(g["file_" + name].tobytes())
+    for ci in range(6):
+        name, imsize, bbx = eval(str(g["case%d_spec" % ci][0]))
+        ds = ImagesFromList(root=str(tmp_path), images=[name + ".png"], imsize=imsize, bbxs=[bbx], transform=ToUint8HWC(),
+                            resize_on_device=True)
+        u8 = ds[0]
+        deferred = imsize is not None and R.on_device(u8.shape[1], u8.shape[0], imsize) is not None
+        assert deferred == (ci in (0, 1, 2))                           # the three that really shrink (less than 4x)
+        np.testing.assert_array_equal(R.DeviceThumbnail(imsize)(u8[None])[0].numpy(), g["case%d_out" % ci])
+
+
 def test_embedding_output_golden(golden):
     """Golden G14: the reference's EmbeddingOutput (output.py:117-139): float64 [N,D], NaN row for an unreadable image."""
     from mdir_amd.stages import EmbeddingOutput

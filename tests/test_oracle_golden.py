@@ -254,3 +254,31 @@ def test_g15_image_loader(golden, tmp_path):
     for ci in range(ncases):
         name, imsize, bbx = eval(str(g["case%d_spec" % ci][0]))
         np.testing.assert_array_equal(O.load_image(str(tmp_path / (name + ".png")), imsize, bbx), g["case%d_out" % ci])
+
+
+def test_thumbnail_restatement_is_pillow_and_g15(golden, tmp_path):
+    """The restated thumbnail (size rule, LANCZOS taps in Pillow's fixed point, two uint8 passes) equals Pillow's
+    ``Image.thumbnail`` pixel for pixel -- Pillow is what the reference calls (datahelpers.py:48-50) -- on random
+    images, and reproduces golden G15 (outputs of the reference's loader) when it replaces Pillow's resize there."""
+    from PIL import Image
+    rng = np.random.default_rng(4)
+    for w, h, imsize in [(221, 150, 64), (97, 203, 64), (640, 480, 362), (1025, 700, 1024), (333, 1000, 500), (800, 600, 1024),
+                         (1023, 4, 512), (9, 890, 300)]:
+        arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        im = Image.fromarray(arr)
+        im.thumbnail((imsize, imsize), Image.LANCZOS)
+        np.testing.assert_array_equal(O.thumbnail_u8(arr, imsize), np.asarray(im))
+        assert O.thumbnail_size(w, h, imsize) in (None, im.size)
+    for _ in range(300):
+        w, h, imsize = int(rng.integers(1, 3000)), int(rng.integers(1, 3000)), int(rng.choice([64, 362, 1024]))
+        im = Image.new("L", (w, h))
+        im.thumbnail((imsize, imsize), Image.LANCZOS)
+        assert (O.thumbnail_size(w, h, imsize) or (w, h)) == im.size
+    g = golden("g15_loader.npz")
+    for name in ("landscape", "portrait", "small"):
+        (tmp_path / (name + ".png")).write_bytes(g["file_" + name].tobytes())
+    for ci in range(6):
+        name, imsize, bbx = eval(str(g["case%d_spec" % ci][0]))
+        raw = O.load_image(str(tmp_path / (name + ".png")), None, bbx)
+        got = raw if imsize is None else O.thumbnail_u8(raw, imsize)
+        np.testing.assert_array_equal(got, g["case%d_out" % ci])
