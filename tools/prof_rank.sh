@@ -6,6 +6,6 @@ python3 - "$W" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
-    if "mdx::" in r["Name"] and ("sort" in r["Name"] or "os_" in r["Name"] or "scores" in r["Name"]):
+    if "mdx::" in r["Name"] and ("sort" in r["Name"] or "msd" in r["Name"] or "os_" in r["Name"] or "scores" in r["Name"]):
         print("%-70s calls %4s avg %9.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
