@@ -69,6 +69,31 @@ int main(int argc, char **argv)
             if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
             return ms / 10;
         };
+        if (getenv("STAMPS")) {     // in-kernel stamps of the consumer waves: barrier-wait share, loop cycles, clock
+            auto kern = scores_lc_kernel<4, 2, 2, 3, 2, true, MmaF32, 1>;
+            const size_t lds = (size_t)3 * (5 + 8) * 2 * 1024;
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const int64_t blocks = (RT + 7) / 8;
+            unsigned long long *dbg; hipMalloc(&dbg, blocks * 4 * 8 * 8);
+            std::vector<unsigned long long> hd(blocks * 4 * 8);
+            for (int rep = 0; rep < 3; ++rep) {
+                hipMemset(dbg, 0, blocks * 4 * 8 * 8);
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70, dbg);
+                hipDeviceSynchronize();
+                hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
+                double wait = 0, work = 0, cyc = 0, ticks = 0, life = 0, epi = 0; unsigned long long t0 = ~0ull, t1 = 0;
+                for (int64_t i = 0; i < blocks * 4; ++i) {
+                    const unsigned long long *d = &hd[i * 8];
+                    wait += d[0]; work += d[1]; cyc += d[2]; ticks += d[3]; life += d[6] - d[4]; epi += d[6] - (d[5] + d[3]);
+                    t0 = d[4] < t0 ? d[4] : t0; t1 = d[6] > t1 ? d[6] : t1;
+                }
+                const double nw = blocks * 4;
+                printf("stamps: barrier-wait share %.3f of the loop, loop %.1f us at %.3f GHz, workgroup life %.1f us (prologue %.1f, epilogue %.1f), launch %.3f ms\n",
+                       wait / (wait + work), ticks / nw / 100.0, cyc / ticks / 10.0, life / nw / 100.0, (life - epi) / nw / 100.0 - ticks / nw / 100.0,
+                       epi / nw / 100.0, (t1 - t0) / 1e5);
+            }
+            return 0;
+        }
         // interleaved rounds in one process
         for (int rep = 0; rep < 3; ++rep)
             printf("n=%lld: QT5 KC2 NST3 %.4f | QT5 KC1 NST4 (3 WG/CU) %.4f | QT5 KC1 NST6 %.4f | QT4+leftover KC2 NST3 %.4f | QT4+leftover KC1 NST6 %.4f | persistent QT5 %.4f ms\n", (long long)n,
