@@ -90,6 +90,55 @@ class ImagesFromList(data.Dataset):
         return len(self.images_fn)
 
 
+class ThreadedLoader:
+    """``DataLoader(dataset, batch_size=1, sampler=order, num_workers=n, pin_memory=True)`` with THREADS instead of worker
+    processes, for datasets whose items are made in C with the GIL released (Pillow's JPEG decode and resize, numpy
+    copies): no fork, no pickling, no shared-memory files -- a decoded image goes from the decoding thread straight into
+    pinned memory.  Yields items in the sampler's order (a batch dimension of 1 in front, like the DataLoader); at most
+    ``2 * workers`` items are in flight.  An item that raises is re-raised at its turn."""
+
+    def __init__(self, dataset, sampler, workers, pin_memory=True):
+        self.dataset, self.sampler, self.workers, self.pin = dataset, sampler, max(1, int(workers)), pin_memory
+
+    def __len__(self):
+        return len(self.sampler)
+
+    def _load(self, index):
+        item = self.dataset[index]
+        if isinstance(item, torch.Tensor):
+            item = item.unsqueeze(0)
+            if self.pin and torch.cuda.is_available():
+                item = item.pin_memory()
+        return item
+
+    def __iter__(self):
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+        pending = collections.deque()
+        with ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="mdir-loader") as pool:
+            try:
+                for index in self.sampler:
+                    pending.append(pool.submit(self._load, index))
+                    if len(pending) >= 2 * self.workers:
+                        yield pending.popleft().result()
+                while pending:
+                    yield pending.popleft().result()
+            finally:
+                for f in pending:
+                    f.cancel()
+
+
+def make_loader(dataset, sampler, workers, device, collate_fn=None):
+    """The batch-size-1 loader of the extraction loops.  Threads by default: with the images decoded in worker PROCESSES
+    (``MDIR_AMD_LOADER=processes``: torch's DataLoader, the reference's choice, imageretrievalnet.py:284-287) the main
+    process's launches slow down threefold as soon as three workers are busy -- 95 descriptors/s instead of 203 on a
+    16-size JPEG list with ResNet101 (tools/list_workers_probe.py) -- while Pillow's decoder releases the GIL."""
+    if workers > 0 and os.environ.get("MDIR_AMD_LOADER", "threads") != "processes":
+        return ThreadedLoader(dataset, sampler, workers, pin_memory=torch.device(device).type == "cuda")
+    kw = {"collate_fn": collate_fn} if collate_fn is not None else {}
+    return data.DataLoader(dataset, batch_size=1, shuffle=False, sampler=sampler, num_workers=workers, pin_memory=True, **kw)
+
+
 def config_imname(cfg, i):
     return os.path.join(cfg["dir_images"], cfg["imlist"][i] + cfg["ext"])
 

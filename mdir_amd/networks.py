@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .backbones import OUTPUT_DIM, TrunkSequential, build_features
-from .datasets import ImagesFromList, ToUint8HWC, get_data_root
+from .datasets import ImagesFromList, ToUint8HWC, get_data_root, make_loader
 from .graphs import ShapeGraphs, graphs_enabled, parallel_map
 from .layers import POOLING, L2N, pool_kind
 from .resample import DeviceThumbnail
@@ -327,10 +327,9 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     if graphs_enabled(device):
         describe = ShapeGraphs(describe)      # per input shape: eager once, then one hipGraph replay per call
         order = ShapeOrder(images, bbxs)
-    loader = torch.utils.data.DataLoader(
-        ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform,
-                       resize_on_device=resize_on_device),
-        batch_size=1, shuffle=False, sampler=order, num_workers=num_workers, pin_memory=True)
+    dataset = ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform,
+                             resize_on_device=resize_on_device)
+    loader = make_loader(dataset, order, num_workers, device)
     state = {"vecs": None}
 
     def store(i, v):

@@ -117,16 +117,20 @@ def infer(params, data, device=None):
     paths = [path_join(image_dir, x) for x in images]
     describe = network
     tail = transform.device_tail() if _gpu_preprocess(device) else None
+    import os
+    image_size, resize_on_device = ds.pop("image_size"), False
     if tail is not None:
-        transform, describe = ToUint8HWC(), (lambda u8: network(ops.u8_to_chw(u8, tail[0], tail[1])))
+        from .resample import DeviceThumbnail
+        resize_on_device = image_size is not None and os.environ.get("MDIR_AMD_GPU_RESIZE", "1") != "0"
+        shrink = DeviceThumbnail(image_size) if resize_on_device else (lambda u8: u8)       # the LANCZOS thumbnail on the device
+        transform, describe = ToUint8HWC(), (lambda u8: network(ops.u8_to_chw(shrink(u8), tail[0], tail[1])))
     order = _Sequential(len(paths))
     if graphs_enabled(device):
         describe, order = ShapeGraphs(describe), ShapeOrder(paths, bbxs)
-    dataset = ImagesFromList(root="", images=paths, imsize=ds.pop("image_size"), bbxs=bbxs, transform=transform, **ds)
-    import os
-    loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, sampler=order, pin_memory=True,
-                                         num_workers=int(os.environ.get("MDIR_AMD_WORKERS", "8")),
-                                         collate_fn=_collate_one)
+    dataset = ImagesFromList(root="", images=paths, imsize=image_size, bbxs=bbxs, transform=transform,
+                             resize_on_device=resize_on_device, **ds)
+    from .datasets import make_loader
+    loader = make_loader(dataset, order, int(os.environ.get("MDIR_AMD_WORKERS", "8")), device, collate_fn=_collate_one)
     t0 = time.time()
     with torch.no_grad():
         batched_loop(loader, order, device, describe, store=lambda i, v: output.add(i, True, v),

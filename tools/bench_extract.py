@@ -251,8 +251,8 @@ def measure_list(arch="resnet101", workers=8, short=4, mid=40, long=64):
             assert vecs.shape == (len(paths), D) and bool(torch.isfinite(vecs).all())
         # loader alone (decode + thumbnail + uint8 tensor, no GPU work) on the long list
         from mdir_amd.datasets import ToUint8HWC
-        loader = torch.utils.data.DataLoader(ImagesFromList("", lists[long], imsize=1024, transform=ToUint8HWC()), batch_size=1,
-                                             num_workers=workers)
+        from mdir_amd.datasets import make_loader
+        loader = make_loader(ImagesFromList("", lists[long], imsize=1024, transform=ToUint8HWC()), range(len(lists[long])), workers, dev)
         t0 = time.perf_counter()
         for _ in loader:
             pass
