@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", dest="n", type=int, default=N_ROXFORD + N_DISTRACTORS, help="database rows (default 1 004 993)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] side legs")
     ap.add_argument("--extract-images", type=int, default=40,
                     help="images PER SIZE (16 sizes) of the (untimed) descriptors/sec leg: ResNet101-GeM, 3 scales + whitening; 0 = skip")
     args = ap.parse_args()
@@ -358,6 +359,45 @@ def main():
             del vecs_host, rk_cpu
         except Exception as exc:          # the reported baseline must not cost the measured line
             extra["cpu_baseline"] = {"value": None, "unit": "queries/s", "error": "%s: %s" % (type(exc).__name__, exc)}
+
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # BASELINE.json's other single-GPU configurations, timed beside the headline (side legs: they cannot cost the
+        # measured line): configs[1] rOxford5k alone (70 x 4 993, latency-bound) and configs[4]'s fp16 descriptors on the
+        # fp16 MFMA (same 1 M x 2048 problem, shard stored as fp16: HBM-bound)
+        try:
+            def timed(fn, reps=20):
+                for _ in range(3):
+                    fn()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps
+            sec = {}
+            small = ops.DescriptorIndex(rows[:N_ROXFORD].contiguous(), "ND")
+            sc5 = torch.empty((NQ, N_ROXFORD), dtype=torch.float32, device=device)
+            rk5 = torch.empty((NQ, N_ROXFORD), dtype=torch.int64, device=device)
+            ws5 = torch.empty(ops.rank_workspace_bytes(N_ROXFORD, NQ), dtype=torch.uint8, device=device)
+            t_s, t_r = timed(lambda: small.scores(qvecs, "DN", out=sc5)), timed(lambda: ops.rank_full(sc5, out=rk5, workspace=ws5))
+            sec["configs1_roxford5k"] = {"workload": "N=%d Q=%d D=%d fp32, similarity + exact full ranking" % (N_ROXFORD, NQ, DIM),
+                                         "scores_us": round(1e3 * t_s, 1), "rank_us": round(1e3 * t_r, 1),
+                                         "queries_per_s": round(NQ / ((t_s + t_r) * 1e-3), 1), "bound": "launch latency"}
+            small.close()
+            half = ops.DescriptorIndex(rows, "ND", storage="f16")
+            t_h = timed(lambda: half.scores(qvecs, "DN", out=sc), reps=10)
+            hb = half.device_bytes + 4 * NQ * n_total
+            sec["configs4_fp16_shard"] = {"workload": "N=%d Q=%d D=%d, shard and queries stored as fp16, v_mfma_f32_16x16x32_f16, fp32 accumulation"
+                                                      % (n_total, NQ, DIM), "scores_ms": round(t_h, 4),
+                                          "roofline": {"bound": "hbm", "achieved": round(hb / (t_h * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                                       "frac": round(hb / (t_h * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes": float(hb)},
+                                          "queries_per_s_with_the_fp32_ranking": round(NQ / ((t_h + extra.get("rank_ms_per_step", 0.0)) * 1e-3), 1),
+                                          "contract": "scores within ~1e-3 of fp32 (input rounding), tests/test_gpu_f16.py"}
+            half.close()
+            extra["secondary_configs"] = sec
+        except Exception as exc:
+            extra["secondary_configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     if args.extract_images > 0:
         # second half of BASELINE.json's metric: descriptors/sec (every rank extracts its own images).  The number is
