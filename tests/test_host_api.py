@@ -680,6 +680,36 @@ def test_device_thumbnail_host_logic(fops, golden, tmp_path):
         np.testing.assert_array_equal(R.DeviceThumbnail(imsize)(u8[None])[0].numpy(), g["case%d_out" % ci])
 
 
+def test_threaded_loader_order_errors_and_missing_images(tmp_path):
+    """The thread-pool loader hands out what DataLoader(batch_size=1, sampler=...) would: items in the sampler's order with
+    a leading batch axis, ``{}`` for an unreadable image under ignore_errors, the loader's exception at the item's turn
+    otherwise; the extraction loop gives the same descriptors through either loader."""
+    from mdir_amd.datasets import ImagesFromList, ThreadedLoader, ToUint8HWC, make_loader
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(13):
+        p = str(tmp_path / ("im%02d.png" % i))
+        Image.fromarray(rng.integers(0, 255, (20 + i, 30, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    order = [5, 0, 12, 3, 3, 7, 1, 11, 2]
+    ds = ImagesFromList("", paths, imsize=None, transform=ToUint8HWC())
+    got = list(ThreadedLoader(ds, order, workers=4, pin_memory=False))
+    assert [tuple(t.shape) for t in got] == [(1, 20 + i, 30, 3) for i in order]
+    for t, i in zip(got, order):
+        np.testing.assert_array_equal(t[0].numpy(), np.asarray(Image.open(paths[i]).convert("RGB")))
+    ref = list(torch.utils.data.DataLoader(ds, batch_size=1, sampler=order, num_workers=0))
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    assert isinstance(make_loader(ds, order, 3, "cpu"), ThreadedLoader)
+    broken = paths[:3] + [str(tmp_path / "missing.png")] + paths[3:5]
+    items = list(ThreadedLoader(ImagesFromList("", broken, transform=ToUint8HWC(), ignore_errors=True), range(6), workers=3, pin_memory=False))
+    assert items[3] == {} and [isinstance(x, torch.Tensor) for x in items] == [True, True, True, False, True, True]
+    seen = []
+    with pytest.raises(OSError):
+        for x in ThreadedLoader(ImagesFromList("", broken, transform=ToUint8HWC()), range(6), workers=2, pin_memory=False):
+            seen.append(x)
+    assert len(seen) == 3                                     # the three readable images before it were delivered
+
+
 def test_embedding_output_golden(golden):
     """Golden G14: the reference's EmbeddingOutput (output.py:117-139): float64 [N,D], NaN row for an unreadable image."""
     from mdir_amd.stages import EmbeddingOutput
