@@ -55,6 +55,19 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes with DPP moves (row shifts inside the rows of 16, then row broadcasts): a dozen
+// vector instructions, where __shfl_up is an LDS round trip per step
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v)
 {
 #pragma unroll

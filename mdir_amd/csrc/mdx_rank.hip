@@ -396,12 +396,7 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         const uint32_t g0 = dtot[4 * lane], g1 = dtot[4 * lane + 1], g2 = dtot[4 * lane + 2],
                        g3 = dtot[4 * lane + 3];
         const uint32_t mine = t0 + t1 + t2 + t3, gmine = g0 + g1 + g2 + g3;
-        uint32_t inc = mine, ginc = gmine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(inc, o, 64), gv = __shfl_up(ginc, o, 64);
-            if (lane >= o) { inc += v; ginc += gv; }
-        }
+        const uint32_t inc = wave_inclusive_sum(mine), ginc = wave_inclusive_sum(gmine);
         const uint32_t ex = inc - mine, gex = ginc - gmine;
         const uint32_t toff[4] = {ex, ex + t0, ex + t0 + t1, ex + t0 + t1 + t2};
         const uint32_t goff[4] = {gex, gex + g0, gex + g0 + g1, gex + g0 + g1 + g2};   // digit bases of the query

@@ -74,13 +74,13 @@ struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e
 // the 2 x 32 of the padded tile's two 16x16x4 MFMAs per 4 k).  A lane reads the 16 k of "its" query row
 // and of "its" database row with four ds_read_b128 each (the four lane groups g of the tile format hold
 // k = 4t+g) and issues the products in k order, so every output is still the k = 0..D-1 fma chain.
-template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0>
-__global__ __launch_bounds__(512, (R >= 4 ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
+template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0, int CWAVES = 4>
+__global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
                                                            float *__restrict__ out, int64_t n, int KB,
                                                            int nq_valid, unsigned long long *dbg = nullptr)
 {
-    constexpr int CW = 4;                           // consumer waves
+    constexpr int CW = CWAVES;                      // consumer waves (8: two per SIMD in ONE workgroup per CU, sharing the query stage)
     constexpr int LW = 4;                           // loader waves
     static_assert(QR == 0 || (R == 2 && MM::STEPS == 4), "the 4x4x1 leftover path covers 32 fp32 rows per wave");
     constexpr int QTL = QT + QR;                    // query tiles in LDS: QT full ones + the leftover tile

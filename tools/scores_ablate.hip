@@ -42,14 +42,14 @@ int main(int argc, char **argv)
     hipMemcpy(db, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(q, h.data(), 5 * KB * 1024, hipMemcpyHostToDevice);
     {
-        auto lc = [&](auto kern, int R_, int KC_, int NST, int QT_) {
-            const size_t lds = (size_t)NST * (QT_ + 4 * R_) * KC_ * 1024;
+        auto lc = [&](auto kern, int R_, int KC_, int NST, int QT_, int CW_ = 4) {
+            const size_t lds = (size_t)NST * (QT_ + CW_ * R_) * KC_ * 1024;
             hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            const int64_t blocks = (RT + 4 * R_ - 1) / (4 * R_);
+            const int64_t blocks = (RT + CW_ * R_ - 1) / (CW_ * R_);
             hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70, (unsigned long long *)nullptr);
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64 + 256), lds, 0, db, q, out, n, KB, 70, (unsigned long long *)nullptr);
             hipEventRecord(a);
-            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, q, out, n, KB, 70, (unsigned long long *)nullptr);
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64 + 256), lds, 0, db, q, out, n, KB, 70, (unsigned long long *)nullptr);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             hipError_t e = hipGetLastError();
@@ -91,6 +91,27 @@ int main(int argc, char **argv)
                 printf("stamps: barrier-wait share %.3f of the loop, loop %.1f us at %.3f GHz, workgroup life %.1f us (prologue %.1f, epilogue %.1f), launch %.3f ms\n",
                        wait / (wait + work), ticks / nw / 100.0, cyc / ticks / 10.0, life / nw / 100.0, (life - epi) / nw / 100.0 - ticks / nw / 100.0,
                        epi / nw / 100.0, (t1 - t0) / 1e5);
+            }
+            return 0;
+        }
+        if (getenv("CW8")) {        // one workgroup per CU with 8 consumer waves sharing the query stage
+            for (int rep = 0; rep < 3; ++rep)
+                printf("2 WG/CU x 4 consumers %.4f | 1 WG/CU x 8 consumers KC2 NST3 %.4f | KC1 NST6 %.4f | KC2 NST2 %.4f ms\n",
+                       lc(scores_lc_kernel<4, 2, 2, 3, 2, false, MmaF32, 1>, 2, 2, 3, 5),
+                       lc(scores_lc_kernel<4, 2, 2, 3, 2, false, MmaF32, 1, 8>, 2, 2, 3, 5, 8),
+                       lc(scores_lc_kernel<4, 2, 1, 6, 2, false, MmaF32, 1, 8>, 2, 1, 6, 5, 8),
+                       lc(scores_lc_kernel<4, 2, 2, 2, 2, false, MmaF32, 1, 8>, 2, 2, 2, 5, 8));
+            {   // bitwise: 8 consumers against 4
+                std::vector<float> ha((size_t)70 * n), hb((size_t)70 * n);
+                hipMemset(out, 0xFF, (size_t)70 * n * 4);
+                lc(scores_lc_kernel<4, 2, 2, 3, 2, false, MmaF32, 1>, 2, 2, 3, 5);
+                hipMemcpy(ha.data(), out, ha.size() * 4, hipMemcpyDeviceToHost);
+                hipMemset(out, 0xFF, (size_t)70 * n * 4);
+                lc(scores_lc_kernel<4, 2, 2, 3, 2, false, MmaF32, 1, 8>, 2, 2, 3, 5, 8);
+                hipMemcpy(hb.data(), out, hb.size() * 4, hipMemcpyDeviceToHost);
+                size_t bad = 0;
+                for (size_t i = 0; i < ha.size(); ++i) bad += memcmp(&ha[i], &hb[i], 4) != 0;
+                printf("8 consumers vs 4 consumers: %zu of %zu scores differ\n", bad, ha.size());
             }
             return 0;
         }
