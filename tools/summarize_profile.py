@@ -61,7 +61,7 @@ for line in open(os.path.join(src, "stats_bench.log")):
         bench = json.loads(line)
 with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
     f.write("# rocprofv3 summary, round %s\n\n" % tag)
-    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline` "
+    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --extract-images 16` "
             "(N=1 004 993, Q=70, D=2048 fp32, 20 timed + 3 warm-up steps); PMC passes in separate runs "
             "(`tools/profile_round.sh`).\n\n")
     if bench:
