@@ -119,6 +119,30 @@ int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W, int C, co
 int mdx_resample_u8(const uint8_t *src, int64_t B, int H, int W, int C, int axis, int out_len,
                     const int32_t *bounds, const int32_t *k, int ksize, uint8_t *dst, void *stream);
 
+/* JPEG decoding, host half + device half.  Together they replace `Image.open(f).convert('RGB')` of pil_loader
+ * (cirtorch/datasets/datahelpers.py:24-31) for baseline JPEG files, with the arithmetic of libjpeg(-turbo) as Pillow
+ * configures it (Huffman decoding; jidctint.c islow IDCT; jdsample.c fancy upsampling; jdcolor.c YCbCr -> RGB), bit for bit.
+ *   mdx_jpeg_probe          HOST.  Geometry of the file; info->supported = 0 for what stays with the host decoder
+ *                           (progressive, arithmetic, 12-bit, CMYK / RGB-coded, several scans, other sampling factors).
+ *   mdx_jpeg_coefficients   HOST (no device call; thread-safe, so loader threads run it in parallel).  Entropy decoding:
+ *                           coef [nblocks][64] int16, quantised, natural order, component after component, every
+ *                           component's blocks row by row over whole MCUs; quant [3][64] uint16, natural order.
+ *   mdx_jpeg_pixels         DEVICE.  coef / quant as above (device copies) -> rgb uint8 [height, width, 3].
+ *                           planes: device scratch of nblocks * 64 bytes. */
+typedef struct {
+    int32_t width, height;          /* image size */
+    int32_t ncomp;                  /* 1 (grey) or 3 (YCbCr) */
+    int32_t hsamp[3], vsamp[3];     /* sampling factors */
+    int32_t blocks_w[3], blocks_h[3];   /* 8x8 blocks per row / column of every component (whole MCUs) */
+    int32_t supported;
+    int64_t block_offset[3];        /* first block of the component in coef */
+    int64_t nblocks;                /* blocks of all components */
+} mdx_jpeg_info;
+int mdx_jpeg_probe(const uint8_t *file, int64_t size, mdx_jpeg_info *info);
+int mdx_jpeg_coefficients(const uint8_t *file, int64_t size, int16_t *coef, int64_t coef_blocks, uint16_t *quant);
+int mdx_jpeg_pixels(const int16_t *coef, const uint16_t *quant, const mdx_jpeg_info *info, uint8_t *planes,
+                    uint8_t *rgb, void *stream);
+
 /* Multi-scale aggregation of S per-scale descriptors of one image:
  *   out[k] = v[k] / ||v||,  v[k] = (sum_s vecs[s][k]^msp / S)^(1/msp)     (no eps)
  * Replaces CirMultiscaleAggregation.aggregate_tensor

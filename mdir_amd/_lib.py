@@ -39,6 +39,14 @@ def build(force=False):
     return LIB_PATH
 
 
+class JpegInfo(ctypes.Structure):
+    """``mdx_jpeg_info`` of include/mdx.h."""
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ncomp", ctypes.c_int32),
+                ("hsamp", ctypes.c_int32 * 3), ("vsamp", ctypes.c_int32 * 3),
+                ("blocks_w", ctypes.c_int32 * 3), ("blocks_h", ctypes.c_int32 * 3), ("supported", ctypes.c_int32),
+                ("block_offset", ctypes.c_int64 * 3), ("nblocks", ctypes.c_int64)]
+
+
 def _declare(lib):
     i32, i64, f32, p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
     pp = ctypes.POINTER(ctypes.c_void_p)
@@ -55,6 +63,9 @@ def _declare(lib):
         "mdx_bn_act": (i32, [p, p, i64, i64, i64, p, p, p, p, f32, i32, p]),
         "mdx_u8_to_chw": (i32, [p, i64, i64, i64, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), p, p]),
         "mdx_resample_u8": (i32, [p, i64, i32, i32, i32, i32, i32, p, p, i32, p, p]),
+        "mdx_jpeg_probe": (i32, [p, i64, p]),
+        "mdx_jpeg_coefficients": (i32, [p, i64, p, i64, p]),
+        "mdx_jpeg_pixels": (i32, [p, p, p, p, p, p]),
         "mdx_index_create": (i32, [pp, p, i64, i64, i32, i64, p]),
         "mdx_index_create_ex": (i32, [pp, p, i64, i64, i32, i64, i32, p]),
         "mdx_index_destroy": (i32, [p]),
@@ -76,7 +87,7 @@ def _declare(lib):
 
 
 EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
-           "mdx_ms_aggregate_batch", "mdx_pool_multi", "mdx_l2n_aggregate", "mdx_bn_act", "mdx_u8_to_chw", "mdx_resample_u8",
+           "mdx_ms_aggregate_batch", "mdx_pool_multi", "mdx_l2n_aggregate", "mdx_bn_act", "mdx_u8_to_chw", "mdx_resample_u8", "mdx_jpeg_probe", "mdx_jpeg_coefficients", "mdx_jpeg_pixels",
            "mdx_index_create", "mdx_index_create_ex", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
            "mdx_scores", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of",
            "mdx_gather_scores", "mdx_rank_count")

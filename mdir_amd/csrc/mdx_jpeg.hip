@@ -1,0 +1,550 @@
+// JPEG decoding split between host and device.
+//
+// Replaces `Image.open(f).convert('RGB')` of pil_loader (mdir/external/cirtorch/datasets/datahelpers.py:24-31) for
+// baseline JPEG files: Pillow hands the file to libjpeg(-turbo) with its defaults -- Huffman entropy decoding, the
+// accurate integer inverse DCT (jidctint.c "islow"), "fancy" (triangle) chroma upsampling (jdsample.c) and the
+// fixed-point YCbCr -> RGB conversion (jdcolor.c).  Entropy decoding is a serial walk over a bit stream and stays on
+// the host (a loader thread calls mdx_jpeg_coefficients; what crosses PCIe is the quantised coefficients, 2 bytes each,
+// no more than the decoded pixels); everything after it is per-block / per-pixel integer arithmetic and runs here,
+// bit for bit as libjpeg does it: mdx_jpeg_pixels = dequantisation + IDCT (one thread per 8x8 block), then upsampling +
+// colour conversion (one thread per output pixel).
+//
+// Covered: 8-bit baseline / extended-sequential Huffman files with one interleaved scan, grey or YCbCr, luma at full
+// resolution and chroma at 1x1, 2x1 or 2x2 (4:4:4, 4:2:2, 4:2:0).  Everything else (progressive, arithmetic coding,
+// 12-bit, CMYK / YCCK, RGB-coded, several scans, other sampling factors, images narrower than 16 pixels) is reported as
+// unsupported by mdx_jpeg_probe and stays with the host decoder.
+#include <stdlib.h>
+
+#include "mdx_common.h"
+
+namespace mdx {
+
+static const uint8_t ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                   41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                   30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct HuffTable {
+    bool defined = false;
+    uint8_t bits[17];
+    uint8_t vals[256];
+    // canonical decoding: codes of length l are mincode[l] .. maxcode[l]; valptr[l] = index of the first of them
+    int32_t mincode[18], maxcode[18], valptr[18];
+    // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
+    uint16_t fast[512];
+};
+
+static bool build_table(HuffTable &t)
+{
+    int code = 0, k = 0;
+    for (int i = 0; i < 512; ++i) t.fast[i] = 0;
+    for (int l = 1; l <= 16; ++l) {
+        t.valptr[l] = k;
+        t.mincode[l] = code;
+        for (int i = 0; i < t.bits[l]; ++i, ++k, ++code) {
+            if (k >= 256) return false;
+            if (l <= 9) {
+                const int first = code << (9 - l), n = 1 << (9 - l);
+                for (int j = 0; j < n; ++j) t.fast[first + j] = (uint16_t)((l << 8) | t.vals[k]);
+            }
+        }
+        t.maxcode[l] = t.bits[l] ? code - 1 : -1;
+        if (code > (1 << l)) return false;
+        code <<= 1;
+    }
+    t.maxcode[17] = 0x7FFFFFFF;
+    return true;
+}
+
+struct JpegHeader {
+    int width = 0, height = 0, ncomp = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, restart = 0;
+    int cid[3], h[3], v[3], tq[3], td[3], ta[3];
+    uint16_t quant[4][64];          // natural order
+    bool qdef[4] = {false, false, false, false};
+    HuffTable dc[4], ac[4];
+    int64_t scan_data = -1;         // offset of the entropy-coded segment
+    bool supported = false;
+    const char *why = "no start of frame";
+};
+
+static inline int be16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
+
+// headers up to the first scan
+static bool parse_header(const uint8_t *d, int64_t size, JpegHeader &hd)
+{
+    if (size < 4 || d[0] != 0xFF || d[1] != 0xD8) { hd.why = "not a JPEG file"; return false; }
+    int64_t p = 2;
+    bool have_frame = false, adobe = false;
+    int adobe_transform = -1;
+    while (p + 4 <= size) {
+        if (d[p] != 0xFF) { hd.why = "marker expected"; return false; }
+        while (p < size && d[p] == 0xFF) ++p;       // fill bytes
+        if (p >= size) break;
+        const int m = d[p++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) break;
+        if (p + 2 > size) break;
+        const int len = be16(d + p);
+        if (len < 2 || p + len > size) { hd.why = "truncated segment"; return false; }
+        const uint8_t *s = d + p + 2;
+        const int n = len - 2;
+        if (m == 0xDB) {                    // DQT
+            int o = 0;
+            while (o < n) {
+                const int pq = s[o] >> 4, tq = s[o] & 15;
+                ++o;
+                if (tq > 3 || o + (pq ? 128 : 64) > n) { hd.why = "bad quantisation table"; return false; }
+                for (int i = 0; i < 64; ++i) {
+                    hd.quant[tq][ZIGZAG[i]] = pq ? (uint16_t)be16(s + o + 2 * i) : s[o + i];
+                }
+                o += pq ? 128 : 64;
+                hd.qdef[tq] = true;
+            }
+        } else if (m == 0xC4) {             // DHT
+            int o = 0;
+            while (o + 17 <= n) {
+                const int tc = s[o] >> 4, th = s[o] & 15;
+                if (tc > 1 || th > 3) { hd.why = "bad Huffman table id"; return false; }
+                HuffTable &t = tc ? hd.ac[th] : hd.dc[th];
+                int total = 0;
+                t.bits[0] = 0;
+                for (int i = 1; i <= 16; ++i) { t.bits[i] = s[o + i]; total += t.bits[i]; }
+                o += 17;
+                if (total > 256 || o + total > n) { hd.why = "bad Huffman table"; return false; }
+                for (int i = 0; i < total; ++i) t.vals[i] = s[o + i];
+                o += total;
+                if (!build_table(t)) { hd.why = "bad Huffman code lengths"; return false; }
+                t.defined = true;
+            }
+        } else if (m == 0xDD) {             // DRI
+            if (n >= 2) hd.restart = be16(s);
+        } else if (m == 0xEE) {             // APP14 Adobe
+            if (n >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
+        } else if (m == 0xC0 || m == 0xC1) {    // SOF0 / SOF1: sequential Huffman
+            if (n < 6) { hd.why = "bad frame header"; return false; }
+            if (s[0] != 8) { hd.why = "not 8 bits per sample"; return false; }
+            hd.height = be16(s + 1);
+            hd.width = be16(s + 3);
+            hd.ncomp = s[5];
+            if (hd.ncomp != 1 && hd.ncomp != 3) { hd.why = "not a grey or three-component image"; return false; }
+            if (n < 6 + 3 * hd.ncomp || hd.width <= 0 || hd.height <= 0) { hd.why = "bad frame header"; return false; }
+            for (int c = 0; c < hd.ncomp; ++c) {
+                hd.cid[c] = s[6 + 3 * c];
+                hd.h[c] = s[7 + 3 * c] >> 4;
+                hd.v[c] = s[7 + 3 * c] & 15;
+                hd.tq[c] = s[8 + 3 * c];
+                if (hd.tq[c] > 3) { hd.why = "bad quantisation table id"; return false; }
+            }
+            have_frame = true;
+        } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            hd.why = "progressive, lossless or arithmetic-coded";
+            return false;
+        } else if (m == 0xDA) {             // SOS
+            if (!have_frame) { hd.why = "scan before frame"; return false; }
+            if (n < 1 + 2 * hd.ncomp + 3 || s[0] != hd.ncomp) { hd.why = "several scans (non-interleaved)"; return false; }
+            for (int c = 0; c < hd.ncomp; ++c) {
+                if (s[1 + 2 * c] != hd.cid[c]) { hd.why = "scan component order"; return false; }
+                hd.td[c] = s[2 + 2 * c] >> 4;
+                hd.ta[c] = s[2 + 2 * c] & 15;
+                if (hd.td[c] > 3 || hd.ta[c] > 3 || !hd.dc[hd.td[c]].defined || !hd.ac[hd.ta[c]].defined || !hd.qdef[hd.tq[c]]) {
+                    hd.why = "missing table";
+                    return false;
+                }
+            }
+            const uint8_t *t = s + 1 + 2 * hd.ncomp;
+            if (t[0] != 0 || t[1] != 63 || t[2] != 0) { hd.why = "not a full sequential scan"; return false; }
+            hd.scan_data = p + len;
+            break;
+        }
+        p += len;
+    }
+    if (hd.scan_data < 0) { if (have_frame) hd.why = "no scan"; return false; }
+    // colour space as libjpeg guesses it (jdapimin.c default_decompress_parms)
+    if (hd.ncomp == 3) {
+        if (adobe && adobe_transform != 1) { hd.why = "Adobe marker: not YCbCr"; return false; }
+        if (!adobe && hd.cid[0] == 'R' && hd.cid[1] == 'G' && hd.cid[2] == 'B') { hd.why = "RGB-coded"; return false; }
+        if (hd.h[1] != 1 || hd.v[1] != 1 || hd.h[2] != 1 || hd.v[2] != 1) { hd.why = "chroma sampling factors"; return false; }
+        if (!((hd.h[0] == 1 && hd.v[0] == 1) || (hd.h[0] == 2 && hd.v[0] == 1) || (hd.h[0] == 2 && hd.v[0] == 2))) {
+            hd.why = "luma sampling factors";
+            return false;
+        }
+        hd.hmax = hd.h[0];
+        hd.vmax = hd.v[0];
+        if (hd.width < 16 || hd.height < 2) { hd.why = "too small"; return false; }
+    } else {
+        hd.h[0] = hd.v[0] = 1;              // a single component is never interleaved: MCU = one block
+        hd.hmax = hd.vmax = 1;
+    }
+    hd.mcux = (hd.width + 8 * hd.hmax - 1) / (8 * hd.hmax);
+    hd.mcuy = (hd.height + 8 * hd.vmax - 1) / (8 * hd.vmax);
+    hd.supported = true;
+    hd.why = "";
+    return true;
+}
+
+// bit reader over the entropy-coded segment: 0xFF00 -> 0xFF, any other marker ends the data (zeros follow)
+struct BitReader {
+    const uint8_t *d;
+    int64_t p, size;
+    uint64_t acc = 0;
+    int nbits = 0;
+    bool marker = false;
+
+    inline void fill()
+    {
+        while (nbits <= 56) {
+            int byte = 0;
+            if (!marker && p < size) {
+                byte = d[p];
+                if (byte == 0xFF) {
+                    if (p + 1 < size && d[p + 1] == 0) p += 2;
+                    else { marker = true; byte = 0; }
+                } else {
+                    ++p;
+                }
+            }
+            acc |= (uint64_t)byte << (56 - nbits);
+            nbits += 8;
+        }
+    }
+    inline int peek(int n) { return (int)(acc >> (64 - n)); }
+    inline void skip(int n) { acc <<= n; nbits -= n; }
+    inline int get(int n)
+    {
+        if (n == 0) return 0;
+        const int v = peek(n);
+        skip(n);
+        return v;
+    }
+    // RSTn: drop the rest of the byte, step over the marker
+    bool restart()
+    {
+        acc = 0;
+        nbits = 0;
+        if (marker) {
+            if (p + 1 < size && d[p] == 0xFF && d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7) { p += 2; marker = false; return true; }
+            return false;
+        }
+        // padding bits were consumed; look for the marker
+        while (p + 1 < size && !(d[p] == 0xFF && d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7)) ++p;
+        if (p + 1 >= size) return false;
+        p += 2;
+        return true;
+    }
+};
+
+static inline int huff_decode(BitReader &br, const HuffTable &t)
+{
+    br.fill();
+    const int look = br.peek(9);
+    const int e = t.fast[look];
+    if (e) {
+        br.skip(e >> 8);
+        return e & 255;
+    }
+    int code = br.peek(10), l = 10;
+    while (l <= 16 && code > t.maxcode[l]) { ++l; code = br.peek(l); }
+    if (l > 16) return -1;
+    br.skip(l);
+    return t.vals[t.valptr[l] + code - t.mincode[l]];
+}
+
+static inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+static bool decode_scan(const uint8_t *d, int64_t size, const JpegHeader &hd, const mdx_jpeg_info &info, int16_t *coef)
+{
+    BitReader br{d, hd.scan_data, size};
+    int pred[3] = {0, 0, 0};
+    const int64_t nmcu = (int64_t)hd.mcux * hd.mcuy;
+    int until_restart = hd.restart;
+    for (int64_t m = 0; m < nmcu; ++m) {
+        if (hd.restart && until_restart == 0) {
+            if (!br.restart()) return false;
+            pred[0] = pred[1] = pred[2] = 0;
+            until_restart = hd.restart;
+        }
+        const int my = (int)(m / hd.mcux), mx = (int)(m % hd.mcux);
+        for (int c = 0; c < hd.ncomp; ++c) {
+            const HuffTable &dct = hd.dc[hd.td[c]], &act = hd.ac[hd.ta[c]];
+            for (int by = 0; by < hd.v[c]; ++by)
+                for (int bx = 0; bx < hd.h[c]; ++bx) {
+                    int16_t *blk = coef + (info.block_offset[c] + (int64_t)(my * hd.v[c] + by) * info.blocks_w[c] + (mx * hd.h[c] + bx)) * 64;
+                    memset(blk, 0, 64 * sizeof(int16_t));
+                    int s = huff_decode(br, dct);
+                    if (s < 0 || s > 15) return false;
+                    if (s) {
+                        br.fill();
+                        pred[c] += extend(br.get(s), s);
+                    }
+                    blk[0] = (int16_t)pred[c];
+                    for (int k = 1; k < 64;) {
+                        const int rs = huff_decode(br, act);
+                        if (rs < 0) return false;
+                        const int r = rs >> 4;
+                        s = rs & 15;
+                        if (s == 0) {
+                            if (r != 15) break;
+                            k += 16;
+                            continue;
+                        }
+                        k += r;
+                        if (k > 63) return false;
+                        br.fill();
+                        blk[ZIGZAG[k]] = (int16_t)extend(br.get(s), s);
+                        ++k;
+                    }
+                }
+        }
+        if (hd.restart) --until_restart;
+    }
+    return true;
+}
+
+static void fill_info(const JpegHeader &hd, mdx_jpeg_info *info)
+{
+    memset(info, 0, sizeof *info);
+    info->width = hd.width;
+    info->height = hd.height;
+    info->ncomp = hd.ncomp;
+    info->supported = hd.supported ? 1 : 0;
+    if (!hd.supported) return;
+    int64_t off = 0;
+    for (int c = 0; c < hd.ncomp; ++c) {
+        info->hsamp[c] = hd.h[c];
+        info->vsamp[c] = hd.v[c];
+        info->blocks_w[c] = hd.mcux * hd.h[c];
+        info->blocks_h[c] = hd.mcuy * hd.v[c];
+        info->block_offset[c] = off;
+        off += (int64_t)info->blocks_w[c] * info->blocks_h[c];
+    }
+    info->nblocks = off;
+}
+
+// ---------------------------------------------------------------------------------------------------------- device
+// jidctint.c (jpeg_idct_islow): 13-bit constants, 2 extra bits kept between the column pass and the row pass
+#define JFIX_0_298631336 2446
+#define JFIX_0_390180644 3196
+#define JFIX_0_541196100 4433
+#define JFIX_0_765366865 6270
+#define JFIX_0_899976223 7373
+#define JFIX_1_175875602 9633
+#define JFIX_1_501321110 12299
+#define JFIX_1_847759065 15137
+#define JFIX_1_961570560 16069
+#define JFIX_2_053119869 16819
+#define JFIX_2_562915447 20995
+#define JFIX_3_072711026 25172
+
+__device__ __forceinline__ int32_t jdescale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// eight inputs of one column / row -> eight outputs, descaled by `shift`
+__device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8], int shift)
+{
+    int32_t z2 = in[2], z3 = in[6];
+    int32_t z1 = (z2 + z3) * JFIX_0_541196100;
+    int32_t tmp2 = z1 + z3 * (-JFIX_1_847759065);
+    int32_t tmp3 = z1 + z2 * JFIX_0_765366865;
+    z2 = in[0];
+    z3 = in[4];
+    int32_t tmp0 = (z2 + z3) << 13;
+    int32_t tmp1 = (z2 - z3) << 13;
+    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7];
+    tmp1 = in[5];
+    tmp2 = in[3];
+    tmp3 = in[1];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    int32_t z4 = tmp1 + tmp3;
+    const int32_t z5 = (z3 + z4) * JFIX_1_175875602;
+    tmp0 *= JFIX_0_298631336;
+    tmp1 *= JFIX_2_053119869;
+    tmp2 *= JFIX_3_072711026;
+    tmp3 *= JFIX_1_501321110;
+    z1 *= -JFIX_0_899976223;
+    z2 *= -JFIX_2_562915447;
+    z3 *= -JFIX_1_961570560;
+    z4 *= -JFIX_0_390180644;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    out[0] = jdescale(tmp10 + tmp3, shift);
+    out[7] = jdescale(tmp10 - tmp3, shift);
+    out[1] = jdescale(tmp11 + tmp2, shift);
+    out[6] = jdescale(tmp11 - tmp2, shift);
+    out[2] = jdescale(tmp12 + tmp1, shift);
+    out[5] = jdescale(tmp12 - tmp1, shift);
+    out[3] = jdescale(tmp13 + tmp0, shift);
+    out[4] = jdescale(tmp13 - tmp0, shift);
+}
+
+// libjpeg's post-IDCT range limit: index (x & 1023) into a table that is 128 + x clamped to 0..255 for -512 <= x < 512
+__device__ __forceinline__ uint8_t idct_limit(int32_t x)
+{
+    const int32_t i = x & 1023;
+    return (uint8_t)(i < 128 ? 128 + i : (i < 512 ? 255 : (i < 896 ? 0 : i - 896)));
+}
+
+struct JpegGeom {
+    int32_t width, height, ncomp, hmax, vmax;
+    int32_t bw[3], bh[3];
+    int64_t boff[3];            // first block of the component
+    int64_t poff[3];            // first byte of the component's plane ([bh*8][bw*8])
+    int64_t nblocks;
+};
+
+// one thread per 8x8 block: dequantise, column pass, row pass, range limit -> the component's plane
+__global__ __launch_bounds__(64) void jpeg_idct_kernel(const int16_t *__restrict__ coef, const uint16_t *__restrict__ quant, JpegGeom g,
+                                                       uint8_t *__restrict__ planes)
+{
+    const int64_t blk = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (blk >= g.nblocks) return;
+    int c = 0;
+    if (g.ncomp == 3) c = blk >= g.boff[2] ? 2 : (blk >= g.boff[1] ? 1 : 0);
+    const int64_t lb = blk - g.boff[c];
+    const int by = (int)(lb / g.bw[c]), bx = (int)(lb % g.bw[c]);
+    const int16_t *src = coef + blk * 64;
+    const uint16_t *q = quant + c * 64;
+    int32_t ws[64];
+#pragma unroll
+    for (int col = 0; col < 8; ++col) {
+        int32_t in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = (int32_t)src[8 * r + col] * (int32_t)q[8 * r + col];
+        idct8(in, out, 13 - 2);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[8 * r + col] = out[r];
+    }
+    uint8_t *dst = planes + g.poff[c] + ((int64_t)by * 8) * ((int64_t)g.bw[c] * 8) + bx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int32_t in[8], out[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) in[k] = ws[8 * r + k];
+        idct8(in, out, 13 + 2 + 3);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo |= (uint32_t)idct_limit(out[k]) << (8 * k);
+            hi |= (uint32_t)idct_limit(out[4 + k]) << (8 * k);
+        }
+        uint32_t *row = (uint32_t *)(dst + (int64_t)r * g.bw[c] * 8);
+        row[0] = lo;
+        row[1] = hi;
+    }
+}
+
+__device__ __forceinline__ uint8_t clamp8(int32_t x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+
+// chroma sample at full resolution (jdsample.c): h2v2 / h2v1 "fancy" triangle filters, or the sample itself
+__device__ __forceinline__ int32_t chroma_at(const uint8_t *__restrict__ pl, int64_t stride, int x, int y, int dw, int dh, int hs, int vs)
+{
+    if (hs == 1) return pl[(int64_t)y * stride + x];
+    const int i = x >> 1;
+    if (vs == 1) {          // h2v1: (3 * this + neighbour + 1 or 2) >> 2; the first and last column copy
+        const int32_t cur = pl[(int64_t)y * stride + i];
+        if (x & 1) return i == dw - 1 ? cur : (3 * cur + pl[(int64_t)y * stride + i + 1] + 2) >> 2;
+        return i == 0 ? cur : (3 * cur + pl[(int64_t)y * stride + i - 1] + 1) >> 2;
+    }
+    // h2v2: column sums 3 * nearer row + farther row, then 3 * this column + neighbouring column
+    const int r = y >> 1;
+    int far = (y & 1) ? r + 1 : r - 1;
+    far = far < 0 ? 0 : (far > dh - 1 ? dh - 1 : far);           // the rows beyond the image repeat its edge rows
+    const uint8_t *n0 = pl + (int64_t)r * stride, *n1 = pl + (int64_t)far * stride;
+    const int32_t cs = 3 * n0[i] + n1[i];
+    if (x & 1) {
+        if (i == dw - 1) return (4 * cs + 7) >> 4;
+        return (3 * cs + 3 * n0[i + 1] + n1[i + 1] + 7) >> 4;
+    }
+    if (i == 0) return (4 * cs + 8) >> 4;
+    return (3 * cs + 3 * n0[i - 1] + n1[i - 1] + 8) >> 4;
+}
+
+// one thread per output pixel: upsample the chroma, YCbCr -> RGB with jdcolor.c's 16-bit fixed point
+__global__ __launch_bounds__(256) void jpeg_rgb_kernel(const uint8_t *__restrict__ planes, JpegGeom g, uint8_t *__restrict__ rgb)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)g.width * g.height) return;
+    const int y = (int)(idx / g.width), x = (int)(idx % g.width);
+    const int32_t lum = planes[g.poff[0] + (int64_t)y * g.bw[0] * 8 + x];
+    uint8_t *o = rgb + idx * 3;
+    if (g.ncomp == 1) {
+        o[0] = o[1] = o[2] = (uint8_t)lum;
+        return;
+    }
+    const int dw = (g.width + g.hmax - 1) / g.hmax, dh = (g.height + g.vmax - 1) / g.vmax;      // chroma size that counts
+    const int32_t cb = chroma_at(planes + g.poff[1], (int64_t)g.bw[1] * 8, x, y, dw, dh, g.hmax, g.vmax) - 128;
+    const int32_t cr = chroma_at(planes + g.poff[2], (int64_t)g.bw[2] * 8, x, y, dw, dh, g.hmax, g.vmax) - 128;
+    // FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554; ONE_HALF = 32768
+    o[0] = clamp8(lum + ((91881 * cr + 32768) >> 16));
+    o[1] = clamp8(lum + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+    o[2] = clamp8(lum + ((116130 * cb + 32768) >> 16));
+}
+
+static void geom_of(const mdx_jpeg_info &info, JpegGeom *g)
+{
+    g->width = info.width;
+    g->height = info.height;
+    g->ncomp = info.ncomp;
+    g->hmax = info.hsamp[0];
+    g->vmax = info.vsamp[0];
+    g->nblocks = info.nblocks;
+    int64_t p = 0;
+    for (int c = 0; c < 3; ++c) {
+        g->bw[c] = c < info.ncomp ? info.blocks_w[c] : 0;
+        g->bh[c] = c < info.ncomp ? info.blocks_h[c] : 0;
+        g->boff[c] = c < info.ncomp ? info.block_offset[c] : info.nblocks;
+        g->poff[c] = p;
+        p += (int64_t)g->bw[c] * g->bh[c] * 64;
+    }
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+extern "C" {
+
+int mdx_jpeg_probe(const uint8_t *file, int64_t size, mdx_jpeg_info *info)
+{
+    MDX_CHECK_ARG(file && info && size > 0, "mdx_jpeg_probe: NULL pointer or empty file");
+    JpegHeader hd;
+    parse_header(file, size, hd);
+    fill_info(hd, info);
+    if (!hd.supported) set_error("mdx_jpeg_probe: left to the host decoder (%s)", hd.why);
+    return MDX_OK;
+}
+
+int mdx_jpeg_coefficients(const uint8_t *file, int64_t size, int16_t *coef, int64_t coef_blocks, uint16_t *quant)
+{
+    MDX_CHECK_ARG(file && coef && quant && size > 0, "mdx_jpeg_coefficients: NULL pointer or empty file");
+    JpegHeader hd;
+    MDX_CHECK_ARG(parse_header(file, size, hd), "mdx_jpeg_coefficients: unsupported file (%s)", hd.why);
+    mdx_jpeg_info info;
+    fill_info(hd, &info);
+    MDX_CHECK_ARG(coef_blocks >= info.nblocks, "mdx_jpeg_coefficients: room for %lld blocks, the image has %lld", (long long)coef_blocks,
+                  (long long)info.nblocks);
+    for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < 64; ++i) quant[c * 64 + i] = c < hd.ncomp ? hd.quant[hd.tq[c]][i] : 0;
+    MDX_CHECK_ARG(decode_scan(file, size, hd, info, coef), "mdx_jpeg_coefficients: corrupt entropy-coded data");
+    return MDX_OK;
+}
+
+int mdx_jpeg_pixels(const int16_t *coef, const uint16_t *quant, const mdx_jpeg_info *info, uint8_t *planes, uint8_t *rgb, void *stream)
+{
+    MDX_CHECK_ARG(coef && quant && info && planes && rgb, "mdx_jpeg_pixels: NULL pointer");
+    MDX_CHECK_ARG(info->supported && info->nblocks > 0 && info->width > 0 && info->height > 0, "mdx_jpeg_pixels: unsupported image");
+    JpegGeom g;
+    geom_of(*info, &g);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)ceil_div(g.nblocks, 64)), dim3(64), 0, s, coef, quant, g, planes);
+    hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((unsigned)ceil_div((int64_t)g.width * g.height, 256)), dim3(256), 0, s,
+                       (const uint8_t *)planes, g, rgb);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+}  // extern "C"

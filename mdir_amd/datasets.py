@@ -54,19 +54,52 @@ def imresize(img, imsize):
 class ImagesFromList(data.Dataset):
     """``resize_on_device=True`` (not in the reference): the down-scaling to ``imsize`` is left to the consumer
     (``mdir_amd.resample.DeviceThumbnail``, same pixels) for the images the device path covers; the others are
-    shrunk here as always."""
+    shrunk here as always.  ``decode_on_device=True`` (with it): a baseline JPEG file is only entropy-decoded here and
+    handed over as ``mdir_amd.jpeg.JpegCoefficients`` -- IDCT, upsampling and colour conversion happen on the device
+    (``mdir_amd.jpeg.pixels``, same pixels); other files, and boxes that stick out of the image, take the usual route."""
 
     def __init__(self, root, images, imsize=None, bbxs=None, transform=None, loader=default_loader,
-                 ignore_errors=False, resize_on_device=False):
+                 ignore_errors=False, resize_on_device=False, decode_on_device=False):
         images_fn = [os.path.join(root, images[i]) for i in range(len(images))]
         if len(images_fn) == 0:
             raise RuntimeError("Dataset contains 0 images!")
         self.root, self.images, self.imsize, self.images_fn = root, images, imsize, images_fn
         self.bbxs, self.transform, self.loader, self.ignore_errors = bbxs, transform, loader, ignore_errors
         self.resize_on_device = resize_on_device
+        self.decode_on_device = decode_on_device and (resize_on_device or imsize is None) and loader is default_loader
+
+    def _coefficients(self, index):
+        """The file as JPEG coefficients for the device, or None (not such a file, or a case for the host route)."""
+        from . import jpeg
+        from .resample import on_device
+        try:
+            with open(self.images_fn[index], "rb") as f:
+                data = f.read()
+        except OSError:
+            return None                                     # the host route reports it
+        if data[:2] != b"\xff\xd8":
+            return None
+        item = jpeg.entropy_decode(data, self.bbxs[index] if self.bbxs else None)
+        if item is None:
+            return None
+        w, h = item.size
+        if item.box:
+            if not jpeg.box_on_device(item.box, w, h):
+                return None
+            w, h = int(item.box[2] - item.box[0]), int(item.box[3] - item.box[1])
+        # the thumbnail must be one the device makes (or none at all): otherwise Pillow shrinks it here, from its own decode
+        if self.imsize is not None and on_device(w, h, self.imsize) is None:
+            from .resample import thumbnail_size
+            if thumbnail_size(w, h, self.imsize) not in (None, (w, h)):
+                return None
+        return item
 
     def __getitem__(self, index):
         path = self.images_fn[index]
+        if self.decode_on_device:
+            item = self._coefficients(index)
+            if item is not None:
+                return item
         img = self.loader(path)
         if isinstance(img, Exception):
             sys.stderr.write("Warning: Image '%s' was not found\n" % path)
@@ -109,6 +142,8 @@ class ThreadedLoader:
             item = item.unsqueeze(0)
             if self.pin and torch.cuda.is_available():
                 item = item.pin_memory()
+        elif self.pin and hasattr(item, "pin_memory") and torch.cuda.is_available():
+            item = item.pin_memory()                        # mdir_amd.jpeg.JpegCoefficients
         return item
 
     def __iter__(self):

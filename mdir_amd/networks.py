@@ -26,6 +26,7 @@ from .backbones import OUTPUT_DIM, TrunkSequential, build_features
 from .datasets import ImagesFromList, ToUint8HWC, get_data_root, make_loader
 from .graphs import ShapeGraphs, graphs_enabled, parallel_map
 from .layers import POOLING, L2N, pool_kind
+from .jpeg import pixels as pixels_of
 from .resample import DeviceThumbnail
 
 
@@ -288,7 +289,7 @@ def batched_loop(loader, order, device, describe, store, missing=None, progress=
         if isinstance(item, dict) and item == {}:
             missing(i)
         else:
-            item = item.to(device, non_blocking=True)
+            item = pixels_of(item, device) if hasattr(item, "coef") else item.to(device, non_blocking=True)
             if buf and buf[0][1].shape != item.shape:
                 flush()
             buf.append((i, item, order.upcoming[done] if getattr(order, "upcoming", None) else None))
@@ -327,8 +328,13 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
     if graphs_enabled(device):
         describe = ShapeGraphs(describe)      # per input shape: eager once, then one hipGraph replay per call
         order = ShapeOrder(images, bbxs)
+    # JPEG files: entropy decoding in the loader threads, the rest of the decoder on the device (thread loader only: the
+    # coefficients are handed over as an object, not collated)
+    decode_on_device = tail is not None and (resize_on_device or image_size is None) and num_workers > 0 \
+        and os.environ.get("MDIR_AMD_GPU_JPEG", "1") != "0" \
+        and os.environ.get("MDIR_AMD_LOADER", "threads") != "processes"
     dataset = ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform,
-                             resize_on_device=resize_on_device)
+                             resize_on_device=resize_on_device, decode_on_device=decode_on_device)
     loader = make_loader(dataset, order, num_workers, device)
     state = {"vecs": None}
 

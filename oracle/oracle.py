@@ -506,6 +506,86 @@ def thumbnail_u8(img, imsize):
     return np.asarray(img).copy() if size is None else resample_u8(img, size[0], size[1])
 
 
+# ---- libjpeg's decompression after the entropy decoder, restated (third-party arithmetic the reference calls through
+# Pillow: datahelpers.py:24-31 -> Image.open().convert('RGB') -> libjpeg-turbo with its defaults; jidctint.c
+# jpeg_idct_islow, jdsample.c h2v1 / h2v2 fancy upsampling, jdcolor.c ycc_rgb_convert).  Pinned against Pillow's own
+# decode of the same files in tests/test_oracle_golden.py. ------------------------------------------------------------------
+
+def _jpeg_idct8(v, shift):
+    """One 1-D pass of jpeg_idct_islow over axis 0 of an int32 array ``[8, ...]``, descaled by ``shift``."""
+    I = np.int32
+    z2, z3 = v[2], v[6]
+    z1 = (z2 + z3) * I(4433)
+    tmp2 = z1 + z3 * I(-15137)
+    tmp3 = z1 + z2 * I(6270)
+    z2, z3 = v[0], v[4]
+    tmp0 = (z2 + z3) << 13
+    tmp1 = (z2 - z3) << 13
+    tmp10, tmp13, tmp11, tmp12 = tmp0 + tmp3, tmp0 - tmp3, tmp1 + tmp2, tmp1 - tmp2
+    tmp0, tmp1, tmp2, tmp3 = v[7], v[5], v[3], v[1]
+    z1, z2, z3, z4 = tmp0 + tmp3, tmp1 + tmp2, tmp0 + tmp2, tmp1 + tmp3
+    z5 = (z3 + z4) * I(9633)
+    tmp0, tmp1, tmp2, tmp3 = tmp0 * I(2446), tmp1 * I(16819), tmp2 * I(25172), tmp3 * I(12299)
+    z1, z2, z3, z4 = z1 * I(-7373), z2 * I(-20995), z3 * I(-16069) + z5, z4 * I(-3196) + z5
+    tmp0, tmp1, tmp2, tmp3 = tmp0 + z1 + z3, tmp1 + z2 + z4, tmp2 + z2 + z3, tmp3 + z1 + z4
+    half = I(1 << (shift - 1))
+    out = [tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3]
+    return np.stack([(o + half) >> shift for o in out])
+
+
+def jpeg_pixels(coef, quant, info):
+    """Quantised coefficients (``[nblocks,64]`` int16, natural order, component after component, blocks row by row over
+    whole MCUs) + quantisation tables (``[3,64]``) -> uint8 ``[H,W,3]``, as libjpeg with its defaults.  ``info``: dict
+    with width, height, ncomp, hsamp, vsamp, blocks_w, blocks_h, block_offset."""
+    W, H, nc = info["width"], info["height"], info["ncomp"]
+    planes = []
+    for c in range(nc):
+        bw, bh, off = info["blocks_w"][c], info["blocks_h"][c], info["block_offset"][c]
+        blk = coef[off:off + bw * bh].astype(np.int32) * quant[c].astype(np.int32)[None, :]       # dequantise
+        blk = blk.reshape(-1, 8, 8)                                                               # [n, row, col]
+        ws = _jpeg_idct8(np.moveaxis(blk, 1, 0), 13 - 2)                                          # columns: over the rows
+        px = _jpeg_idct8(np.moveaxis(ws, 2, 0), 13 + 2 + 3)                                       # rows: over the columns
+        px = np.moveaxis(px, 0, 2)                                                                # [row, n, col] -> [row, n, col]
+        idx = px & 1023                                                                           # the post-IDCT range limit table
+        val = np.where(idx < 128, 128 + idx, np.where(idx < 512, 255, np.where(idx < 896, 0, idx - 896))).astype(np.int32)
+        val = np.moveaxis(val, 0, 1).reshape(bh, bw, 8, 8).transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8)
+        planes.append(val)
+    lum = planes[0][:H, :W]
+    if nc == 1:
+        return np.repeat(lum[:, :, None], 3, axis=2).astype(np.uint8)
+    hs, vs = info["hsamp"][0], info["vsamp"][0]
+    dw, dh = -(-W // hs), -(-H // vs)
+    chroma = []
+    for pl in planes[1:]:
+        pl = pl[:dh, :dw]
+        if hs == 2 and vs == 2:         # h2v2 fancy: 3 * nearer row + farther row, then 3 * this column + the neighbouring one
+            up = np.concatenate([pl[:1], pl[:-1]]), np.concatenate([pl[1:], pl[-1:]])
+            rows = np.empty((2 * dh, dw), dtype=np.int32)
+            rows[0::2], rows[1::2] = 3 * pl + up[0], 3 * pl + up[1]
+            out = np.empty((2 * dh, 2 * dw), dtype=np.int32)
+            left = np.concatenate([rows[:, :1], rows[:, :-1]], axis=1)
+            right = np.concatenate([rows[:, 1:], rows[:, -1:]], axis=1)
+            out[:, 0::2] = (3 * rows + left + 8) >> 4
+            out[:, 1::2] = (3 * rows + right + 7) >> 4
+            out[:, 0] = (4 * rows[:, 0] + 8) >> 4
+            out[:, -1] = (4 * rows[:, -1] + 7) >> 4
+            pl = out
+        elif hs == 2:                   # h2v1 fancy
+            out = np.empty((dh, 2 * dw), dtype=np.int32)
+            left = np.concatenate([pl[:, :1], pl[:, :-1]], axis=1)
+            right = np.concatenate([pl[:, 1:], pl[:, -1:]], axis=1)
+            out[:, 0::2] = (3 * pl + left + 1) >> 2
+            out[:, 1::2] = (3 * pl + right + 2) >> 2
+            out[:, 0], out[:, -1] = pl[:, 0], pl[:, -1]
+            pl = out
+        chroma.append(pl[:H, :W] - 128)
+    cb, cr = chroma
+    r = lum + ((91881 * cr + 32768) >> 16)
+    g = lum + ((-22554 * cb + 32768 - 46802 * cr) >> 16)
+    b = lum + ((116130 * cb + 32768) >> 16)
+    return np.clip(np.stack([r, g, b], axis=2), 0, 255).astype(np.uint8)
+
+
 def nanmean_metric(per_query):
     """The number eval.py prints: nan-filtered mean of the per-query rows
     (``mdir/tools/eventprocessor.py:101-115``)."""

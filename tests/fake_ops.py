@@ -56,6 +56,18 @@ def resample_u8(images, axis, bounds, taps):
     return torch.from_numpy(np.ascontiguousarray(np.moveaxis(out, 0, 2 if axis == 1 else 1)))
 
 
+def jpeg_pixels(item, device):
+    """Stand-in for mdir_amd.jpeg.pixels: the oracle's restatement of libjpeg on the item's coefficients."""
+    info = item.info
+    meta = {k: (list(getattr(info, k)) if k.endswith(("samp", "_w", "_h", "offset")) else getattr(info, k))
+            for k in ("width", "height", "ncomp", "hsamp", "vsamp", "blocks_w", "blocks_h", "block_offset")}
+    rgb = O.jpeg_pixels(item.coef.numpy(), item.quant.numpy().view(np.uint16), meta)[None]
+    if item.box:
+        x1, y1, x2, y2 = (int(v) for v in item.box)
+        rgb = rgb[:, y1:y2, x1:x2]
+    return torch.from_numpy(np.ascontiguousarray(rgb))
+
+
 class DescriptorIndex:
     def __init__(self, vecs, layout="DN", row_offset=0):
         v = vecs.detach().numpy()

@@ -271,15 +271,19 @@ def test_extraction_with_device_thumbnail_equals_host_thumbnail(tmp_path, monkey
     tr = initialize_transforms("pil2np | totensor | normalize", [net.meta["mean"], net.meta["std"]])
     monkeypatch.setattr(ShapeGraphs, "PAYOFF_IMAGES", 0)
     monkeypatch.setenv("MDIR_AMD_WORKERS", "2")
-    calls = []
+    calls, decoded = [], []
     real = ops.resample_u8
     monkeypatch.setattr(ops, "resample_u8", lambda *a: (calls.append(a[1]), real(*a))[1])
+    from mdir_amd import networks
+    real_px = networks.pixels_of
+    monkeypatch.setattr(networks, "pixels_of", lambda item, dev: (decoded.append(item.size), real_px(item, dev))[1])
     on_dev = extract_vectors_device(net, paths, 224, tr, bbxs=bbxs, ms=[1, 0.5], msp=1.0, device=DEV)
     assert calls.count(0) >= 3 and calls.count(1) >= 3                   # width and height passes ran (eager + captured)
+    assert len(decoded) == len(paths)                                    # every JPEG went through the device half of the decoder
     ncalls = len(calls)
     monkeypatch.setenv("MDIR_AMD_GPU_RESIZE", "0")
     on_host = extract_vectors_device(net, paths, 224, tr, bbxs=bbxs, ms=[1, 0.5], msp=1.0, device=DEV)
-    assert len(calls) == ncalls
+    assert len(calls) == ncalls and len(decoded) == len(paths)            # Pillow decoded and shrank these
     np.testing.assert_allclose(on_dev.cpu().numpy(), on_host.cpu().numpy(), rtol=0, atol=2e-6)    # MIOpen is not run-to-run bit-stable
     monkeypatch.setenv("MDIR_AMD_GPU_RESIZE", "1")
     monkeypatch.setenv("MDIR_AMD_GRAPHS", "0")

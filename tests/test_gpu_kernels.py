@@ -254,6 +254,33 @@ def test_device_thumbnail_is_pillow(ops, w, h, imsize, batch):
         np.testing.assert_array_equal(got[0], O.thumbnail_u8(arr[0], imsize))
 
 
+def test_jpeg_pixels_is_pillow(ops):
+    """The device half of the JPEG decoder (mdx_jpeg_pixels: dequantisation, islow IDCT, fancy upsampling, YCbCr -> RGB)
+    on the coefficients the host half delivers = Pillow's ``Image.open(f).convert('RGB')`` (datahelpers.py:24-31), pixel
+    for pixel: 4:4:4 / 4:2:2 / 4:2:0 / grey, odd sizes, qualities 1..100, saturated pictures, restart markers, a crop box."""
+    import io
+    from PIL import Image
+    from mdir_amd import jpeg
+    from test_oracle_golden import _jpeg_cases
+    cases, picture = _jpeg_cases()
+    buf = io.BytesIO()
+    picture(1600, 1200, "photo").save(buf, format="JPEG", quality=90)
+    cases.append(("camera-sized", buf.getvalue()))
+    for name, data in cases:
+        item = jpeg.entropy_decode(data)
+        assert item is not None, name
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        got = jpeg.pixels(item.pin_memory(), torch.device(DEV))
+        assert got.shape == (1,) + want.shape
+        np.testing.assert_array_equal(got[0].cpu().numpy(), want, err_msg=name)
+    item = jpeg.entropy_decode(cases[2][1], box=(3, 5, 100, 70))
+    want = np.asarray(Image.open(io.BytesIO(cases[2][1])).convert("RGB").crop((3, 5, 100, 70)))
+    np.testing.assert_array_equal(jpeg.pixels(item, torch.device(DEV))[0].cpu().numpy(), want)
+    buf = io.BytesIO()
+    picture(64, 64, "noise").save(buf, format="JPEG", progressive=True)
+    assert jpeg.entropy_decode(buf.getvalue()) is None
+
+
 def test_u8_to_chw_matches_host_chain(ops):
     """mdx_u8_to_chw == `pil2np | totensor | normalize` bit for bit (RGB and single channel, odd sizes, batch)."""
     rng = np.random.default_rng(2)

@@ -710,6 +710,34 @@ def test_threaded_loader_order_errors_and_missing_images(tmp_path):
     assert len(seen) == 3                                     # the three readable images before it were delivered
 
 
+def test_loader_hands_jpeg_files_over_as_coefficients(tmp_path):
+    """``decode_on_device``: a baseline JPEG leaves the loader entropy-decoded (pixels = Pillow's once the device half,
+    here the oracle, has run: crop box included); PNG and progressive files, boxes that stick out and thumbnails Pillow makes
+    in several steps take the usual route and arrive as pixels."""
+    from mdir_amd.datasets import ImagesFromList, ToUint8HWC
+    from mdir_amd.jpeg import JpegCoefficients
+    rng = np.random.default_rng(6)
+    low = rng.integers(0, 255, (40, 52, 3)).astype(np.float32)
+    arr = np.clip(np.kron(low, np.ones((8, 8, 1), np.float32)) + rng.normal(0, 10, (320, 416, 3)), 0, 255).astype(np.uint8)
+    big = np.tile(arr, (8, 6, 1))[:2400, :2200]
+    Image.fromarray(arr).save(tmp_path / "base.jpg", quality=88)
+    Image.fromarray(arr).save(tmp_path / "prog.jpg", quality=88, progressive=True)
+    Image.fromarray(arr).save(tmp_path / "pic.png")
+    Image.fromarray(big).save(tmp_path / "big.jpg", quality=80)
+    names = ["base.jpg", "base.jpg", "base.jpg", "prog.jpg", "pic.png", "big.jpg"]
+    boxes = [None, (10, 20, 300, 250), (-5, 0, 100, 100), None, None, None]
+    ds = ImagesFromList(str(tmp_path), names, imsize=256, bbxs=boxes, transform=ToUint8HWC(), resize_on_device=True, decode_on_device=True)
+    plain = ImagesFromList(str(tmp_path), names, imsize=256, bbxs=boxes, transform=ToUint8HWC(), resize_on_device=True)
+    kinds = [isinstance(ds[i], JpegCoefficients) for i in range(6)]
+    assert kinds == [True, True, False, False, False, False]           # big.jpg shrinks 9x: Pillow reduces first, from its own decode
+    for i in (0, 1):
+        np.testing.assert_array_equal(fake_ops.jpeg_pixels(ds[i], "cpu")[0].numpy(), plain[i].numpy())
+    for i in (2, 3, 4, 5):
+        assert torch.equal(ds[i], plain[i])
+    assert isinstance(ImagesFromList(str(tmp_path), names, imsize=None, transform=ToUint8HWC(), decode_on_device=True)[0], JpegCoefficients)
+    assert not isinstance(ImagesFromList(str(tmp_path), names, imsize=256, transform=ToUint8HWC(), decode_on_device=True)[0], JpegCoefficients)
+
+
 def test_embedding_output_golden(golden):
     """Golden G14: the reference's EmbeddingOutput (output.py:117-139): float64 [N,D], NaN row for an unreadable image."""
     from mdir_amd.stages import EmbeddingOutput

@@ -282,3 +282,74 @@ def test_thumbnail_restatement_is_pillow_and_g15(golden, tmp_path):
         raw = O.load_image(str(tmp_path / (name + ".png")), None, bbx)
         got = raw if imsize is None else O.thumbnail_u8(raw, imsize)
         np.testing.assert_array_equal(got, g["case%d_out" % ci])
+
+
+def _jpeg_cases():
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(21)
+
+    def picture(w, h, kind):
+        if kind == "sat":
+            a = rng.integers(0, 2, (h, w, 3)) * 255
+        elif kind == "noise":
+            a = rng.integers(0, 256, (h, w, 3))
+        elif kind == "photo":
+            low = rng.integers(0, 255, (h // 8 + 1, w // 8 + 1, 3)).astype(np.float32)
+            a = np.clip(np.kron(low, np.ones((8, 8, 1), np.float32))[:h, :w] + rng.normal(0, 15, (h, w, 3)), 0, 255)
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            a = np.stack([xx * 255 // max(w - 1, 1), yy * 255 // max(h - 1, 1), (xx * 7 + yy * 13) % 256], axis=2)
+        return Image.fromarray(a.astype(np.uint8))
+
+    out = []
+    for w, h, kind, q, sub, kw in [(64, 48, "photo", 90, 0, {}), (65, 47, "photo", 75, 2, {}), (131, 77, "photo", 85, 1, {}),
+                                   (33, 50, "photo", 95, 2, {"optimize": True}), (17, 19, "noise", 80, 2, {}), (16, 16, "grad", 30, 1, {}),
+                                   (97, 61, "sat", 1, 2, {}), (97, 61, "sat", 100, 0, {}), (97, 61, "noise", 10, 1, {}), (97, 61, "grad", 100, 2, {}),
+                                   (300, 200, "noise", 85, 2, {"restart_marker_blocks": 7}), (300, 200, "grad", 85, 1, {"restart_marker_rows": 1}),
+                                   (640, 480, "photo", 90, 2, {})]:
+        buf = io.BytesIO()
+        picture(w, h, kind).save(buf, format="JPEG", quality=q, subsampling=sub, **kw)
+        out.append(("%dx%d %s q%d sub%d %s" % (w, h, kind, q, sub, kw), buf.getvalue()))
+    buf = io.BytesIO()
+    picture(200, 120, "photo").convert("L").save(buf, format="JPEG", quality=50)
+    out.append(("grey", buf.getvalue()))
+    return out, picture
+
+
+def test_jpeg_restatement_is_pillow():
+    """libjpeg's decompression restated (host: the library's entropy decoder, the serial half of the product's JPEG path;
+    oracle: dequantisation, islow IDCT, fancy upsampling, YCbCr -> RGB) equals Pillow's decode of the same file -- Pillow is
+    what the reference calls (datahelpers.py:24-31) -- pixel for pixel: 4:4:4 / 4:2:2 / 4:2:0 / grey, odd sizes, qualities
+    1..100, saturated pictures, optimised Huffman tables, restart markers; progressive, CMYK and non-JPEG files are declined."""
+    import ctypes
+    import io
+    from PIL import Image
+    from mdir_amd import _lib
+    lib = _lib.lib()
+    cases, picture = _jpeg_cases()
+
+    def decode(data):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        info = _lib.JpegInfo()
+        assert lib.mdx_jpeg_probe(buf.ctypes.data, buf.size, ctypes.byref(info)) == 0
+        if not info.supported:
+            return None
+        coef, quant = np.empty((info.nblocks, 64), dtype=np.int16), np.empty((3, 64), dtype=np.uint16)
+        assert lib.mdx_jpeg_coefficients(buf.ctypes.data, buf.size, coef.ctypes.data, info.nblocks, quant.ctypes.data) == 0
+        return O.jpeg_pixels(coef, quant, {k: (list(getattr(info, k)) if k.endswith(("samp", "_w", "_h", "offset")) else getattr(info, k))
+                                           for k in ("width", "height", "ncomp", "hsamp", "vsamp", "blocks_w", "blocks_h", "block_offset")})
+
+    for name, data in cases:
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        got = decode(data)
+        assert got is not None, name
+        np.testing.assert_array_equal(got, want, err_msg=name)
+    for kw, mode in (({"progressive": True}, "RGB"), ({}, "CMYK")):
+        buf = io.BytesIO()
+        picture(64, 64, "noise").convert(mode).save(buf, format="JPEG", **kw)
+        assert decode(buf.getvalue()) is None
+    buf = io.BytesIO()
+    picture(64, 64, "noise").save(buf, format="PNG")
+    assert decode(buf.getvalue()) is None
+    assert decode(cases[0][1][:300] + b"\x00" * 50) is None or True        # a truncated stream must not crash
