@@ -106,6 +106,14 @@ int mdx_bn_act(float *x, const float *residual, int64_t N, int64_t C, int64_t HW
 int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W, int C, const float *mean,
                   const float *std, float *out, void *stream);
 
+/* The scaled copies of an image batch, every level in ONE launch:  src [B,C,H,W] fp32 -> outs[l] [B,C,floor(H*s_l),floor(W*s_l)]
+ * = `F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False)` of CirMultiscaleAggregation.preprocess
+ * (mdir/components/data/wrapper.py:104-107) and extract_ms (cirtorch/networks/imageretrievalnet.py:315), torch >= 1.6
+ * semantics (source coordinate (dst + 0.5) / s - 0.5 clamped at 0, fp32).  scales: HOST array of L doubles (levels with
+ * s = 1 are the caller's own tensor and are not passed); outs: HOST array of L device pointers. */
+int mdx_bilinear_pyramid(const float *src, int64_t B, int64_t C, int H, int W, int L, const double *scales,
+                         float *const *outs, void *stream);
+
 /* One pass of the image down-scaling, along the width (axis 1: [B,H,W,C] -> [B,H,out_len,C]) or the height
  * (axis 0: -> [B,out_len,W,C]) of uint8 images:
  *   dst[o] = clip8((2^21 + sum_{t < count[o]} src[first[o] + t] * k[o*ksize + t]) >> 22)

@@ -215,3 +215,71 @@ extern "C" int mdx_resample_u8(const uint8_t *src, int64_t B, int H, int W, int 
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// The image pyramid: `F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False)` of
+// CirMultiscaleAggregation.preprocess (mdir/components/data/wrapper.py:104-107) and extract_ms
+// (cirtorch/networks/imageretrievalnet.py:315) for every scale of the pyramid in ONE launch.  torch >= 1.6 semantics
+// (SURVEY quirk Q6): output size floor(in * s); source coordinate (dst + 0.5) / s - 0.5 clamped at 0, computed in fp32
+// with 1 / s rounded to fp32 first; the four neighbours blended as
+//     h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d),     h1 = frac(y), h0 = 1 - h1  (and likewise w).
+// ---------------------------------------------------------------------------
+namespace mdx {
+
+struct PyramidLevels {
+    float *out[8];
+    int h[8], w[8];
+    float rh[8], rw[8];         // 1 / scale as fp32
+    int64_t first[9];           // first output element of level l
+};
+
+__global__ __launch_bounds__(256) void bilinear_pyramid_kernel(const float *__restrict__ src, int64_t planes, int H, int W,
+                                                               PyramidLevels lv, int L)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= lv.first[L]) return;
+    int l = 0;
+    while (l + 1 < L && idx >= lv.first[l + 1]) ++l;
+    const int64_t e = idx - lv.first[l];
+    const int w = lv.w[l], h = lv.h[l];
+    const int x = (int)(e % w), y = (int)((e / w) % h);
+    const int64_t plane = e / ((int64_t)w * h);
+    float fy = lv.rh[l] * ((float)y + 0.5f) - 0.5f, fx = lv.rw[l] * ((float)x + 0.5f) - 0.5f;
+    fy = fy < 0.0f ? 0.0f : fy;
+    fx = fx < 0.0f ? 0.0f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int yp = y0 < H - 1 ? 1 : 0, xp = x0 < W - 1 ? 1 : 0;
+    const float h1 = fy - (float)y0, h0 = 1.0f - h1, w1 = fx - (float)x0, w0 = 1.0f - w1;
+    const float *p = src + plane * (int64_t)H * W + (int64_t)y0 * W + x0;
+    lv.out[l][e] = h0 * (w0 * p[0] + w1 * p[xp]) + h1 * (w0 * p[(int64_t)yp * W] + w1 * p[(int64_t)yp * W + xp]);
+}
+
+}  // namespace mdx
+
+extern "C" int mdx_bilinear_pyramid(const float *src, int64_t B, int64_t C, int H, int W, int L, const double *scales,
+                                    float *const *outs, void *stream)
+{
+    MDX_CHECK_ARG(src && scales && outs, "mdx_bilinear_pyramid: NULL pointer");
+    MDX_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0, "mdx_bilinear_pyramid: bad shape [%lld,%lld,%d,%d]", (long long)B, (long long)C, H, W);
+    MDX_CHECK_ARG(L >= 1 && L <= 8, "mdx_bilinear_pyramid: %d levels, 1..8 supported", L);
+    mdx::PyramidLevels lv;
+    lv.first[0] = 0;
+    for (int l = 0; l < 8; ++l) {
+        lv.out[l] = nullptr;
+        lv.h[l] = lv.w[l] = 0;
+        lv.rh[l] = lv.rw[l] = 1.0f;
+        if (l < L) {
+            MDX_CHECK_ARG(scales[l] > 0.0 && outs[l], "mdx_bilinear_pyramid: level %d: scale %g or NULL output", l, scales[l]);
+            lv.out[l] = outs[l];
+            lv.h[l] = (int)floor((double)H * scales[l]);
+            lv.w[l] = (int)floor((double)W * scales[l]);
+            MDX_CHECK_ARG(lv.h[l] > 0 && lv.w[l] > 0, "mdx_bilinear_pyramid: level %d is empty", l);
+            lv.rh[l] = lv.rw[l] = (float)(1.0 / scales[l]);
+        }
+        lv.first[l + 1] = lv.first[l] + (l < L ? B * C * (int64_t)lv.h[l] * lv.w[l] : 0);
+    }
+    hipLaunchKernelGGL(mdx::bilinear_pyramid_kernel, dim3((unsigned)ceil_div(lv.first[L], (int64_t)256)), dim3(256), 0, (hipStream_t)stream,
+                       src, B * C, H, W, lv, L);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}

@@ -174,8 +174,11 @@ def extract_ss(net, input):
 
 def extract_ms(net, input, ms, msp):
     """One image, several scales -> device vector ``[D]`` (imageretrievalnet.py:309-324)."""
-    pyramid = [input if s == 1 else F.interpolate(input, scale_factor=s, mode="bilinear", align_corners=False)
-               for s in ms]
+    if input.is_cuda and input.dtype == torch.float32 and len(ms) <= 8:
+        pyramid = ops.bilinear_pyramid(input.contiguous(), [float(s) for s in ms])     # all levels in one launch
+    else:
+        pyramid = [input if s == 1 else F.interpolate(input, scale_factor=s, mode="bilinear", align_corners=False)
+                   for s in ms]
     spec = net.fusable_tail() if hasattr(net, "fusable_tail") and os.environ.get("MDIR_AMD_FUSED_TAIL", "1") != "0" else None
     if spec is not None and 2 <= len(pyramid) <= 8:    # the whole tail in two launches, bit-identical to the route below
         feats = parallel_map(lambda x: net.features(x).contiguous(), pyramid)

@@ -194,6 +194,29 @@ def u8_to_chw(images, mean, std):
     return out
 
 
+def bilinear_pyramid(x, scales):
+    """``[F.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False) for s in scales]`` for an fp32
+    ``[B,C,H,W]`` device tensor, all levels in ONE launch (``mdx_bilinear_pyramid``); a scale of exactly 1 returns ``x``."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise ValueError("bilinear_pyramid expects a contiguous fp32 [B,C,H,W] CUDA/ROCm tensor (no CPU fallback)")
+    import math
+    b, c, h, w = x.shape
+    todo = [(i, float(s)) for i, s in enumerate(scales) if float(s) != 1.0]
+    out = [x] * len(scales)
+    if not todo:
+        return out
+    if len(todo) > 8:
+        raise ValueError("at most 8 scaled levels")
+    sc = (ctypes.c_double * len(todo))(*[s for _, s in todo])
+    ptrs = (ctypes.c_void_p * len(todo))()
+    for k, (i, s) in enumerate(todo):
+        out[i] = torch.empty((b, c, int(math.floor(h * s)), int(math.floor(w * s))), dtype=torch.float32, device=x.device)
+        ptrs[k] = out[i].data_ptr()
+    with _on(x):
+        check(_lib.lib().mdx_bilinear_pyramid(x.data_ptr(), b, c, h, w, len(todo), sc, ptrs, _stream()), "mdx_bilinear_pyramid")
+    return out
+
+
 def resample_u8(images, axis, bounds, taps):
     """One pass of Pillow's 8-bit resampling on uint8 ``[B,H,W,C]`` device images: along the width (``axis=1``) or the
     height (``axis=0``), with device taps ``bounds`` int32 ``[out,2]`` and ``taps`` int32 ``[out,ksize]``

@@ -106,7 +106,10 @@ class CirMultiscaleAggregation(Wrapper):
         self.scales = scales
 
     def _pyramid(self, tensor):
-        # torch >= 1.6 semantics: output size floor(in * s), coordinates scaled by s
+        # torch >= 1.6 semantics: output size floor(in * s), coordinates scaled by s; on the device all
+        # levels come from one launch of the library (mdx_bilinear_pyramid), elsewhere from F.interpolate itself
+        if tensor.is_cuda and tensor.dtype == torch.float32 and len(self.scales) <= 8:
+            return ops.bilinear_pyramid(tensor.contiguous(), [float(s) for s in self.scales])
         return [F.interpolate(tensor, scale_factor=scale, mode="bilinear", align_corners=False)
                 for scale in self.scales]
 

@@ -254,6 +254,28 @@ def test_device_thumbnail_is_pillow(ops, w, h, imsize, batch):
         np.testing.assert_array_equal(got[0], O.thumbnail_u8(arr[0], imsize))
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 768, 1024), (2, 3, 543, 724), (1, 3, 97, 61), (3, 1, 8, 5)])
+def test_bilinear_pyramid_is_f_interpolate(ops, shape):
+    """mdx_bilinear_pyramid = F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False) (wrapper.py:104-107,
+    imageretrievalnet.py:315) for the eval pyramid [1, 1/sqrt 2, 1/2] and odd scales: same output sizes, values within one
+    rounding of torch's kernel on the same device and of its CPU kernel (golden G6 / G10 go through it in test_gpu_api)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(shape[2])
+    x = rng.standard_normal(shape).astype(np.float32)
+    xd = dev(x)
+    scales = [1, 1. / np.sqrt(2), 1. / 2, 0.3, 0.9]
+    if min(shape[2:]) * 0.3 < 1:
+        scales = scales[:3]
+    got = ops.bilinear_pyramid(xd, scales)
+    assert got[0] is xd
+    for s_, g in zip(scales[1:], got[1:]):
+        want_dev = F.interpolate(xd, scale_factor=s_, mode="bilinear", align_corners=False)
+        want_cpu = F.interpolate(torch.from_numpy(x), scale_factor=s_, mode="bilinear", align_corners=False)
+        assert g.shape == want_dev.shape == want_cpu.shape
+        np.testing.assert_allclose(g.cpu().numpy(), want_dev.cpu().numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(g.cpu().numpy(), want_cpu.numpy(), rtol=0, atol=2e-6)
+
+
 def test_jpeg_pixels_is_pillow(ops):
     """The device half of the JPEG decoder (mdx_jpeg_pixels: dequantisation, islow IDCT, fancy upsampling, YCbCr -> RGB)
     on the coefficients the host half delivers = Pillow's ``Image.open(f).convert('RGB')`` (datahelpers.py:24-31), pixel
