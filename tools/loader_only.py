@@ -25,29 +25,25 @@ for name, tr in (("float chain", full), ("uint8", ToUint8HWC())):
             t2 = time.perf_counter()
             print("%-12s workers %2d pin %d: start-up %.2f s, then %.1f images/s" % (name, wk, pin, t1 - t0, (n - 2 * wk) / (t2 - t1)), flush=True)
 
-# the LANCZOS thumbnail in the workers (Pillow) against the workers decoding only + mdx_resample_u8 on the device
+# the thread-pool loader (the default of the extraction loops): Pillow does everything / only decodes (thumbnail on the device) /
+# only undoes the entropy coding (IDCT, upsampling, colour conversion and thumbnail on the device)
 if torch.cuda.is_available():
+    from mdir_amd.datasets import ThreadedLoader
+    from mdir_amd.jpeg import pixels
     from mdir_amd.resample import DeviceThumbnail
     dev = torch.device("cuda:0")
     shrink = DeviceThumbnail(1024)
-    for name, deferred in (("thumbnail in the workers", False), ("thumbnail on the device", True)):
-        for wk in (8, 16):
-            dl = torch.utils.data.DataLoader(ImagesFromList("", paths, imsize=1024, transform=ToUint8HWC(), resize_on_device=deferred),
-                                             batch_size=1, num_workers=wk, pin_memory=True)
+    for name, kw in (("Pillow decodes and shrinks", {}), ("Pillow decodes, device shrinks", {"resize_on_device": True}),
+                     ("host entropy stage, device decodes and shrinks", {"resize_on_device": True, "decode_on_device": True})):
+        for wk in (2, 4, 8, 16):
+            dl = ThreadedLoader(ImagesFromList("", paths, imsize=1024, transform=ToUint8HWC(), **kw), range(len(paths)), wk)
             n = 0
             for i, x in enumerate(dl):
                 if i == 2 * wk:
                     torch.cuda.synchronize(); t1 = time.perf_counter()
-                y = shrink(x.to(dev, non_blocking=True)) if deferred else x.to(dev, non_blocking=True)
+                y = pixels(x, dev) if hasattr(x, "coef") else x.to(dev, non_blocking=True)
+                y = shrink(y) if kw else y
                 assert tuple(y.shape) == (1, 768, 1024, 3)
                 n += 1
             torch.cuda.synchronize(); t2 = time.perf_counter()
-            print("%-26s workers %2d: %.1f images/s into device memory (1600x1200 JPEG -> 1024x768 uint8)" % (name, wk, (n - 2 * wk) / (t2 - t1)), flush=True)
-    x = torch.randint(0, 255, (1, 1200, 1600, 3), dtype=torch.uint8, device=dev)
-    shrink(x); torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(50):
-        shrink(x)
-    b.record(); torch.cuda.synchronize()
-    print("device thumbnail 1600x1200 -> 1024x768: %.1f us per image (two launches)" % (a.elapsed_time(b) / 50 * 1e3))
+            print("%-48s threads %2d: %.1f images/s into device memory (1600x1200 JPEG -> 1024x768 uint8)" % (name, wk, (n - 2 * wk) / (t2 - t1)), flush=True)
