@@ -94,6 +94,29 @@ int main(int argc, char **argv)
             }
             return 0;
         }
+        if (getenv("R4")) {         // 64 queries, no leftover tile: 2 WG/CU x 4 consumers x 2 row tiles against 1 WG/CU x 8 consumers x 4 row tiles
+            auto lc64 = [&](auto kern, int R_, int KC_, int NST, int CW_) {
+                const size_t lds = (size_t)NST * (4 + CW_ * R_) * KC_ * 1024;
+                hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                const int64_t blocks = (RT + CW_ * R_ - 1) / (CW_ * R_);
+                hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+                for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64 + 256), lds, 0, db, q, out, n, KB, 64, (unsigned long long *)nullptr);
+                hipEventRecord(a);
+                for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64 + 256), lds, 0, db, q, out, n, KB, 64, (unsigned long long *)nullptr);
+                hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
+                return ms / 10;
+            };
+            for (int rep = 0; rep < 3; ++rep)
+                printf("64 queries: 2 WG/CU x 4 cons x R2 KC2 NST3 %.4f | 1 WG/CU x 8 cons x R2 KC2 NST3 %.4f | 1 WG/CU x 8 cons x R4 KC1 NST4 %.4f | 1 WG/CU x 4 cons x R4 KC2 NST3 %.4f ms\n",
+                       lc64(scores_lc_kernel<4, 2, 2, 3, 2, false, MmaF32, 0, 4>, 2, 2, 3, 4),
+                       lc64(scores_lc_kernel<4, 2, 2, 3, 2, false, MmaF32, 0, 8>, 2, 2, 3, 8),
+                       lc64(scores_lc_kernel<4, 4, 1, 4, 2, false, MmaF32, 0, 8>, 4, 1, 4, 8),
+                       lc64(scores_lc_kernel<4, 4, 2, 3, 2, false, MmaF32, 0, 4>, 4, 2, 3, 4));
+            return 0;
+        }
         if (getenv("CW8")) {        // one workgroup per CU with 8 consumer waves sharing the query stage
             for (int rep = 0; rep < 3; ++rep)
                 printf("2 WG/CU x 4 consumers %.4f | 1 WG/CU x 8 consumers KC2 NST3 %.4f | KC1 NST6 %.4f | KC2 NST2 %.4f ms\n",
