@@ -131,8 +131,10 @@ int mdx_resample_u8(const uint8_t *src, int64_t B, int H, int W, int C, int axis
  * (cirtorch/datasets/datahelpers.py:24-31) for baseline JPEG files, with the arithmetic of libjpeg(-turbo) as Pillow
  * configures it (Huffman decoding; jidctint.c islow IDCT; jdsample.c fancy upsampling; jdcolor.c YCbCr -> RGB), bit for bit.
  *   mdx_jpeg_probe          HOST.  Geometry of the file; info->supported = 0 for what stays with the host decoder
- *                           (progressive, arithmetic, 12-bit, CMYK / RGB-coded, several scans, other sampling factors).
- *   mdx_jpeg_coefficients   HOST (no device call; thread-safe, so loader threads run it in parallel).  Entropy decoding:
+ *                           (arithmetic, 12-bit, lossless, CMYK / RGB-coded, other sampling factors).  Sequential and
+ *                           progressive Huffman files are covered.
+ *   mdx_jpeg_coefficients   HOST (no device call; thread-safe, so loader threads run it in parallel).  Entropy decoding
+ *                           of all scans (an error for a stream whose data runs out inside a scan: leave it to Pillow):
  *                           coef [nblocks][64] int16, quantised, natural order, component after component, every
  *                           component's blocks row by row over whole MCUs; quant [3][64] uint16, natural order.
  *   mdx_jpeg_pixels         DEVICE.  coef / quant as above (device copies) -> rgb uint8 [height, width, 3].

@@ -9,10 +9,11 @@
 // bit for bit as libjpeg does it: mdx_jpeg_pixels = dequantisation + IDCT (one thread per 8x8 block), then upsampling +
 // colour conversion (one thread per output pixel).
 //
-// Covered: 8-bit baseline / extended-sequential Huffman files with one interleaved scan, grey or YCbCr, luma at full
-// resolution and chroma at 1x1, 2x1 or 2x2 (4:4:4, 4:2:2, 4:2:0).  Everything else (progressive, arithmetic coding,
-// 12-bit, CMYK / YCCK, RGB-coded, several scans, other sampling factors, images narrower than 16 pixels) is reported as
-// unsupported by mdx_jpeg_probe and stays with the host decoder.
+// Covered: 8-bit Huffman-coded files -- baseline / extended sequential (one interleaved scan or one scan per component)
+// and progressive (spectral selection + successive approximation, jdphuff.c) -- grey or YCbCr, luma at full resolution and
+// chroma at 1x1, 2x1 or 2x2 (4:4:4, 4:2:2, 4:2:0).  Everything else (arithmetic coding, 12-bit, lossless, CMYK / YCCK,
+// RGB-coded, other sampling factors, images narrower than 16 pixels) is reported as unsupported by mdx_jpeg_probe and stays
+// with the host decoder.
 #include <stdlib.h>
 
 #include "mdx_common.h"
@@ -55,18 +56,55 @@ static bool build_table(HuffTable &t)
     return true;
 }
 
+static inline int be16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
+
 struct JpegHeader {
     int width = 0, height = 0, ncomp = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, restart = 0;
     int cid[3], h[3], v[3], tq[3], td[3], ta[3];
     uint16_t quant[4][64];          // natural order
     bool qdef[4] = {false, false, false, false};
     HuffTable dc[4], ac[4];
-    int64_t scan_data = -1;         // offset of the entropy-coded segment
+    int64_t scan_data = -1;         // offset of the entropy-coded segment of the first scan
+    int64_t first_sos = -1;         // offset of the first SOS marker's length field
+    bool progressive = false;
     bool supported = false;
     const char *why = "no start of frame";
 };
 
-static inline int be16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
+// DQT / DHT / DRI segment (they may also come between the scans of a file)
+static bool table_segment(JpegHeader &hd, int m, const uint8_t *s, int n)
+{
+    if (m == 0xDB) {                        // DQT
+        int o = 0;
+        while (o < n) {
+            const int pq = s[o] >> 4, tq = s[o] & 15;
+            ++o;
+            if (tq > 3 || o + (pq ? 128 : 64) > n) { hd.why = "bad quantisation table"; return false; }
+            for (int i = 0; i < 64; ++i) hd.quant[tq][ZIGZAG[i]] = pq ? (uint16_t)be16(s + o + 2 * i) : s[o + i];
+            o += pq ? 128 : 64;
+            hd.qdef[tq] = true;
+        }
+    } else if (m == 0xC4) {                 // DHT
+        int o = 0;
+        while (o + 17 <= n) {
+            const int tc = s[o] >> 4, th = s[o] & 15;
+            if (tc > 1 || th > 3) { hd.why = "bad Huffman table id"; return false; }
+            HuffTable &t = tc ? hd.ac[th] : hd.dc[th];
+            int total = 0;
+            t.bits[0] = 0;
+            for (int i = 1; i <= 16; ++i) { t.bits[i] = s[o + i]; total += t.bits[i]; }
+            o += 17;
+            if (total > 256 || o + total > n) { hd.why = "bad Huffman table"; return false; }
+            for (int i = 0; i < total; ++i) t.vals[i] = s[o + i];
+            o += total;
+            if (!build_table(t)) { hd.why = "bad Huffman code lengths"; return false; }
+            t.defined = true;
+        }
+    } else if (m == 0xDD) {                 // DRI
+        if (n >= 2) hd.restart = be16(s);
+    }
+    return true;
+}
 
 // headers up to the first scan
 static bool parse_header(const uint8_t *d, int64_t size, JpegHeader &hd)
@@ -87,39 +125,12 @@ static bool parse_header(const uint8_t *d, int64_t size, JpegHeader &hd)
         if (len < 2 || p + len > size) { hd.why = "truncated segment"; return false; }
         const uint8_t *s = d + p + 2;
         const int n = len - 2;
-        if (m == 0xDB) {                    // DQT
-            int o = 0;
-            while (o < n) {
-                const int pq = s[o] >> 4, tq = s[o] & 15;
-                ++o;
-                if (tq > 3 || o + (pq ? 128 : 64) > n) { hd.why = "bad quantisation table"; return false; }
-                for (int i = 0; i < 64; ++i) {
-                    hd.quant[tq][ZIGZAG[i]] = pq ? (uint16_t)be16(s + o + 2 * i) : s[o + i];
-                }
-                o += pq ? 128 : 64;
-                hd.qdef[tq] = true;
-            }
-        } else if (m == 0xC4) {             // DHT
-            int o = 0;
-            while (o + 17 <= n) {
-                const int tc = s[o] >> 4, th = s[o] & 15;
-                if (tc > 1 || th > 3) { hd.why = "bad Huffman table id"; return false; }
-                HuffTable &t = tc ? hd.ac[th] : hd.dc[th];
-                int total = 0;
-                t.bits[0] = 0;
-                for (int i = 1; i <= 16; ++i) { t.bits[i] = s[o + i]; total += t.bits[i]; }
-                o += 17;
-                if (total > 256 || o + total > n) { hd.why = "bad Huffman table"; return false; }
-                for (int i = 0; i < total; ++i) t.vals[i] = s[o + i];
-                o += total;
-                if (!build_table(t)) { hd.why = "bad Huffman code lengths"; return false; }
-                t.defined = true;
-            }
-        } else if (m == 0xDD) {             // DRI
-            if (n >= 2) hd.restart = be16(s);
+        if (m == 0xDB || m == 0xC4 || m == 0xDD) {
+            if (!table_segment(hd, m, s, n)) return false;
         } else if (m == 0xEE) {             // APP14 Adobe
             if (n >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
-        } else if (m == 0xC0 || m == 0xC1) {    // SOF0 / SOF1: sequential Huffman
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {    // SOF0 / SOF1: sequential Huffman; SOF2: progressive Huffman
+            hd.progressive = m == 0xC2;
             if (n < 6) { hd.why = "bad frame header"; return false; }
             if (s[0] != 8) { hd.why = "not 8 bits per sample"; return false; }
             hd.height = be16(s + 1);
@@ -135,23 +146,12 @@ static bool parse_header(const uint8_t *d, int64_t size, JpegHeader &hd)
                 if (hd.tq[c] > 3) { hd.why = "bad quantisation table id"; return false; }
             }
             have_frame = true;
-        } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            hd.why = "progressive, lossless or arithmetic-coded";
+        } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            hd.why = "lossless, hierarchical or arithmetic-coded";
             return false;
-        } else if (m == 0xDA) {             // SOS
+        } else if (m == 0xDA) {             // SOS: the scans are walked by decode_scans
             if (!have_frame) { hd.why = "scan before frame"; return false; }
-            if (n < 1 + 2 * hd.ncomp + 3 || s[0] != hd.ncomp) { hd.why = "several scans (non-interleaved)"; return false; }
-            for (int c = 0; c < hd.ncomp; ++c) {
-                if (s[1 + 2 * c] != hd.cid[c]) { hd.why = "scan component order"; return false; }
-                hd.td[c] = s[2 + 2 * c] >> 4;
-                hd.ta[c] = s[2 + 2 * c] & 15;
-                if (hd.td[c] > 3 || hd.ta[c] > 3 || !hd.dc[hd.td[c]].defined || !hd.ac[hd.ta[c]].defined || !hd.qdef[hd.tq[c]]) {
-                    hd.why = "missing table";
-                    return false;
-                }
-            }
-            const uint8_t *t = s + 1 + 2 * hd.ncomp;
-            if (t[0] != 0 || t[1] != 63 || t[2] != 0) { hd.why = "not a full sequential scan"; return false; }
+            hd.first_sos = p;
             hd.scan_data = p + len;
             break;
         }
@@ -187,7 +187,11 @@ struct BitReader {
     int64_t p, size;
     uint64_t acc = 0;
     int nbits = 0;
+    int pad = 0;            // zero bytes appended after the data ran out (a marker or the end of the file)
     bool marker = false;
+
+    // did the decoder consume bits that were not in the file?  (truncated or corrupt data: such files go to the host decoder)
+    inline bool overran() const { return nbits < 8 * pad; }
 
     inline void fill()
     {
@@ -197,10 +201,12 @@ struct BitReader {
                 byte = d[p];
                 if (byte == 0xFF) {
                     if (p + 1 < size && d[p + 1] == 0) p += 2;
-                    else { marker = true; byte = 0; }
+                    else { marker = true; byte = 0; ++pad; }
                 } else {
                     ++p;
                 }
+            } else {
+                ++pad;
             }
             acc |= (uint64_t)byte << (56 - nbits);
             nbits += 8;
@@ -218,8 +224,10 @@ struct BitReader {
     // RSTn: drop the rest of the byte, step over the marker
     bool restart()
     {
+        if (overran()) return false;
         acc = 0;
         nbits = 0;
+        pad = 0;
         if (marker) {
             if (p + 1 < size && d[p] == 0xFF && d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7) { p += 2; marker = false; return true; }
             return false;
@@ -250,53 +258,198 @@ static inline int huff_decode(BitReader &br, const HuffTable &t)
 
 static inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
-static bool decode_scan(const uint8_t *d, int64_t size, const JpegHeader &hd, const mdx_jpeg_info &info, int16_t *coef)
+// one block of a sequential scan (all 64 coefficients)
+static inline bool block_sequential(BitReader &br, const HuffTable &dct, const HuffTable &act, int &pred, int16_t *blk)
 {
-    BitReader br{d, hd.scan_data, size};
-    int pred[3] = {0, 0, 0};
-    const int64_t nmcu = (int64_t)hd.mcux * hd.mcuy;
-    int until_restart = hd.restart;
-    for (int64_t m = 0; m < nmcu; ++m) {
-        if (hd.restart && until_restart == 0) {
-            if (!br.restart()) return false;
-            pred[0] = pred[1] = pred[2] = 0;
-            until_restart = hd.restart;
+    int s = huff_decode(br, dct);
+    if (s < 0 || s > 15) return false;
+    if (s) {
+        br.fill();
+        pred += extend(br.get(s), s);
+    }
+    blk[0] = (int16_t)pred;
+    for (int k = 1; k < 64;) {
+        const int rs = huff_decode(br, act);
+        if (rs < 0) return false;
+        const int r = rs >> 4;
+        s = rs & 15;
+        if (s == 0) {
+            if (r != 15) break;
+            k += 16;
+            continue;
         }
-        const int my = (int)(m / hd.mcux), mx = (int)(m % hd.mcux);
-        for (int c = 0; c < hd.ncomp; ++c) {
-            const HuffTable &dct = hd.dc[hd.td[c]], &act = hd.ac[hd.ta[c]];
-            for (int by = 0; by < hd.v[c]; ++by)
-                for (int bx = 0; bx < hd.h[c]; ++bx) {
-                    int16_t *blk = coef + (info.block_offset[c] + (int64_t)(my * hd.v[c] + by) * info.blocks_w[c] + (mx * hd.h[c] + bx)) * 64;
-                    memset(blk, 0, 64 * sizeof(int16_t));
-                    int s = huff_decode(br, dct);
-                    if (s < 0 || s > 15) return false;
-                    if (s) {
-                        br.fill();
-                        pred[c] += extend(br.get(s), s);
-                    }
-                    blk[0] = (int16_t)pred[c];
-                    for (int k = 1; k < 64;) {
-                        const int rs = huff_decode(br, act);
-                        if (rs < 0) return false;
-                        const int r = rs >> 4;
-                        s = rs & 15;
-                        if (s == 0) {
-                            if (r != 15) break;
-                            k += 16;
-                            continue;
-                        }
-                        k += r;
-                        if (k > 63) return false;
-                        br.fill();
-                        blk[ZIGZAG[k]] = (int16_t)extend(br.get(s), s);
-                        ++k;
-                    }
-                }
-        }
-        if (hd.restart) --until_restart;
+        k += r;
+        if (k > 63) return false;
+        br.fill();
+        blk[ZIGZAG[k]] = (int16_t)extend(br.get(s), s);
+        ++k;
     }
     return true;
+}
+
+// one block of a progressive AC scan (jdphuff.c decode_mcu_AC_first / decode_mcu_AC_refine)
+static inline bool block_ac_first(BitReader &br, const HuffTable &act, int ss, int se, int al, int &eobrun, int16_t *blk)
+{
+    if (eobrun > 0) { --eobrun; return true; }
+    for (int k = ss; k <= se; ++k) {
+        const int rs = huff_decode(br, act);
+        if (rs < 0) return false;
+        const int r = rs >> 4, s = rs & 15;
+        if (s) {
+            k += r;
+            if (k > 63) return false;
+            br.fill();
+            blk[ZIGZAG[k]] = (int16_t)(extend(br.get(s), s) * (1 << al));
+        } else if (r == 15) {
+            k += 15;
+        } else {
+            eobrun = 1 << r;
+            if (r) { br.fill(); eobrun += br.get(r); }
+            --eobrun;
+            break;
+        }
+    }
+    return true;
+}
+
+static inline bool block_ac_refine(BitReader &br, const HuffTable &act, int ss, int se, int al, int &eobrun, int16_t *blk)
+{
+    const int p1 = 1 << al, m1 = -(1 << al);
+    int k = ss;
+    if (eobrun == 0) {
+        for (; k <= se; ++k) {
+            const int rs = huff_decode(br, act);
+            if (rs < 0) return false;
+            int r = rs >> 4, s = rs & 15;
+            if (s) {
+                br.fill();
+                s = br.get(1) ? p1 : m1;
+            } else if (r != 15) {
+                eobrun = 1 << r;
+                if (r) { br.fill(); eobrun += br.get(r); }
+                break;
+            }
+            do {            // past the coefficients that are already non-zero (each takes a correction bit) and r zero ones
+                int16_t *c = blk + ZIGZAG[k];
+                if (*c != 0) {
+                    br.fill();
+                    if (br.get(1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                } else if (--r < 0) {
+                    break;
+                }
+                ++k;
+            } while (k <= se);
+            if (s) {
+                if (k > 63) return false;
+                blk[ZIGZAG[k]] = (int16_t)s;
+            }
+        }
+    }
+    if (eobrun > 0) {
+        for (; k <= se; ++k) {
+            int16_t *c = blk + ZIGZAG[k];
+            if (*c != 0) {
+                br.fill();
+                if (br.get(1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+            }
+        }
+        --eobrun;
+    }
+    return true;
+}
+
+// all scans of the file: sequential (one interleaved scan, or one scan per component) or progressive
+static bool decode_scans(const uint8_t *d, int64_t size, JpegHeader &hd, const mdx_jpeg_info &info, int16_t *coef)
+{
+    memset(coef, 0, (size_t)info.nblocks * 64 * sizeof(int16_t));
+    int64_t pos = hd.first_sos;                 // at the length field of an SOS segment
+    for (int scans = 0; scans < 1000; ++scans) {
+        if (pos + 2 > size) return false;
+        const int len = be16(d + pos);
+        if (len < 6 || pos + len > size) return false;
+        const uint8_t *s = d + pos + 2;
+        const int ns = s[0];
+        if (ns < 1 || ns > hd.ncomp || len != 6 + 2 * ns) return false;
+        int comp[3], td[3], ta[3];
+        for (int i = 0; i < ns; ++i) {
+            int c = 0;
+            while (c < hd.ncomp && hd.cid[c] != s[1 + 2 * i]) ++c;
+            if (c == hd.ncomp || (i && c <= comp[i - 1])) return false;
+            comp[i] = c;
+            td[i] = s[2 + 2 * i] >> 4;
+            ta[i] = s[2 + 2 * i] & 15;
+            if (td[i] > 3 || ta[i] > 3) return false;
+        }
+        const int ss = s[1 + 2 * ns], se = s[2 + 2 * ns], ah = s[3 + 2 * ns] >> 4, al = s[3 + 2 * ns] & 15;
+        if (!hd.progressive) {
+            if (ss != 0 || se != 63 || ah != 0 || al != 0) return false;
+        } else {
+            if (ss > se || se > 63 || al > 13 || (ss == 0 && se != 0) || (ss > 0 && ns != 1)) return false;
+        }
+        for (int i = 0; i < ns; ++i) {
+            if ((ss == 0 && ah == 0 && !hd.dc[td[i]].defined) || (se > 0 && !hd.ac[ta[i]].defined)) return false;
+        }
+        BitReader br{d, pos + len, size};
+        int pred[3] = {0, 0, 0}, eobrun = 0, until_restart = hd.restart;
+        // a scan of one component walks that component's own blocks (not padded to whole MCUs); several components are interleaved
+        const int c0 = comp[0];
+        const int cw = (hd.width * hd.h[c0] + hd.hmax - 1) / hd.hmax, ch = (hd.height * hd.v[c0] + hd.vmax - 1) / hd.vmax;
+        const int64_t units = ns == 1 ? (int64_t)((cw + 7) / 8) * ((ch + 7) / 8) : (int64_t)hd.mcux * hd.mcuy;
+        const int row_units = ns == 1 ? (cw + 7) / 8 : hd.mcux;
+        for (int64_t u = 0; u < units; ++u) {
+            if (hd.restart && until_restart == 0) {
+                if (!br.restart()) return false;
+                pred[0] = pred[1] = pred[2] = 0;
+                eobrun = 0;
+                until_restart = hd.restart;
+            }
+            const int uy = (int)(u / row_units), ux = (int)(u % row_units);
+            for (int i = 0; i < ns; ++i) {
+                const int c = comp[i];
+                const int nv = ns == 1 ? 1 : hd.v[c], nh = ns == 1 ? 1 : hd.h[c];
+                for (int by = 0; by < nv; ++by)
+                    for (int bx = 0; bx < nh; ++bx) {
+                        int16_t *blk = coef + (info.block_offset[c] + (int64_t)(uy * nv + by) * info.blocks_w[c] + (ux * nh + bx)) * 64;
+                        bool ok = true;
+                        if (!hd.progressive) {
+                            ok = block_sequential(br, hd.dc[td[i]], hd.ac[ta[i]], pred[c], blk);
+                        } else if (ss == 0) {
+                            if (ah == 0) {                  // DC, first pass
+                                const int t = huff_decode(br, hd.dc[td[i]]);
+                                if (t < 0 || t > 15) return false;
+                                if (t) { br.fill(); pred[c] += extend(br.get(t), t); }
+                                blk[0] = (int16_t)(pred[c] * (1 << al));
+                            } else {                        // DC, one more bit
+                                br.fill();
+                                if (br.get(1)) blk[0] = (int16_t)(blk[0] | (1 << al));
+                            }
+                        } else if (ah == 0) {
+                            ok = block_ac_first(br, hd.ac[ta[i]], ss, se, al, eobrun, blk);
+                        } else {
+                            ok = block_ac_refine(br, hd.ac[ta[i]], ss, se, al, eobrun, blk);
+                        }
+                        if (!ok) return false;
+                    }
+            }
+            if (hd.restart) --until_restart;
+        }
+        if (br.overran()) return false;
+        // on to the next marker that is not a restart marker; tables may be redefined between scans
+        int64_t q = br.p;
+        for (;;) {
+            while (q + 1 < size && !(d[q] == 0xFF && d[q + 1] != 0x00 && d[q + 1] != 0xFF && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7))) ++q;
+            if (q + 1 >= size) return true;                 // no end-of-image marker: what was decoded stands (as libjpeg, with a warning)
+            const int m = d[q + 1];
+            if (m == 0xD9) return true;
+            if (q + 4 > size) return true;
+            const int sl = be16(d + q + 2);
+            if (sl < 2 || q + 2 + sl > size) return false;
+            if (m == 0xDA) { pos = q + 2; break; }
+            if (!table_segment(hd, m, d + q + 4, sl - 2)) return false;
+            q += 2 + sl;
+        }
+    }
+    return false;
 }
 
 static void fill_info(const JpegHeader &hd, mdx_jpeg_info *info)
@@ -529,7 +682,7 @@ int mdx_jpeg_coefficients(const uint8_t *file, int64_t size, int16_t *coef, int6
                   (long long)info.nblocks);
     for (int c = 0; c < 3; ++c)
         for (int i = 0; i < 64; ++i) quant[c * 64 + i] = c < hd.ncomp ? hd.quant[hd.tq[c]][i] : 0;
-    MDX_CHECK_ARG(decode_scan(file, size, hd, info, coef), "mdx_jpeg_coefficients: corrupt entropy-coded data");
+    MDX_CHECK_ARG(decode_scans(file, size, hd, info, coef), "mdx_jpeg_coefficients: corrupt or unsupported entropy-coded data");
     return MDX_OK;
 }
 

@@ -279,7 +279,8 @@ def test_bilinear_pyramid_is_f_interpolate(ops, shape):
 def test_jpeg_pixels_is_pillow(ops):
     """The device half of the JPEG decoder (mdx_jpeg_pixels: dequantisation, islow IDCT, fancy upsampling, YCbCr -> RGB)
     on the coefficients the host half delivers = Pillow's ``Image.open(f).convert('RGB')`` (datahelpers.py:24-31), pixel
-    for pixel: 4:4:4 / 4:2:2 / 4:2:0 / grey, odd sizes, qualities 1..100, saturated pictures, restart markers, a crop box."""
+    for pixel: 4:4:4 / 4:2:2 / 4:2:0 / grey, odd sizes, qualities 1..100, saturated pictures, restart markers, progressive
+    files, a crop box."""
     import io
     from PIL import Image
     from mdir_amd import jpeg
@@ -299,8 +300,8 @@ def test_jpeg_pixels_is_pillow(ops):
     want = np.asarray(Image.open(io.BytesIO(cases[2][1])).convert("RGB").crop((3, 5, 100, 70)))
     np.testing.assert_array_equal(jpeg.pixels(item, torch.device(DEV))[0].cpu().numpy(), want)
     buf = io.BytesIO()
-    picture(64, 64, "noise").save(buf, format="JPEG", progressive=True)
-    assert jpeg.entropy_decode(buf.getvalue()) is None
+    picture(64, 64, "noise").convert("CMYK").save(buf, format="JPEG")
+    assert jpeg.entropy_decode(buf.getvalue()) is None and jpeg.entropy_decode(cases[12][1][:5000]) is None
 
 
 def test_u8_to_chw_matches_host_chain(ops):

@@ -712,8 +712,8 @@ def test_threaded_loader_order_errors_and_missing_images(tmp_path):
 
 def test_loader_hands_jpeg_files_over_as_coefficients(tmp_path):
     """``decode_on_device``: a baseline JPEG leaves the loader entropy-decoded (pixels = Pillow's once the device half,
-    here the oracle, has run: crop box included); PNG and progressive files, boxes that stick out and thumbnails Pillow makes
-    in several steps take the usual route and arrive as pixels."""
+    here the oracle, has run: crop box included; a progressive file too); PNG files, boxes that stick out and thumbnails Pillow
+    makes in several steps take the usual route and arrive as pixels."""
     from mdir_amd.datasets import ImagesFromList, ToUint8HWC
     from mdir_amd.jpeg import JpegCoefficients
     rng = np.random.default_rng(6)
@@ -729,10 +729,10 @@ def test_loader_hands_jpeg_files_over_as_coefficients(tmp_path):
     ds = ImagesFromList(str(tmp_path), names, imsize=256, bbxs=boxes, transform=ToUint8HWC(), resize_on_device=True, decode_on_device=True)
     plain = ImagesFromList(str(tmp_path), names, imsize=256, bbxs=boxes, transform=ToUint8HWC(), resize_on_device=True)
     kinds = [isinstance(ds[i], JpegCoefficients) for i in range(6)]
-    assert kinds == [True, True, False, False, False, False]           # big.jpg shrinks 9x: Pillow reduces first, from its own decode
-    for i in (0, 1):
+    assert kinds == [True, True, False, True, False, False]            # big.jpg shrinks 9x: Pillow reduces first, from its own decode
+    for i in (0, 1, 3):
         np.testing.assert_array_equal(fake_ops.jpeg_pixels(ds[i], "cpu")[0].numpy(), plain[i].numpy())
-    for i in (2, 3, 4, 5):
+    for i in (2, 4, 5):
         assert torch.equal(ds[i], plain[i])
     assert isinstance(ImagesFromList(str(tmp_path), names, imsize=None, transform=ToUint8HWC(), decode_on_device=True)[0], JpegCoefficients)
     assert not isinstance(ImagesFromList(str(tmp_path), names, imsize=256, transform=ToUint8HWC(), decode_on_device=True)[0], JpegCoefficients)

@@ -314,6 +314,14 @@ def _jpeg_cases():
     buf = io.BytesIO()
     picture(200, 120, "photo").convert("L").save(buf, format="JPEG", quality=50)
     out.append(("grey", buf.getvalue()))
+    for w, h, kind, q, sub in [(97, 61, "photo", 92, 2), (256, 160, "photo", 50, 1), (33, 47, "noise", 75, 0), (97, 61, "sat", 5, 2),
+                               (131, 77, "grad", 100, 2)]:
+        buf = io.BytesIO()
+        picture(w, h, kind).save(buf, format="JPEG", quality=q, subsampling=sub, progressive=True)
+        out.append(("progressive %dx%d %s q%d sub%d" % (w, h, kind, q, sub), buf.getvalue()))
+    buf = io.BytesIO()
+    picture(200, 120, "grad").convert("L").save(buf, format="JPEG", quality=70, progressive=True)
+    out.append(("progressive grey", buf.getvalue()))
     return out, picture
 
 
@@ -321,7 +329,8 @@ def test_jpeg_restatement_is_pillow():
     """libjpeg's decompression restated (host: the library's entropy decoder, the serial half of the product's JPEG path;
     oracle: dequantisation, islow IDCT, fancy upsampling, YCbCr -> RGB) equals Pillow's decode of the same file -- Pillow is
     what the reference calls (datahelpers.py:24-31) -- pixel for pixel: 4:4:4 / 4:2:2 / 4:2:0 / grey, odd sizes, qualities
-    1..100, saturated pictures, optimised Huffman tables, restart markers; progressive, CMYK and non-JPEG files are declined."""
+    1..100, saturated pictures, optimised Huffman tables, restart markers, progressive files (spectral selection + successive
+    approximation); CMYK, non-JPEG, truncated and corrupt files are declined (they stay with Pillow)."""
     import ctypes
     import io
     from PIL import Image
@@ -345,11 +354,26 @@ def test_jpeg_restatement_is_pillow():
         got = decode(data)
         assert got is not None, name
         np.testing.assert_array_equal(got, want, err_msg=name)
-    for kw, mode in (({"progressive": True}, "RGB"), ({}, "CMYK")):
-        buf = io.BytesIO()
-        picture(64, 64, "noise").convert(mode).save(buf, format="JPEG", **kw)
-        assert decode(buf.getvalue()) is None
+    buf = io.BytesIO()
+    picture(64, 64, "noise").convert("CMYK").save(buf, format="JPEG")
+    assert decode(buf.getvalue()) is None
     buf = io.BytesIO()
     picture(64, 64, "noise").save(buf, format="PNG")
     assert decode(buf.getvalue()) is None
-    assert decode(cases[0][1][:300] + b"\x00" * 50) is None or True        # a truncated stream must not crash
+
+    def declined(data):
+        b = np.frombuffer(data, dtype=np.uint8)
+        info = _lib.JpegInfo()
+        lib.mdx_jpeg_probe(b.ctypes.data, b.size, ctypes.byref(info))
+        if not info.supported:
+            return True
+        coef, quant = np.empty((info.nblocks, 64), dtype=np.int16), np.empty((3, 64), dtype=np.uint16)
+        return lib.mdx_jpeg_coefficients(b.ctypes.data, b.size, coef.ctypes.data, info.nblocks, quant.ctypes.data) != 0
+
+    whole = cases[12][1]                                                  # 640x480
+    for cut in (len(whole) // 2, len(whole) - 3, 700):
+        assert declined(whole[:cut])                                      # data runs out inside the scan
+    broken = bytearray(whole)
+    for i in range(1000, len(broken), 997):
+        broken[i] ^= 0x5A
+    declined(bytes(broken))                                               # anything but a crash
