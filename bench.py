@@ -395,6 +395,22 @@ def main():
                                           "queries_per_s_with_the_fp32_ranking": round(NQ / ((t_h + extra.get("rank_ms_per_step", 0.0)) * 1e-3), 1),
                                           "contract": "scores within ~1e-3 of fp32 (input rounding), tests/test_gpu_f16.py"}
             half.close()
+            # configs[4]'s own shape: 247tokyo1k, query == database (1 125 x 1 125), VGG16 descriptors (512-d) stored as fp16
+            g4 = torch.Generator(device=device)
+            g4.manual_seed(4)
+            tk = torch.randn((1125, 512), generator=g4, device=device)
+            tk /= tk.norm(dim=1, keepdim=True)
+            tix = ops.DescriptorIndex(tk, "ND", storage="f16")
+            tsc = torch.empty((1125, 1125), dtype=torch.float32, device=device)
+            trk = torch.empty((1125, 1125), dtype=torch.int64, device=device)
+            tws = torch.empty(ops.rank_workspace_bytes(1125, 1125), dtype=torch.uint8, device=device)
+            tq = tk.t().contiguous()
+            t_s, t_r = timed(lambda: tix.scores(tq, "DN", out=tsc)), timed(lambda: ops.rank_full(tsc, out=trk, workspace=tws))
+            assert bool((trk[:, 0] == torch.arange(1125, device=device)).all())          # every image retrieves itself first
+            sec["configs4_247tokyo1k_shape"] = {"workload": "N=Q=1125 D=512, fp16 shard, query == database, similarity + exact full ranking",
+                                                "scores_us": round(1e3 * t_s, 1), "rank_us": round(1e3 * t_r, 1),
+                                                "queries_per_s": round(1125 / ((t_s + t_r) * 1e-3), 1), "bound": "launch latency"}
+            tix.close()
             extra["secondary_configs"] = sec
         except Exception as exc:
             extra["secondary_configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
@@ -412,6 +428,9 @@ def main():
                 ex = measure_list("resnet101", workers=8, short=4, mid=max(8, args.extract_images // 2), long=max(16, args.extract_images))
                 ex["resident_single_shape"] = measure(types.SimpleNamespace(arch="resnet101", images=24, channels_last=False,
                                                                             miopen_find=False, batch=4))
+                if world == 1:      # configs[4]'s network: VGG16-GeM, 3 scales + learned whitening, one resident 1024x768 shape
+                    vg = measure(types.SimpleNamespace(arch="vgg16", images=24, channels_last=False, miopen_find=False, batch=4))
+                    ex["vgg16_resident_single_shape_descriptors_per_s"] = vg["value"]
         except Exception as exc:        # an untimed side leg must not cost the ranking result (or hang the other ranks)
             err = "%s: %s" % (type(exc).__name__, exc)
         agg = torch.tensor([ex["value"] if ex else 0.0, 1.0 if ex else 0.0], dtype=torch.float64,

@@ -582,6 +582,164 @@ static int64_t carve(RankWs *ws, char *base, int64_t n, int64_t nq)
     return off;
 }
 
+// ---------------------------------------------------------------------------
+// Rows of at most 8192 scores (rOxford5k alone: 4 993; 247tokyo1k: 1 125; the candidate lists of mdx_topk): the whole
+// ranking of a query by ONE workgroup in LDS -- load, stable LSD radix over the key bytes that differ, write -- one launch
+// instead of twelve.  Needs the ordered ds_add_rtn (atomic_rank_ok); the tiled passes above serve otherwise.
+// ---------------------------------------------------------------------------
+constexpr int LS_THREADS = 512, LS_WAVES = LS_THREADS / 64, LS_MAX_ITEMS = 16, LS_CAP = LS_THREADS * LS_MAX_ITEMS;
+
+struct LsShared {
+    uint32_t key[LS_CAP];
+    uint32_t val[LS_CAP];
+    uint32_t cnt[LS_WAVES][RADIX];
+    uint32_t tot[RADIX];
+    uint32_t diff;
+};
+
+// Stable sort of m <= 512 * ITEMS (key, val) pairs held in registers in (wave, round, lane) order -- element
+// i = wave * 64 * ITEMS + round * 64 + lane -- by key; equal keys keep their order.  LSD radix, 8 bits per pass,
+// only over the bytes in which the keys differ; a pass ranks with ds_add_rtn on per-wave digit counters (ordered:
+// atomic_rank_ok), puts the elements in place in LDS and reloads them.  Three barriers per pass: a wave zeroes and
+// reads only ITS OWN counters outside the scan (LDS operations of one wave stay in order), and the scan over the
+// waves and over the digits is one wave's work.  The sorted pairs are left in sh.key / sh.val[0..m).
+template <int ITEMS>
+__device__ __forceinline__ void lds_radix_sort(uint32_t (&key)[ITEMS], uint32_t (&val)[ITEMS], int m, LsShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = wave * 64 * ITEMS + lane;
+    uint32_t pos[ITEMS];
+    uint32_t diff = 0;
+    if (tid == 0) {
+        sh.diff = 0;
+        sh.tot[0] = key[0];
+    }
+    uint32_t *mycnt = sh.cnt[wave];
+#pragma unroll
+    for (int e = 0; e < RADIX / 64; ++e) mycnt[e * 64 + lane] = 0;
+    __syncthreads();
+    const uint32_t first = sh.tot[0];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r)
+        if (sub + r * 64 < m) diff |= key[r] ^ first;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    if (lane == 0 && diff) atomicOr(&sh.diff, diff);
+    __syncthreads();
+    diff = sh.diff;
+    bool staged = false;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 8 * pass;
+        if (((diff >> shift) & 255u) == 0) continue;        // this byte is the same in every key
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            pos[r] = 0;
+            if (sub + r * 64 < m)
+                pos[r] = __hip_atomic_fetch_add(&mycnt[(key[r] >> shift) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane l owns digits l, l + 64, l + 128, l + 192 (consecutive lanes = consecutive banks): per digit the
+            // waves' counts become offsets, then the digit totals are scanned in digit order
+            uint32_t t[4], c[4][LS_WAVES];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int w = 0; w < LS_WAVES; ++w) c[k][w] = sh.cnt[w][64 * k + lane];      // all 32 reads in flight
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int w = 0; w < LS_WAVES; ++w) {
+                    sh.cnt[w][64 * k + lane] = run;
+                    run += c[k][w];
+                }
+                t[k] = run;
+            }
+            uint32_t inc[4] = {t[0], t[1], t[2], t[3]};
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t v = __shfl_up(inc[k], o, 64);
+                    if (lane >= o) inc[k] += v;
+                }
+            uint32_t before = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sh.tot[64 * k + lane] = before + inc[k] - t[k];
+                before += __shfl(inc[k], 63, 64);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            if (sub + r * 64 >= m) continue;
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t dst = sh.tot[d] + mycnt[d] + pos[r];
+            sh.key[dst] = key[r];
+            sh.val[dst] = val[r];
+        }
+        staged = true;
+        if ((diff >> shift) >> 8) {                         // a later pass follows
+#pragma unroll
+            for (int e = 0; e < RADIX / 64; ++e) mycnt[e * 64 + lane] = 0;     // own counters, after this wave's own reads
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r)
+                if (sub + r * 64 < m) {                     // back to registers, in order
+                    key[r] = sh.key[sub + r * 64];
+                    val[r] = sh.val[sub + r * 64];
+                }
+        } else {
+            __syncthreads();
+        }
+    }
+    if (!staged) {          // all keys equal: the input order is the answer
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+            if (sub + r * 64 < m) {
+                sh.key[sub + r * 64] = key[r];
+                sh.val[sub + r * 64] = val[r];
+            }
+        __syncthreads();
+    }
+}
+
+template <int ITEMS>
+__device__ __forceinline__ void rank_small(const float *__restrict__ scores, const SegTable &seg, int64_t q, int n, int64_t id_offset,
+                                           int64_t *__restrict__ ranks, float *__restrict__ top_scores, int klimit, LsShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = wave * 64 * ITEMS + lane;
+    uint32_t key[ITEMS], val[ITEMS];
+    const float *row = scores + q * (int64_t)n;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int i = sub + r * 64;
+        const int j = i < n ? i : n - 1;                // every lane loads: all loads in flight together
+        key[r] = desc_key(seg.nseg > 0 ? *seg_elem(seg, q, j) : row[j]);
+        val[r] = (uint32_t)j;
+    }
+    lds_radix_sort<ITEMS>(key, val, n, sh);
+    for (int i = tid; i < klimit; i += LS_THREADS) {
+        const uint32_t v = sh.val[i];
+        if (ranks) ranks[q * (int64_t)klimit + i] = (int64_t)v + id_offset;
+        if (top_scores) top_scores[q * (int64_t)klimit + i] = seg.nseg > 0 ? *seg_elem(seg, q, v) : row[v];
+    }
+}
+
+__global__ __launch_bounds__(LS_THREADS, 2) void rank_small_kernel(const float *__restrict__ scores, SegTable seg, int n, int64_t id_offset,
+                                                                   int64_t *__restrict__ ranks, float *__restrict__ top_scores, int klimit)
+{
+    __shared__ LsShared sh;
+    const int64_t q = blockIdx.x;
+    if (n <= LS_THREADS * 4) rank_small<4>(scores, seg, q, n, id_offset, ranks, top_scores, klimit, sh);
+    else if (n <= LS_THREADS * 8) rank_small<8>(scores, seg, q, n, id_offset, ranks, top_scores, klimit, sh);
+    else if (n <= LS_THREADS * 12) rank_small<12>(scores, seg, q, n, id_offset, ranks, top_scores, klimit, sh);
+    else rank_small<16>(scores, seg, q, n, id_offset, ranks, top_scores, klimit, sh);
+}
+
 // Does the LDS serve same-address lanes of one ds_add_rtn in ascending lane order?  Eight waves at once, 64 rounds
 // each, digits drawn from a few values (long conflict chains), from 256 values, and all equal; every lane checks
 // that what it got back is the count of earlier rounds plus the number of LOWER lanes with its digit (ballots).
@@ -688,6 +846,14 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
     // MDX_SORT_NO_PACK=1: the (key word, id word) layout also for small n (tests run both)
     static const bool no_pack = getenv("MDX_SORT_NO_PACK") && atoi(getenv("MDX_SORT_NO_PACK")) != 0;
     const bool arank = atomic_rank_ok(s);
+    // MDX_SORT_SMALL=0: the tiled passes also for short rows (tests run both)
+    static const bool no_small = getenv("MDX_SORT_SMALL") && atoi(getenv("MDX_SORT_SMALL")) == 0;
+    if (arank && n <= LS_CAP && !no_small) {
+        hipLaunchKernelGGL(rank_small_kernel, dim3((unsigned)nq), dim3(LS_THREADS), 0, s, scores, seg, (int)n, id_offset, ranks, top_scores,
+                           (int)klimit);
+        MDX_LAUNCH_CHECK();
+        return MDX_OK;
+    }
     if (n <= (1ll << 24) && !no_pack) {
         sort_pass<FMT_SCORES, FMT_A>(ws, scores, n, nq, 0, id_offset, ranks, top_scores, klimit, arank, seg, s);
         sort_pass<FMT_A, FMT_B>(ws, scores, n, nq, 1, id_offset, ranks, top_scores, klimit, arank, seg, s);
