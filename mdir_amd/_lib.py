@@ -101,6 +101,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MdxError("libmdx.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` or `make -C mdir_amd/csrc`" % LIB_PATH)
+        # torch first: its wheel carries its own libamdhip64, and libmdx.so must bind to THAT copy of the HIP runtime -- loaded
+        # before torch it would pull in /opt/rocm's, and a process with two HIP runtimes loses the device ("no ROCm-capable
+        # device is detected" at the first launch)
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         _declare(handle)
         if handle.mdx_abi_version() != 1:
