@@ -1,4 +1,4 @@
-"""Exactness + timing of the MSD ranking route (MDX_SORT_MSD=1 forces it from 65 536 columns on) against the C oracle."""
+"""Exactness of rank_full against the C oracle over distributions and column segments (written for the parked MSD route, tools/attic/rank_msd.h: MDX_SORT_MSD is only honoured by a library built with it)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
