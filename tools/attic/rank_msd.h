@@ -9,8 +9,11 @@
 // at all (load, stage, store) it takes 0.20 ms, the first pass hides under that (0.21), every further pass adds ~0.1 ms
 // (0.31 with two, 0.43 with the ~3.2 the 8-bit digits need; tools/msd_local_probe.hip).  Digits of up to 10 bits on
 // key - min(key) (two passes for 91 % of the buckets) measured 0.41 ms: the scan over 1024 bins costs what the saved pass
-// gains.  What would be left to try: persistent workgroups that prefetch the next bucket into registers while the
-// current one is sorted (estimated 0.32 ms for the finish, 0.73 in total).
+// gains.  Persistent workgroups that prefetch the next bucket into registers while the current one is sorted were tried
+// last (tools/msd_local_probe.hip, PERSIST=512): 0.77 ms against 0.43 -- on gfx9 loads and stores share ONE counter (vmcnt,
+// in-order), so the wait for the prefetched loads is also a wait for every store of the bucket written just before: a wave
+// that both stores results and loads its next input cannot overlap the two.  (The same holds for the persistent similarity
+// kernels under tools/attic/.)
 // To build it again: paste this block into mdx_rank.hip before the probe kernel, add FMT_BUCKETS to the scatter kernel
 // (digit = bucket byte staged through sval, carried in the top byte of the id word; git history of round 2 has the
 // patch) and the launch sequence at the end of this file into rank_impl.

@@ -236,6 +236,145 @@ __global__ __launch_bounds__(LS_THREADS, 2) void msd_local_sort_wide_kernel(cons
     else if (threadIdx.x == 0) atomicAdd(oversize, 1);
 }
 
+
+// ---- variant: persistent workgroups; the next bucket's pairs are prefetched into registers while the current one is sorted ----
+template <int ITEMS>
+__device__ __forceinline__ void sort_regs(uint32_t (&key)[ITEMS], uint32_t (&val)[ITEMS], int m, uint32_t *skey, uint32_t *sval,
+                                          uint32_t (*cnt)[256], uint32_t *tot, uint32_t *sdiff)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = wave * 64 * ITEMS + lane;
+    uint32_t pos[ITEMS];
+    uint32_t diff = 0;
+    if (tid == 0) { *sdiff = 0; tot[0] = key[0]; }
+    uint32_t *mycnt = cnt[wave];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mycnt[e * 64 + lane] = 0;
+    __syncthreads();
+    const uint32_t first = tot[0];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) if (sub + r * 64 < m) diff |= key[r] ^ first;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    if (lane == 0 && diff) atomicOr(sdiff, diff);
+    __syncthreads();
+    diff = *sdiff;
+    bool staged = false;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 8 * pass;
+        if (((diff >> shift) & 255u) == 0) continue;
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            pos[r] = 0;
+            if (sub + r * 64 < m) pos[r] = __hip_atomic_fetch_add(&mycnt[(key[r] >> shift) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < LS_WAVES; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
+            tot[tid] = run;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t t0 = tot[4 * lane], t1 = tot[4 * lane + 1], t2 = tot[4 * lane + 2], t3 = tot[4 * lane + 3];
+            const uint32_t mine = t0 + t1 + t2 + t3;
+            uint32_t inc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+            const uint32_t ex = inc - mine;
+            tot[4 * lane] = ex; tot[4 * lane + 1] = ex + t0; tot[4 * lane + 2] = ex + t0 + t1; tot[4 * lane + 3] = ex + t0 + t1 + t2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            if (sub + r * 64 >= m) continue;
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t dst = tot[d] + mycnt[d] + pos[r];
+            skey[dst] = key[r];
+            sval[dst] = val[r];
+        }
+        staged = true;
+        if ((diff >> shift) >> 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mycnt[e * 64 + lane] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) if (sub + r * 64 < m) { key[r] = skey[sub + r * 64]; val[r] = sval[sub + r * 64]; }
+        } else {
+            __syncthreads();
+        }
+    }
+    if (!staged) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) if (sub + r * 64 < m) sval[sub + r * 64] = val[r];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(LS_THREADS, 2) void msd_local_sort_persistent_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                                                  const uint32_t *__restrict__ bucket_start, int64_t n, int njobs,
+                                                                                  int64_t *__restrict__ out, int *__restrict__ oversize)
+{
+    __shared__ uint32_t skey[LS_THREADS * 16];
+    __shared__ uint32_t sval[LS_THREADS * 16];
+    __shared__ uint32_t cnt[LS_WAVES][256];
+    __shared__ uint32_t tot[256];
+    __shared__ uint32_t sdiff;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t nk[16], nv[16];
+    int job = blockIdx.x;
+    auto geometry = [&](int j, int64_t &q, uint32_t &s0, int &m, int &items) {
+        q = j / 256;
+        const int b = j % 256;
+        s0 = bucket_start[q * 257 + b];
+        m = (int)(bucket_start[q * 257 + b + 1] - s0);
+        items = m <= LS_THREADS * 8 ? 8 : (m <= LS_THREADS * 12 ? 12 : 16);
+    };
+    auto prefetch = [&](int j) {
+        int64_t q; uint32_t s0; int m, items;
+        geometry(j, q, s0, m, items);
+        const uint32_t *kin = keys + q * n + s0, *vin = vals + q * n + s0;
+        const int sub = wave * 64 * items + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (r < items && m > 0) {
+                const int i = sub + r * 64;
+                const int jj = i < m ? i : m - 1;
+                nk[r] = kin[jj];
+                nv[r] = vin[jj];
+            }
+    };
+    if (job < njobs) prefetch(job);
+    for (; job < njobs; job += gridDim.x) {
+        int64_t q; uint32_t s0; int m, items;
+        geometry(job, q, s0, m, items);
+        int64_t *o = out + q * n + s0;
+        if (m > LS_THREADS * 16) { if (tid == 0) atomicAdd(oversize, 1); if (job + (int)gridDim.x < njobs) prefetch(job + gridDim.x); continue; }
+        if (items == 8) {
+            uint32_t k8[8], v8[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { k8[r] = nk[r]; v8[r] = nv[r]; }
+            if (job + (int)gridDim.x < njobs) prefetch(job + gridDim.x);
+            if (m > 0) sort_regs<8>(k8, v8, m, skey, sval, cnt, tot, &sdiff);
+        } else if (items == 12) {
+            uint32_t k12[12], v12[12];
+#pragma unroll
+            for (int r = 0; r < 12; ++r) { k12[r] = nk[r]; v12[r] = nv[r]; }
+            if (job + (int)gridDim.x < njobs) prefetch(job + gridDim.x);
+            sort_regs<12>(k12, v12, m, skey, sval, cnt, tot, &sdiff);
+        } else {
+            uint32_t k16[16], v16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { k16[r] = nk[r]; v16[r] = nv[r]; }
+            if (job + (int)gridDim.x < njobs) prefetch(job + gridDim.x);
+            sort_regs<16>(k16, v16, m, skey, sval, cnt, tot, &sdiff);
+        }
+        for (int i = tid; i < m; i += LS_THREADS) o[i] = (int64_t)sval[i];
+        __syncthreads();        // the next sort writes the staging arrays
+    }
+}
+
 constexpr int LS_MAX_ITEMS = 16;
 
 __global__ __launch_bounds__(LS_THREADS, 2) void msd_local_sort_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
@@ -309,7 +448,8 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
         for (int i = 0; i < 5; ++i) {
-            if (getenv("WIDE")) hipLaunchKernelGGL(msd_local_sort_wide_kernel, dim3(256, nq), dim3(LS_THREADS), 0, 0, dk, dv, ds, n, dout, dover);
+            if (getenv("PERSIST")) hipLaunchKernelGGL(msd_local_sort_persistent_kernel, dim3(atoi(getenv("PERSIST"))), dim3(LS_THREADS), 0, 0, dk, dv, ds, n, 256 * nq, dout, dover);
+            else if (getenv("WIDE")) hipLaunchKernelGGL(msd_local_sort_wide_kernel, dim3(256, nq), dim3(LS_THREADS), 0, 0, dk, dv, ds, n, dout, dover);
             else hipLaunchKernelGGL(msd_local_sort_kernel, dim3(256, nq), dim3(LS_THREADS), 0, 0, dk, dv, ds, n, dout, dover);
         }
         hipEventRecord(b); hipEventSynchronize(b);
