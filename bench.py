@@ -385,6 +385,13 @@ def main():
                                          "scores_us": round(1e3 * t_s, 1), "rank_us": round(1e3 * t_r, 1),
                                          "queries_per_s": round(NQ / ((t_s + t_r) * 1e-3), 1), "bound": "launch latency"}
             small.close()
+            # the serving form of configs[2]: the 100 best rows per query instead of the full ranking (mdx_topk, exact)
+            t_k = timed(lambda: ops.topk(sc, 100, workspace=ws), reps=10)
+            ids100, _ = ops.topk(sc, 100, workspace=ws)
+            assert bool((ids100 == rk[:, :100]).all())                   # = the head of the full ranking
+            kms = extra.get("roofline", {}).get("kernel_ms") or 0.0
+            sec["configs2_top100"] = {"workload": "N=%d Q=%d: exact top-100 per query instead of the full ranking" % (n_total, NQ),
+                                      "topk_ms": round(t_k, 4), "queries_per_s_with_the_fp32_similarity": round(NQ / ((kms + t_k) * 1e-3), 1) if kms else None}
             half = ops.DescriptorIndex(rows, "ND", storage="f16")
             t_h = timed(lambda: half.scores(qvecs, "DN", out=sc), reps=10)
             hb = half.device_bytes + 4 * NQ * n_total
