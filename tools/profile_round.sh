@@ -8,7 +8,7 @@ W=/tmp/prof_$TAG; rm -rf $W; mkdir -p $W
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -- python3 $R/bench.py --no-cpu-baseline --no-secondary --extract-images 16 > $OUT/stats_bench.log 2>&1
 cp $W/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv
 head -1 $W/stats/*/*_kernel_trace.csv > $OUT/kernel_trace_mdx.csv; grep "mdx::" $W/stats/*/*_kernel_trace.csv | grep -v "bn_act" | head -4000 >> $OUT/kernel_trace_mdx.csv
-for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAVES"; do
+for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAVES"; do
   n=$(echo $c | cut -d' ' -f1)
   timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "mdx::" --output-format csv -d $W/pmc_$n -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --extract-images 0 > $OUT/pmc_$n.log 2>&1
   cp $W/pmc_$n/*/*_counter_collection.csv $OUT/pmc_$n.csv

@@ -85,6 +85,19 @@ with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
                 if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
                     cyc = c["GRBM_GUI_ACTIVE"] / 8.0
                     f.write("\nMFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) = %.1f %%; "
-                            "GRBM_GUI_ACTIVE/8 = %.3g cycles per launch (sustained clock = that / the launch's duration "
-                            "in the counter pass, see pmc csv)\n" % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, cyc))
+                            "GRBM_GUI_ACTIVE/8 = %.3g cycles per launch" % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, cyc))
+                    # sustained clock: cycles of a launch / its duration in the same (counter) pass
+                    durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                            for r in csv.DictReader(open(os.path.join(src, "pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv")))
+                            if short(r["Kernel_Name"]) == k and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+                    if durs:
+                        ms = sum(durs) / len(durs) / 1e6
+                        f.write("; launch duration in the counter pass %.3f ms -> sustained clock %.2f GHz (2.4 GHz is what the "
+                                "157.3 TFLOP/s peak assumes)" % (ms, cyc / ms / 1e6))
+                    busy = pmc("pmc_SQ_BUSY_CYCLES.csv").get(k, {})
+                    if busy.get("SQ_BUSY_CYCLES") and busy.get("GRBM_GUI_ACTIVE"):
+                        b = sum(busy["SQ_BUSY_CYCLES"]) / len(busy["SQ_BUSY_CYCLES"])
+                        g = sum(busy["GRBM_GUI_ACTIVE"]) / len(busy["GRBM_GUI_ACTIVE"])
+                        f.write("; SQ_BUSY_CYCLES %.4g per launch = %.2f x GRBM_GUI_ACTIVE of its own pass" % (b, b / g))
+                    f.write("\n")
 print(open(os.path.join(dst, tag + "_summary.md")).read())
