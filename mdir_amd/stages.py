@@ -127,10 +127,13 @@ def infer(params, data, device=None):
     order = _Sequential(len(paths))
     if graphs_enabled(device):
         describe, order = ShapeGraphs(describe), ShapeOrder(paths, bbxs)
+    workers = int(os.environ.get("MDIR_AMD_WORKERS", "8"))
+    decode_on_device = tail is not None and (resize_on_device or image_size is None) and workers > 0 \
+        and os.environ.get("MDIR_AMD_GPU_JPEG", "1") != "0" and os.environ.get("MDIR_AMD_LOADER", "threads") != "processes"
     dataset = ImagesFromList(root="", images=paths, imsize=image_size, bbxs=bbxs, transform=transform,
-                             resize_on_device=resize_on_device, **ds)
+                             resize_on_device=resize_on_device, decode_on_device=decode_on_device, **ds)
     from .datasets import make_loader
-    loader = make_loader(dataset, order, int(os.environ.get("MDIR_AMD_WORKERS", "8")), device, collate_fn=_collate_one)
+    loader = make_loader(dataset, order, workers, device, collate_fn=_collate_one)
     t0 = time.time()
     with torch.no_grad():
         batched_loop(loader, order, device, describe, store=lambda i, v: output.add(i, True, v),
