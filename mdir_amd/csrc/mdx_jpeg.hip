@@ -32,6 +32,9 @@ struct HuffTable {
     int32_t mincode[18], maxcode[18], valptr[18];
     // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
     uint16_t fast[512];
+    // AC tables, sequential scans: when code AND magnitude bits fit the 9-bit window, the whole coefficient at once:
+    // (value << 8) | (run << 4) | total bits, 0 = take the long way
+    int16_t fast_ac[512];
 };
 
 static bool build_table(HuffTable &t)
@@ -53,6 +56,17 @@ static bool build_table(HuffTable &t)
         code <<= 1;
     }
     t.maxcode[17] = 0x7FFFFFFF;
+    for (int i = 0; i < 512; ++i) {
+        t.fast_ac[i] = 0;
+        const int e = t.fast[i];
+        if (!e) continue;
+        const int len = e >> 8, rs = e & 255, run = rs >> 4, mag = rs & 15;
+        if (mag && len + mag <= 9) {
+            int v = (i >> (9 - len - mag)) & ((1 << mag) - 1);
+            if (v < (1 << (mag - 1))) v -= (1 << mag) - 1;
+            if (v >= -128 && v <= 127) t.fast_ac[i] = (int16_t)(v * 256 + run * 16 + len + mag);
+        }
+    }
     return true;
 }
 
@@ -196,6 +210,21 @@ struct BitReader {
     inline void fill()
     {
         while (nbits <= 56) {
+            if (!marker && p + 8 <= size) {
+                // eight bytes at once when none of them is 0xFF (no stuffing, no marker): the bits below the ones counted
+                // in are the true next bits of the stream, and a later fill ORs the same bits over them
+                uint64_t w;
+                memcpy(&w, d + p, 8);
+                w = __builtin_bswap64(w);
+                const uint64_t x = ~w;
+                if (((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) == 0) {
+                    const int take = (64 - nbits) >> 3;
+                    acc |= w >> nbits;
+                    p += take;
+                    nbits += 8 * take;
+                    return;
+                }
+            }
             int byte = 0;
             if (!marker && p < size) {
                 byte = d[p];
@@ -269,6 +298,15 @@ static inline bool block_sequential(BitReader &br, const HuffTable &dct, const H
     }
     blk[0] = (int16_t)pred;
     for (int k = 1; k < 64;) {
+        br.fill();
+        const int f = act.fast_ac[br.peek(9)];
+        if (f) {                            // run, size and value in one look
+            k += (f >> 4) & 15;
+            if (k > 63) return false;
+            br.skip(f & 15);
+            blk[ZIGZAG[k++]] = (int16_t)(f >> 8);
+            continue;
+        }
         const int rs = huff_decode(br, act);
         if (rs < 0) return false;
         const int r = rs >> 4;
