@@ -45,15 +45,20 @@ def entropy_decode(data, box=None):
     quant = torch.empty((3, 64), dtype=torch.int16)            # uint16 bit patterns
     if lib.mdx_jpeg_coefficients(buf.ctypes.data, buf.size, coef.data_ptr(), info.nblocks, quant.data_ptr()) != 0:
         return None                                             # corrupt stream: let Pillow report (or repair) it
-    return JpegCoefficients(info, coef, quant, box)
+    return JpegCoefficients(info, coef, quant, pil_box(box))
+
+
+def pil_box(box):
+    """The integer box ``Image.crop`` makes of ``box``: every corner through Python's ``round`` (PIL ``Image._crop``)."""
+    return tuple(int(round(v)) for v in box) if box else None
 
 
 def box_on_device(box, width, height):
-    """A crop box the device can take as a slice: integer corners inside the image (PIL pads boxes that stick out)."""
+    """A crop box (already rounded) the device can take as a slice: inside the image (PIL pads boxes that stick out)."""
     if not box:
         return True
     x1, y1, x2, y2 = box
-    return all(float(v).is_integer() for v in box) and 0 <= x1 < x2 <= width and 0 <= y1 < y2 <= height
+    return 0 <= x1 < x2 <= width and 0 <= y1 < y2 <= height
 
 
 def pixels(item, device):

@@ -265,7 +265,7 @@ def test_extraction_with_device_thumbnail_equals_host_thumbnail(tmp_path, monkey
         p = str(tmp_path / ("im%d.jpg" % i))
         Image.fromarray(img.astype(np.uint8)).save(p, quality=90)
         paths.append(p)
-        bbxs.append((10, 20, 390, 280) if i == 4 else None)
+        bbxs.append((10.5, 19.6, 390.4, 280.5) if i == 4 else None)       # fractional corners, as rOxford's query boxes have
     torch.manual_seed(2)
     net = init_network({"architecture": "resnet18", "pooling": "gem", "whitening": False, "pretrained": False}).to(DEV).eval()
     tr = initialize_transforms("pil2np | totensor | normalize", [net.meta["mean"], net.meta["std"]])

@@ -725,7 +725,7 @@ def test_loader_hands_jpeg_files_over_as_coefficients(tmp_path):
     Image.fromarray(arr).save(tmp_path / "pic.png")
     Image.fromarray(big).save(tmp_path / "big.jpg", quality=80)
     names = ["base.jpg", "base.jpg", "base.jpg", "prog.jpg", "pic.png", "big.jpg"]
-    boxes = [None, (10, 20, 300, 250), (-5, 0, 100, 100), None, None, None]
+    boxes = [None, (10.5, 19.6, 300.4, 250.5), (-5, 0, 100, 100), None, None, None]      # fractional corners: rounded as Image.crop does
     ds = ImagesFromList(str(tmp_path), names, imsize=256, bbxs=boxes, transform=ToUint8HWC(), resize_on_device=True, decode_on_device=True)
     plain = ImagesFromList(str(tmp_path), names, imsize=256, bbxs=boxes, transform=ToUint8HWC(), resize_on_device=True)
     kinds = [isinstance(ds[i], JpegCoefficients) for i in range(6)]
