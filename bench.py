@@ -228,10 +228,11 @@ def main():
         algo_bytes = 4.0 * n_total * DIM + 4.0 * NQ * DIM + 4.0 * NQ * n_total
         # HBM traffic is NOT measured in this run: it is the per-launch PMC figure (FETCH_SIZE x2 + WRITE_SIZE, separate
         # rocprofv3 --pmc passes, tools/profile_round.sh) of the newest committed profile -- named in traffic_source
-        traffic, traffic_source = None, None
+        traffic, traffic_source, prof = None, None, {}
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
         if tf:
-            traffic = json.load(open(tf[-1])).get("scores_kernel_hbm_bytes_per_launch")
+            prof = json.load(open(tf[-1]))
+            traffic = prof.get("scores_kernel_hbm_bytes_per_launch")
             traffic_source = "committed PMC summary %s (not measured in this run)" % os.path.relpath(tf[-1], ROOT)
         full_tiles, tail = divmod(NQ, 16)
         if n_total >= 32768 and 0 < tail <= 8 and full_tiles >= 1:
@@ -246,6 +247,13 @@ def main():
                     "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops, "algorithmic_bytes": algo_bytes,
                     "hbm_GBps_at_algorithmic_bytes": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 1),
                     "hbm_frac_of_8TBps": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        if prof.get("scores_kernel_sustained_clock_ghz"):
+            # from the same committed profile (SQ counter pass), not measured in this run: the kernel is power-limited, the peak
+            # figure assumes 2.4 GHz (profiles/r02_scores_stamps.md)
+            ghz = prof["scores_kernel_sustained_clock_ghz"]
+            roofline["profiled_sustained_clock_ghz"] = ghz
+            roofline["profiled_mfma_pipe_busy"] = prof.get("scores_kernel_mfma_pipe_busy")
+            roofline["frac_of_peak_at_profiled_clock"] = round(achieved / (PEAK_F32_MFMA_TFLOPS * ghz / 2.4), 4)
         extra["roofline"] = roofline
         extra["rank_ms_per_step"] = round(elapsed / args.steps * 1e3 - kernel_ms, 4)
         # the same evaluation without materialising a ranking: similarity + rank positions of the labelled

@@ -50,9 +50,21 @@ for k in sorted(set(fetch) | set(write)):
     wr = 1024 * (sum(wv) / len(wv)) if wv else 0.0
     traffic[k] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
 sk = [k for k in traffic if "::scores_" in k and "gather" not in k]
+clock = mfma_busy = None
+for k in sq:            # sustained clock and MFMA pipe occupancy of the similarity kernel in the SQ counter pass
+    if "::scores_" in k and "gather" not in k and sq[k].get("GRBM_GUI_ACTIVE") and sq[k].get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        cyc = sum(sq[k]["GRBM_GUI_ACTIVE"]) / len(sq[k]["GRBM_GUI_ACTIVE"]) / 8.0
+        durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                for r in csv.DictReader(open(os.path.join(src, "pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv")))
+                if short(r["Kernel_Name"]) == k and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+        if durs and cyc > 1e6:
+            clock = cyc / (sum(durs) / len(durs))                   # cycles per ns = GHz
+            mfma_busy = sum(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024 / cyc
 out = {"note": "HBM bytes per launch; FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1; KiB -> bytes",
        "per_kernel": traffic,
-       "scores_kernel_hbm_bytes_per_launch": traffic[sk[0]]["total_bytes"] if sk else None}
+       "scores_kernel_hbm_bytes_per_launch": traffic[sk[0]]["total_bytes"] if sk else None,
+       "scores_kernel_sustained_clock_ghz": round(clock, 3) if clock else None,
+       "scores_kernel_mfma_pipe_busy": round(mfma_busy, 4) if mfma_busy else None}
 json.dump(out, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 
 bench = {}
