@@ -271,6 +271,8 @@ def test_extraction_with_device_thumbnail_equals_host_thumbnail(tmp_path, monkey
     tr = initialize_transforms("pil2np | totensor | normalize", [net.meta["mean"], net.meta["std"]])
     monkeypatch.setattr(ShapeGraphs, "PAYOFF_IMAGES", 0)
     monkeypatch.setenv("MDIR_AMD_WORKERS", "2")
+    for name, value in (("MDIR_AMD_LOADER", "threads"), ("MDIR_AMD_GPU_JPEG", "1"), ("MDIR_AMD_GPU_RESIZE", "1")):
+        monkeypatch.setenv(name, value)                                  # the defaults, whatever the caller's environment says
     calls, decoded = [], []
     real = ops.resample_u8
     monkeypatch.setattr(ops, "resample_u8", lambda *a: (calls.append(a[1]), real(*a))[1])
