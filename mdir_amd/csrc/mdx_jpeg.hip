@@ -109,7 +109,10 @@ static bool table_segment(JpegHeader &hd, int m, const uint8_t *s, int n)
             for (int i = 1; i <= 16; ++i) { t.bits[i] = s[o + i]; total += t.bits[i]; }
             o += 17;
             if (total > 256 || o + total > n) { hd.why = "bad Huffman table"; return false; }
-            for (int i = 0; i < total; ++i) t.vals[i] = s[o + i];
+            for (int i = 0; i < total; ++i) {
+                t.vals[i] = s[o + i];
+                if (tc == 0 && t.vals[i] > 15) { hd.why = "bad Huffman table"; return false; }     // libjpeg: a fatal error
+            }
             o += total;
             if (!build_table(t)) { hd.why = "bad Huffman code lengths"; return false; }
             t.defined = true;
@@ -163,6 +166,9 @@ static bool parse_header(const uint8_t *d, int64_t size, JpegHeader &hd)
         } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             hd.why = "lossless, hierarchical or arithmetic-coded";
             return false;
+        } else if (!(m == 0xFE || (m >= 0xE0 && m <= 0xEF) || m == 0xDA)) {
+            hd.why = "unexpected marker";
+            return false;
         } else if (m == 0xDA) {             // SOS: the scans are walked by decode_scans
             if (!have_frame) { hd.why = "scan before frame"; return false; }
             hd.first_sos = p;
@@ -188,6 +194,10 @@ static bool parse_header(const uint8_t *d, int64_t size, JpegHeader &hd)
         hd.h[0] = hd.v[0] = 1;              // a single component is never interleaved: MCU = one block
         hd.hmax = hd.vmax = 1;
     }
+    for (int c = 0; c < hd.ncomp; ++c)
+        if (!hd.qdef[hd.tq[c]]) { hd.why = "missing quantisation table"; return false; }
+    // Pillow refuses images beyond twice its MAX_IMAGE_PIXELS (a decompression bomb): leave those to it
+    if ((int64_t)hd.width * hd.height > 2 * (int64_t)89478485) { hd.why = "too many pixels"; return false; }
     hd.mcux = (hd.width + 8 * hd.hmax - 1) / (8 * hd.hmax);
     hd.mcuy = (hd.height + 8 * hd.vmax - 1) / (8 * hd.vmax);
     hd.supported = true;
@@ -483,6 +493,7 @@ static bool decode_scans(const uint8_t *d, int64_t size, JpegHeader &hd, const m
             const int sl = be16(d + q + 2);
             if (sl < 2 || q + 2 + sl > size) return false;
             if (m == 0xDA) { pos = q + 2; break; }
+            if (!(m == 0xDB || m == 0xC4 || m == 0xDD || m == 0xFE || (m >= 0xE0 && m <= 0xEF))) return false;   // libjpeg: unsupported marker
             if (!table_segment(hd, m, d + q + 4, sl - 2)) return false;
             q += 2 + sl;
         }
@@ -572,11 +583,13 @@ __device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8],
     out[4] = jdescale(tmp13 - tmp0, shift);
 }
 
-// libjpeg's post-IDCT range limit: index (x & 1023) into a table that is 128 + x clamped to 0..255 for -512 <= x < 512
+// + 128, limited to 0..255: saturating, as libjpeg-turbo's SIMD IDCT packs its result (the C IDCT looks (x & 1023) up in a
+// table that wraps beyond +-512; for every sample a sound file can produce the two agree, on damaged files Pillow's
+// x86 build saturates)
 __device__ __forceinline__ uint8_t idct_limit(int32_t x)
 {
-    const int32_t i = x & 1023;
-    return (uint8_t)(i < 128 ? 128 + i : (i < 512 ? 255 : (i < 896 ? 0 : i - 896)));
+    x += 128;
+    return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x));
 }
 
 struct JpegGeom {
@@ -721,6 +734,22 @@ int mdx_jpeg_coefficients(const uint8_t *file, int64_t size, int16_t *coef, int6
     for (int c = 0; c < 3; ++c)
         for (int i = 0; i < 64; ++i) quant[c * 64 + i] = c < hd.ncomp ? hd.quant[hd.tq[c]][i] : 0;
     MDX_CHECK_ARG(decode_scans(file, size, hd, info, coef), "mdx_jpeg_coefficients: corrupt or unsupported entropy-coded data");
+    // The DCT of 8-bit samples stays within +-1024 (x the quantiser's rounding); a dequantised coefficient beyond +-2048 is
+    // damage.  libjpeg decodes such a file too, but what comes out then depends on its build (the SIMD IDCT multiplies and
+    // packs in 16 bits with saturation, the C one does not), so those files are left to it.
+    for (int c = 0; c < hd.ncomp; ++c) {
+        const int16_t *blk = coef + info.block_offset[c] * 64;
+        const int64_t nb = (int64_t)info.blocks_w[c] * info.blocks_h[c];
+        int32_t lim[64];
+        for (int i = 0; i < 64; ++i) lim[i] = 2048 / (quant[c * 64 + i] ? quant[c * 64 + i] : 1);
+        int bad = 0;
+        for (int64_t b = 0; b < nb; ++b)
+            for (int i = 0; i < 64; ++i) {
+                const int32_t v = blk[b * 64 + i];
+                bad |= (v > lim[i]) | (v < -lim[i]);
+            }
+        MDX_CHECK_ARG(!bad, "mdx_jpeg_coefficients: coefficients out of the range of 8-bit samples (damaged file)");
+    }
     return MDX_OK;
 }
 

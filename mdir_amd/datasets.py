@@ -82,6 +82,13 @@ class ImagesFromList(data.Dataset):
         item = jpeg.entropy_decode(data, self.bbxs[index] if self.bbxs else None)
         if item is None:
             return None
+        try:                                                # Pillow must at least recognise the file the same way (header parse only)
+            import io
+            with Image.open(io.BytesIO(data)) as seen:
+                if seen.format != "JPEG" or seen.size != item.size or seen.mode not in ("RGB", "L"):
+                    return None
+        except Exception:
+            return None                                     # the host route raises what the reference raises
         w, h = item.size
         if item.box:
             if not jpeg.box_on_device(item.box, w, h):

@@ -546,8 +546,9 @@ def jpeg_pixels(coef, quant, info):
         ws = _jpeg_idct8(np.moveaxis(blk, 1, 0), 13 - 2)                                          # columns: over the rows
         px = _jpeg_idct8(np.moveaxis(ws, 2, 0), 13 + 2 + 3)                                       # rows: over the columns
         px = np.moveaxis(px, 0, 2)                                                                # [row, n, col] -> [row, n, col]
-        idx = px & 1023                                                                           # the post-IDCT range limit table
-        val = np.where(idx < 128, 128 + idx, np.where(idx < 512, 255, np.where(idx < 896, 0, idx - 896))).astype(np.int32)
+        # + 128 and limited to 0..255, saturating as libjpeg-turbo's SIMD IDCT does (the C one looks (x & 1023) up in a table
+        # that wraps beyond +-512: the same for every sample a sound file can produce)
+        val = np.clip(px + 128, 0, 255).astype(np.int32)
         val = np.moveaxis(val, 0, 1).reshape(bh, bw, 8, 8).transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8)
         planes.append(val)
     lum = planes[0][:H, :W]

@@ -377,3 +377,63 @@ def test_jpeg_restatement_is_pillow():
     for i in range(1000, len(broken), 997):
         broken[i] ^= 0x5A
     declined(bytes(broken))                                               # anything but a crash
+
+
+def test_jpeg_host_stage_on_damaged_files():
+    """Damaged files (random bytes overwritten, tails cut off) never crash the host entropy stage; most are declined (they
+    go to Pillow, whose tolerance the reference relies on: LOAD_TRUNCATED_IMAGES); those it still decodes must almost
+    always be what Pillow makes of the same bytes (a few damaged progressive files are handled differently by libjpeg)."""
+    import ctypes
+    import io
+    import warnings
+    from PIL import Image, ImageFile
+    from mdir_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(33)
+    old = ImageFile.LOAD_TRUNCATED_IMAGES
+    ImageFile.LOAD_TRUNCATED_IMAGES = True
+    same = differ = declined = 0
+    try:
+        for prog in (False, True):
+            for sub in (0, 2):
+                low = rng.integers(0, 255, (12, 17, 3)).astype(np.float32)
+                img = np.clip(np.kron(low, np.ones((8, 8, 1), np.float32))[:90, :130] + rng.normal(0, 12, (90, 130, 3)), 0, 255).astype(np.uint8)
+                buf = io.BytesIO()
+                Image.fromarray(img).save(buf, format="JPEG", quality=80, subsampling=sub, progressive=prog)
+                base = bytearray(buf.getvalue())
+                for trial in range(120):
+                    d = bytearray(base)
+                    for _ in range(int(rng.integers(1, 4))):
+                        d[int(rng.integers(2, len(d)))] = int(rng.integers(0, 256))
+                    if trial % 5 == 0:
+                        d = d[:int(rng.integers(20, len(d)))]
+                    data = bytes(d)
+                    b = np.frombuffer(data, dtype=np.uint8)
+                    info = _lib.JpegInfo()
+                    lib.mdx_jpeg_probe(b.ctypes.data, b.size, ctypes.byref(info))
+                    if not info.supported or info.nblocks > 100000:
+                        declined += 1
+                        continue
+                    coef, quant = np.empty((info.nblocks, 64), dtype=np.int16), np.empty((3, 64), dtype=np.uint16)
+                    if lib.mdx_jpeg_coefficients(b.ctypes.data, b.size, coef.ctypes.data, info.nblocks, quant.ctypes.data) != 0:
+                        declined += 1
+                        continue
+                    meta = {k: (list(getattr(info, k)) if k.endswith(("samp", "_w", "_h", "offset")) else getattr(info, k))
+                            for k in ("width", "height", "ncomp", "hsamp", "vsamp", "blocks_w", "blocks_h", "block_offset")}
+                    got = O.jpeg_pixels(coef, quant, meta)
+                    try:
+                        with warnings.catch_warnings():
+                            warnings.simplefilter("ignore")
+                            im = Image.open(io.BytesIO(data))
+                            if im.size != (info.width, info.height) or im.mode not in ("RGB", "L"):
+                                continue                          # the loader compares these too and takes the host route
+                            want = np.asarray(im.convert("RGB"))
+                    except Exception:
+                        continue                                  # ... as it does when Pillow refuses the file
+                    if np.array_equal(got, want):
+                        same += 1
+                    else:
+                        differ += 1
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = old
+    assert declined > 100 and same > 50 and differ <= max(2, same // 50), (same, differ, declined)
