@@ -12,8 +12,14 @@
  *    a parameter says "host".  The caller owns every buffer; the library allocates
  *    nothing persistent except inside an mdx_index (explicit create/destroy).
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
- *    only enqueue work; nothing synchronises the device.  Safe under graph capture
- *    except mdx_index_create / mdx_index_destroy (they allocate / free).
+ *    only enqueue work and do not synchronise the device, with two exceptions:
+ *    mdx_index_create / _ex / _destroy allocate / free, and creation also waits for a
+ *    one-off probe kernel (a few hundred microseconds per device and process) that
+ *    settles how the sort ranks inside a wave; a process that ranks WITHOUT ever
+ *    creating an index runs that probe in its first mdx_rank_* / mdx_topk call instead
+ *    (and waits for it once) -- unless that stream is being captured, in which case
+ *    nothing synchronises and the probe-free kernels are recorded.  Everything but
+ *    index creation / destruction and mdx_comm_init / _destroy is safe under graph capture.
  *  - Every function returns MDX_OK (0) or a negative mdx_status; the message of
  *    the last failure on the calling thread is mdx_last_error().  Nothing aborts.
  *  - One host thread per device at a time; handles are not internally locked.
@@ -261,6 +267,60 @@ int mdx_gather_scores(const float *scores, int64_t n, int64_t nq, const int64_t 
 int mdx_rank_count(const float *scores, int64_t n, int64_t nq, int64_t id_offset,
                    const float *ref_scores, const int64_t *ref_ids, const int64_t *offsets,
                    int64_t total, int64_t *cnt, void *stream);
+
+/* ------------------------------------------------- whitening learning (float64) */
+
+/* The dense products of whitenlearn / pcawhitenlearn (mdir/external/cirtorch/utils/whiten.py:14-53), which the
+ * reference runs in float64 on float64 descriptors; here on the f64 matrix cores (v_mfma_f64_16x16x4_f64, f64
+ * accumulation).  Cholesky / eig / inverse of the D x D results stay on the host, as in the reference.
+ *
+ * Gram matrix of the rows of a dimension-major matrix:
+ *   a [d, n] row-major, center [d] or NULL  ->  out [d, d],  out[i][j] = sum_k (a[i][k] - center[i]) * (a[j][k] - center[j])
+ * = `np.dot(Xc, Xc.T)` with `Xc = X - m` (whiten.py:21-22), `np.dot(df, df.T)` (whiten.py:42 and :46).  Only the
+ * tiles on or above the diagonal are computed and each is stored twice: the result is exactly symmetric. */
+int mdx_gram_f64(const double *a, int64_t d, int64_t n, const double *center, double *out, void *stream);
+
+/* Projection of centred descriptors:
+ *   p [dout, d] row-major, x [d, n] row-major, center [d] or NULL  ->  out [dout, n] = p . (x - center)
+ * = `df = np.dot(P, X-m)` (whiten.py:45). */
+int mdx_project_f64(const double *p, int64_t dout, int64_t d, const double *x, int64_t n, const double *center,
+                    double *out, void *stream);
+
+/* ------------------------------------------------- multi-GPU exchange (RCCL over xGMI) */
+
+/* The reference is single-process; what is sharded here is `scores = np.dot(vecs.T, qvecs)` (cirscore.py:69):
+ * database rows are independent, so rank g of G (one process per GPU) keeps rows [lo_g, hi_g) as its own mdx_index
+ * and computes its block S_g [nq, w_g] with mdx_scores alone.  The two calls below move the blocks to where
+ * `np.argsort(-scores, axis=0)` (cirscore.py:70) needs them; both deliver blocks BACK TO BACK in rank order (block g
+ * row-major, widths[g] columns), which is the form mdx_rank_full_segments reads in place.
+ *
+ * RCCL is bound at run time (dlopen of librccl.so.1 -- the copy the process already holds, e.g. PyTorch's); a box
+ * without it gets MDX_ERR_RUNTIME from these calls and nothing else changes.  Communicator set-up follows RCCL:
+ * ONE rank calls mdx_comm_unique_id and hands the MDX_COMM_ID_BYTES bytes to the others by any means (the Python
+ * host uses its torch.distributed group), then EVERY rank calls mdx_comm_init with its device selected
+ * (hipSetDevice); the call is collective.  Exchange calls only enqueue work on `stream`. */
+typedef struct mdx_comm mdx_comm;
+#define MDX_COMM_ID_BYTES 128
+int mdx_comm_unique_id(void *id_host);
+int mdx_comm_init(mdx_comm **out, const void *id_host, int nranks, int rank);
+int mdx_comm_destroy(mdx_comm *comm);
+int mdx_comm_info(const mdx_comm *comm, int *nranks, int *rank);
+
+/* Queries [lo, hi) that rank `rank` of `nranks` ranks (sorts) under the query split: contiguous, sizes differ by <= 1. */
+int mdx_query_bounds(int64_t nq, int nranks, int rank, int64_t *lo, int64_t *hi);
+
+/* "All-gather of per-shard partial scores" (BASELINE.json north_star):
+ *   local [nq, widths[rank]] on every rank  ->  all = G blocks back to back, block g = S_g [nq, widths[g]], on every rank.
+ * widths: HOST array of nranks column counts (the shard sizes; the same on every rank).  Equal widths go out as one
+ * ncclAllGather, unequal ones as a grouped send/receive per peer (one per xGMI link). */
+int mdx_allgather_scores(mdx_comm *comm, const float *local, int64_t nq, const int64_t *widths, float *all, void *stream);
+
+/* The query-split form (1/G of the bytes per rank; the ranking becomes G-way parallel): rank r keeps queries
+ * [qlo_r, qhi_r) = mdx_query_bounds(nq, G, r) and receives their rows of every block:
+ *   local [nq, widths[rank]]  ->  mine = G blocks back to back, block g = S_g[qlo_r:qhi_r, :]  ([nq_mine, widths[g]]).
+ * mdx_rank_full_segments(blocks, widths, G, nq_mine, 0, ...) then yields the rankings of this rank's queries with
+ * GLOBAL row ids. */
+int mdx_exchange_scores(mdx_comm *comm, const float *local, int64_t nq, const int64_t *widths, float *mine, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,9 @@ namespace mdx {
 
 void set_error(const char *fmt, ...);
 
+// mdx_rank.hip: decides once per device how the sort ranks inside a wave (may synchronise `s`); 0 = not decided (capturing)
+int probe_lds_order(hipStream_t s);
+
 #define MDX_CHECK_ARG(cond, ...)                  \
     do {                                          \
         if (!(cond)) {                            \

@@ -246,6 +246,9 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
         delete ix;
         return rc;
     }
+    // index creation is the one call of the ranking path that may synchronise: settle here how the sort ranks inside a
+    // wave on this device (mdx_rank.hip), so that the enqueue-only ranking calls -- also captured ones -- find the answer
+    (void)probe_lds_order(s);
     *out = ix;
     return MDX_OK;
 }

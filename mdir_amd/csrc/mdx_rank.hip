@@ -8,6 +8,8 @@
 // All of it is HBM-bound integer work: 4 passes of 8 bits; per pass a per-tile
 // histogram, a per-query scan, and a stable scatter.  Stability (equal keys keep
 // ascending id) is what fixes the tie order documented in include/mdx.h.
+#include <atomic>
+
 #include "mdx_common.h"
 
 namespace mdx {
@@ -774,30 +776,48 @@ __global__ __launch_bounds__(SORT_THREADS) void lds_order_probe_kernel(uint32_t 
     if (wrong) atomicOr(bad, 1);
 }
 
-// once per device; 0 unknown, 1 ballots, 2 ds_add_rtn.  MDX_SORT_RANK=ballot|atomic overrides the probe.
-static int g_arank[64];
+// Which form ranks the elements of a wave, per device: 0 unknown, 1 ballots, 2 ds_add_rtn.  The atomic form is taken only
+// on the architecture it was validated on (gfx950) AND after the probe above has passed on this very device; every other
+// case -- another architecture, a failed or impossible probe, a stream that is being captured before the probe has run --
+// ranks with ballots, which rest on documented behaviour only.  MDX_SORT_RANK=ballot|atomic overrides both (tests run both).
+static std::atomic<int> g_arank[64];
+
+// Runs the probe on `s` and WAITS for it (a few hundred microseconds, once per device and process).  Called from
+// mdx_index_create (which may synchronise) so that enqueue-only ranking calls normally find the answer; a ranking call on
+// a device that never built an index runs it itself, unless its stream is capturing.
+int probe_lds_order(hipStream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    int known = g_arank[dev].load(std::memory_order_acquire);
+    if (known > 0) return known;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;     // ask later
+    int verdict = 1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && !strncmp(prop.gcnArchName, "gfx950", 6)) {
+        int *bad = nullptr, host = 1;
+        if (hipMalloc(&bad, sizeof(int)) == hipSuccess) {
+            bool ok = hipMemsetAsync(bad, 0, sizeof(int), s) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1024), dim3(SORT_THREADS), 0, s, 0x9E3779B9u, bad);
+                ok = hipMemcpyAsync(&host, bad, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                     hipStreamSynchronize(s) == hipSuccess;
+            }
+            (void)hipFree(bad);
+            if (ok && host == 0) verdict = 2;
+        }
+    }
+    g_arank[dev].store(verdict, std::memory_order_release);
+    return verdict;
+}
 
 static bool atomic_rank_ok(hipStream_t s)
 {
-    const char *force = getenv("MDX_SORT_RANK");
+    static const char *force = getenv("MDX_SORT_RANK");
     if (force && !strcmp(force, "ballot")) return false;
     if (force && !strcmp(force, "atomic")) return true;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if (g_arank[dev] > 0) return g_arank[dev] == 2;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;   // ask later
-    int *bad = nullptr, host = 1;
-    if (hipMalloc(&bad, sizeof(int)) != hipSuccess) return false;
-    bool ok = hipMemsetAsync(bad, 0, sizeof(int), s) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1024), dim3(SORT_THREADS), 0, s, 0x9E3779B9u, bad);
-        ok = hipMemcpyAsync(&host, bad, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
-             hipStreamSynchronize(s) == hipSuccess;
-    }
-    (void)hipFree(bad);
-    g_arank[dev] = (ok && host == 0) ? 2 : 1;
-    return g_arank[dev] == 2;
+    return probe_lds_order(s) == 2;
 }
 
 template <int IN, int OUT>

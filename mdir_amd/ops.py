@@ -453,3 +453,130 @@ def rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, off_t):
                                             ref_ids.numel(), _dev(cnt, torch.int64, "cnt"), _stream()),
                   "mdx_rank_count")
     return cnt
+
+
+# ---------------------------------------------------------- whitening learning
+
+def gram_f64(a, center=None):
+    """``(a - center) @ (a - center).T`` for a float64 ``[d, n]`` device matrix -> ``[d, d]`` (exactly symmetric):
+    the ``np.dot(df, df.T)`` / ``np.dot(Xc, Xc.T)`` of cirtorch/utils/whiten.py:22,42,46 on the f64 matrix cores."""
+    ap = _dev(a, torch.float64, "a")
+    if a.dim() != 2:
+        raise ValueError("a must be [d, n]")
+    d, n = a.shape
+    cp = _dev(center, torch.float64, "center") if center is not None else None
+    if center is not None and center.numel() != d:
+        raise ValueError("center has %d elements, expected %d" % (center.numel(), d))
+    out = torch.empty((d, d), dtype=torch.float64, device=a.device)
+    with _on(a):
+        check(_lib.lib().mdx_gram_f64(ap, d, n, cp, _vp(out.data_ptr()), _stream()), "mdx_gram_f64")
+    return out
+
+
+def project_f64(p, x, center=None):
+    """``p @ (x - center)`` for float64 ``p [dout, d]``, ``x [d, n]``, ``center [d]`` -> ``[dout, n]``
+    (``np.dot(P, X-m)``, whiten.py:45)."""
+    pp = _dev(p, torch.float64, "p")
+    xp = _dev(x, torch.float64, "x")
+    if p.dim() != 2 or x.dim() != 2 or p.shape[1] != x.shape[0]:
+        raise ValueError("p [dout, d] and x [d, n] expected, got %s and %s" % (tuple(p.shape), tuple(x.shape)))
+    cp = _dev(center, torch.float64, "center") if center is not None else None
+    if center is not None and center.numel() != x.shape[0]:
+        raise ValueError("center has %d elements, expected %d" % (center.numel(), x.shape[0]))
+    out = torch.empty((p.shape[0], x.shape[1]), dtype=torch.float64, device=x.device)
+    with _on(x):
+        check(_lib.lib().mdx_project_f64(pp, p.shape[0], p.shape[1], xp, x.shape[1], cp, _vp(out.data_ptr()), _stream()),
+              "mdx_project_f64")
+    return out
+
+
+# ------------------------------------------------------------ multi-GPU exchange
+
+def query_bounds(nq, nranks, rank):
+    """Queries ``[lo, hi)`` of ``rank`` under the query split (``mdx_query_bounds``)."""
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    check(_lib.lib().mdx_query_bounds(int(nq), int(nranks), int(rank), ctypes.byref(lo), ctypes.byref(hi)), "mdx_query_bounds")
+    return lo.value, hi.value
+
+
+class Comm:
+    """RCCL communicator of libmdx.so (``mdx_comm``): the exchange of per-shard partial scores through the C ABI.
+
+    ``Comm.from_process_group(device)`` builds one over an initialised ``torch.distributed`` group (rank 0's unique id is
+    broadcast through that group -- the only use made of it); ``Comm(id_bytes, nranks, rank)`` takes an id that
+    travelled by other means (``Comm.unique_id()`` on one rank)."""
+
+    def __init__(self, id_bytes, nranks, rank, device=None):
+        self._h = None
+        self.nranks, self.rank = int(nranks), int(rank)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if len(id_bytes) != 128:
+            raise ValueError("a communicator id is 128 bytes")
+        buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id_bytes))
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mdx_comm_init(ctypes.byref(h), buf, self.nranks, self.rank), "mdx_comm_init")
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_char * 128)()
+        check(_lib.lib().mdx_comm_unique_id(buf), "mdx_comm_unique_id")
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_process_group(cls, device, group=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], world, rank, device)
+
+    def _widths(self, widths):
+        if len(widths) != self.nranks:
+            raise ValueError("need one width per rank")
+        return (ctypes.c_int64 * self.nranks)(*[int(w) for w in widths])
+
+    def allgather_scores(self, local, widths):
+        """``local [nq, widths[rank]]`` -> list of the G blocks ``[nq, widths[g]]`` (views of one buffer, back to back)."""
+        nq = local.shape[0]
+        if local.shape[1] != widths[self.rank]:
+            raise ValueError("local block is %s, widths[%d] = %d" % (tuple(local.shape), self.rank, widths[self.rank]))
+        out = torch.empty(nq * int(sum(widths)), dtype=torch.float32, device=local.device)
+        with torch.cuda.device(local.device):
+            check(_lib.lib().mdx_allgather_scores(self._h, _dev(local, torch.float32, "local scores"), nq, self._widths(widths),
+                                                  _vp(out.data_ptr()), _stream()), "mdx_allgather_scores")
+        return self._blocks(out, nq, widths)
+
+    def exchange_scores(self, local, widths):
+        """``local [nq, widths[rank]]`` -> ``(blocks [nq_mine, widths[g]] of MY queries, (qlo, qhi))``."""
+        nq = local.shape[0]
+        if local.shape[1] != widths[self.rank]:
+            raise ValueError("local block is %s, widths[%d] = %d" % (tuple(local.shape), self.rank, widths[self.rank]))
+        qlo, qhi = query_bounds(nq, self.nranks, self.rank)
+        out = torch.empty(max(1, (qhi - qlo) * int(sum(widths))), dtype=torch.float32, device=local.device)
+        with torch.cuda.device(local.device):
+            check(_lib.lib().mdx_exchange_scores(self._h, _dev(local, torch.float32, "local scores"), nq, self._widths(widths),
+                                                 _vp(out.data_ptr()), _stream()), "mdx_exchange_scores")
+        return self._blocks(out, qhi - qlo, widths), (qlo, qhi)
+
+    @staticmethod
+    def _blocks(buf, rows, widths):
+        blocks, o = [], 0
+        for w in widths:
+            blocks.append(buf[o:o + rows * int(w)].view(rows, int(w)))
+            o += rows * int(w)
+        return blocks
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            h, self._h = self._h, None
+            check(_lib.lib().mdx_comm_destroy(h), "mdx_comm_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

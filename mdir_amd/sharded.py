@@ -57,10 +57,23 @@ class HipBackend:
 
 
 class BlockScores:
-    """``[Q_mine, N]`` similarities held as the column blocks the exchange delivered."""
+    """``[Q_mine, N]`` similarities held as the column blocks the exchange delivered (``.blocks``: block g is
+    ``[Q_mine, rows of that peer chunk]``; ``.dense()`` concatenates on demand).  The blocks are the caller's: every
+    ``rank_queries`` / ``exchange`` call receives into fresh memory unless the index was told to recycle its receive
+    buffers (``ShardedIndex.reuse_buffers = True``: a benchmark loop that keeps only the newest result) -- then they
+    are valid until the next exchange of the same index."""
 
     def __init__(self, blocks):
         self.blocks = blocks
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, item):
+        return self.dense()[item]
+
+    def cpu(self):
+        return self.dense().cpu()
 
     @property
     def shape(self):
@@ -139,7 +152,10 @@ class ShardedIndex:
         # RCCL moves device buffers directly; under gloo (CPU tests, or several ranks
         # sharing one GPU for a dry run) collectives are staged through host memory.
         self._host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
-        self._recv = {}                    # (chunk, elements) -> receive buffer of the exchange, allocated once
+        # False: every exchange receives into fresh memory (results stay valid).  True: one receive buffer per chunk is
+        # kept and OVERWRITTEN by the next exchange -- for loops that only keep the newest result (bench.py)
+        self.reuse_buffers = False
+        self._recv = {}                    # (chunk, elements) -> receive buffer of the exchange (reuse_buffers only)
         self.phases = None                 # events of the last rank_queries(): see phase_ms()
         self._use_a2a = self._probe_all_to_all()
 
@@ -206,9 +222,11 @@ class ShardedIndex:
                     for r in range(self.world)]
         out_split = [(qhi - qlo) * w for w in widths]
         key = (chunk, sum(out_split))
-        recv = self._recv.get(key)
+        recv = self._recv.get(key) if self.reuse_buffers else None
         if recv is None or recv.device != s_part.device:
-            recv = self._recv[key] = torch.empty(sum(out_split), dtype=s_part.dtype, device=s_part.device)
+            recv = torch.empty(sum(out_split), dtype=s_part.dtype, device=s_part.device)
+            if self.reuse_buffers:
+                self._recv[key] = recv
         if self._host_staged:
             send, host_recv = s_part.reshape(-1).cpu(), torch.empty(recv.shape, dtype=recv.dtype)
             if self._use_a2a:

@@ -29,26 +29,26 @@ def whitenapply(X, m, P, dimensions=None, device="cuda"):
 
 # ---------------------------------------------------------------------------
 # learning.  The reference does all of it in float64 (whiten.py:37-53 on float64
-# descriptors): the low-variance directions of a 2048-d covariance sit below fp32 noise, so the two D x D Gram
-# matrices and the projection are float64 here too -- plain library GEMMs (rocBLAS dgemm on the f64 MFMA through
-# torch.matmul; the fp32 chain kernel of the hot path is NOT used for this offline step).  The small dense
-# factorisations stay on the host, as in the reference.
+# descriptors): the low-variance directions of a 2048-d covariance sit below fp32 noise, so the D x D Gram
+# matrices and the projection are float64 here too -- libmdx's own f64 matrix-core kernels (mdx_gram_f64,
+# SYRK-shaped; mdx_project_f64 with the centring fused into the operand load; csrc/mdx_gram.hip), not the fp32 chain
+# kernel of the hot path.  The small dense factorisations stay on the host, as in the reference.
 # ---------------------------------------------------------------------------
 
 def _as_f64(a, device):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=torch.device(device))
 
 
-def gram(A, device="cuda"):
-    """``A @ A.T`` for ``A [D,n]`` in float64: the ``np.dot(df, df.T)`` of ``whiten.py:42,46`` and the
-    ``np.dot(Xc, Xc.T)`` of ``:22``."""
-    Ad = _as_f64(A, device)
-    return (Ad @ Ad.t()).cpu().numpy()
+def gram(A, device="cuda", center=None):
+    """``(A - center) @ (A - center).T`` for ``A [D,n]`` in float64: the ``np.dot(df, df.T)`` of ``whiten.py:42,46``
+    and, with ``center = m``, the ``np.dot(Xc, Xc.T)`` of ``:21-22`` (``mdx_gram_f64``)."""
+    c = None if center is None else _as_f64(np.asarray(center).reshape(-1), device)
+    return ops.gram_f64(_as_f64(A, device), c).cpu().numpy()
 
 
 def project(P, X, m, device="cuda"):
-    """``np.dot(P, X - m)`` for ``X [D,N]`` in float64: returns ``[D_out, N]`` (``whiten.py:45``)."""
-    return (_as_f64(P, device) @ (_as_f64(X, device) - _as_f64(np.asarray(m).reshape(-1, 1), device))).cpu().numpy()
+    """``np.dot(P, X - m)`` for ``X [D,N]`` in float64: returns ``[D_out, N]`` (``whiten.py:45``; ``mdx_project_f64``)."""
+    return ops.project_f64(_as_f64(P, device), _as_f64(X, device), _as_f64(np.asarray(m).reshape(-1), device)).cpu().numpy()
 
 
 def cholesky(S):
@@ -67,7 +67,7 @@ def pcawhitenlearn(X, shrink=None, device="cuda"):
     """PCA whitening without annotations (``whiten.py:14-35``): returns ``(m, P)``."""
     N = X.shape[1]
     m = X.mean(axis=1, keepdims=True)
-    Xcov = gram(X - m, device)
+    Xcov = gram(X, device, center=m)
     Xcov = (Xcov + Xcov.T) / (2 * N)
     eigval, eigvec = np.linalg.eig(Xcov)
     order = eigval.argsort()[::-1]

@@ -69,9 +69,12 @@ def jpeg_pixels(item, device):
 
 
 class DescriptorIndex:
-    def __init__(self, vecs, layout="DN", row_offset=0):
+    def __init__(self, vecs, layout="DN", row_offset=0, storage="f32"):
         v = vecs.detach().numpy()
+        self.storage = storage
         self.nd = np.ascontiguousarray(v.T if layout in ("DN", "dim_major") else v)
+        if storage == "f16":                # shard (and queries) rounded to fp16, fp32 accumulation
+            self.nd = self.nd.astype(np.float16).astype(np.float32)
         self.n, self.d = self.nd.shape
         self.row_offset = row_offset
         self.device = vecs.device
@@ -81,6 +84,8 @@ class DescriptorIndex:
         q = np.ascontiguousarray(q.T if qlayout in ("DN", "dim_major") else q)
         if center is not None:
             q = q - center.detach().numpy().reshape(1, -1)
+        if self.storage == "f16":
+            q = q.astype(np.float16).astype(np.float32)
         res = torch.from_numpy(OC.gemm_nt_chain(q, self.nd))
         if out is not None:
             out.copy_(res)
@@ -131,7 +136,21 @@ def rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, off_t):
     return cnt
 
 
-NAMES = ("pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "rank_full", "topk", "rank_of",
+def gram_f64(a, center=None):
+    x = a.detach().numpy()
+    if center is not None:
+        x = x - center.detach().numpy().reshape(-1, 1)
+    return torch.from_numpy(x @ x.T)
+
+
+def project_f64(p, x, center=None):
+    xv = x.detach().numpy()
+    if center is not None:
+        xv = xv - center.detach().numpy().reshape(-1, 1)
+    return torch.from_numpy(p.detach().numpy() @ xv)
+
+
+NAMES = ("gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 

@@ -88,6 +88,9 @@ def _worker(rank, world, port, n, nq, d, out_dir, chunks, exchange=None):
     sh = ShardedIndex(torch.from_numpy(np.ascontiguousarray(vecs[:, lo:hi])), "DN", n, backend=OracleBackend())
     assert sh.chunks == (chunks or 1) and len(sh.parts) == sh.chunks
     rk, sc, (qlo, qhi) = sh.rank_queries(torch.from_numpy(qvecs), "DN")
+    # a second exchange of the same sizes must not touch what the first one returned (`sc` is saved below)
+    _, sc2, _ = sh.rank_queries(torch.from_numpy(np.ascontiguousarray(-qvecs)), "DN")
+    assert qhi == qlo or not np.array_equal(sc2.dense().numpy(), sc.dense().numpy())
     gnd = O.synth_gnd(nq, n, seed=1, easy=3, hard=4, junk=2)
     lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
     lists[0] = np.array([3, 7, n - 1])

@@ -60,7 +60,10 @@ for k in sq:            # sustained clock and MFMA pipe occupancy of the similar
         if durs and cyc > 1e6:
             clock = cyc / (sum(durs) / len(durs))                   # cycles per ns = GHz
             mfma_busy = sum(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024 / cyc
+sys.path.insert(0, root)
+from bench import scores_source_sha16          # ties the figures below to the kernel sources they were measured on
 out = {"note": "HBM bytes per launch; FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1; KiB -> bytes",
+       "scores_kernel_source_sha16": scores_source_sha16(),
        "per_kernel": traffic,
        "scores_kernel_hbm_bytes_per_launch": traffic[sk[0]]["total_bytes"] if sk else None,
        "scores_kernel_sustained_clock_ghz": round(clock, 3) if clock else None,
