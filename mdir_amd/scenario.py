@@ -47,13 +47,44 @@ def dict_deep_overlay(*data, list_replace=False):
     return overlay
 
 
+def validate_hash(content, path):
+    """A name that ends in ``-<8+ hex digits>.<ext>`` promises the sha256 prefix of its content
+    (``validate`` of ``mdir/tools/utils.py:27-34``; same error)."""
+    import hashlib
+    import re
+    match = re.search(r'.*-([a-f0-9]{8,})\.[a-zA-Z0-9]{2,}$', path)
+    if match:
+        stored = match.group(1)
+        computed = hashlib.sha256(content).hexdigest()[:len(stored)]
+        if computed != stored:
+            raise ValueError("Computed hash '%s' is not consistent with stored hash '%s'" % (computed, stored))
+
+
+def resource_dirs():
+    """Where a model / whitening file named by a URL is looked for locally: ``$MDIR_AMD_MODELS`` (``:``-separated),
+    then ``<data root>/networks``."""
+    from .datasets import get_data_root
+    dirs = [d for d in os.environ.get("MDIR_AMD_MODELS", "").split(":") if d]
+    return dirs + [os.path.join(get_data_root(), "networks")]
+
+
 def open_resource(path):
-    """Bytes of a checkpoint / whitening file.  Local paths only: the reference also accepts URLs and
-    downloads them (``mdir/tools/utils.py:36-41``); fetching models is outside this build (the MI355X
-    boxes have no network), so a URL is answered with an error that says where to put the file."""
+    """Bytes of a checkpoint / whitening file.  The reference accepts URLs and downloads them (``load_url``,
+    ``mdir/tools/utils.py:36-41``); nothing is fetched here (the MI355X boxes have no network): a URL is answered
+    from a local copy of the same file NAME under ``resource_dirs()``, checked against the sha256 suffix of the name
+    exactly as the reference checks its download, and otherwise with an error that says where to put the file."""
     import io
     if path.startswith("http://") or path.startswith("https://"):
-        raise RuntimeError("'%s' is a URL: download it yourself and give the scenario the local path" % path)
+        name = path.rstrip("/").rsplit("/", 1)[-1]
+        for d in resource_dirs():
+            local = os.path.join(d, name)
+            if os.path.isfile(local):
+                with open(local, "rb") as handle:
+                    content = handle.read()
+                validate_hash(content, path)
+                return io.BytesIO(content)
+        raise RuntimeError("'%s' is a URL and nothing is downloaded here: put '%s' into one of %s (or give the scenario "
+                           "the local path)" % (path, name, resource_dirs()))
     with open(path, "rb") as handle:
         return io.BytesIO(handle.read())
 

@@ -12,7 +12,8 @@ rows, same printed lines.  What changed underneath (cirscore.py:54-71):
 The default ``ranking="positions"`` feeds compute_map from ``mdx_rank_of`` (identical APs --
 asserted in the tests and in bench.py -- without an N-long sort; the score object exposes
 nothing but the APs); ``ranking="full"`` runs the reference's dot + argsort + compute_map
-sequence literally.
+sequence literally.  ``storage="f16"`` (criterion key, not in the reference) keeps the database shard in
+fp16 for the fp16 MFMA -- BASELINE.json configs[4].
 """
 import os.path
 
@@ -45,6 +46,11 @@ class CirDatasetAp:
         self.transforms = initialize_transforms(params.pop("transforms"), params.pop("mean_std"))
         self.ranking = params.pop("ranking", "positions")
         assert self.ranking in {"full", "positions"}, self.ranking
+        # how the database shard is kept on the GPU: "f32" (the reference's arithmetic: exact k-ordered fp32 chain) or
+        # "f16" (BASELINE.json configs[4]: fp16 descriptors on the fp16 MFMA, fp32 accumulation; half the HBM bytes,
+        # scores within ~1e-3 relative: a looser, separately tested contract)
+        self.storage = params.pop("storage", "f32")
+        assert self.storage in {"f32", "f16"}, self.storage
         if isinstance(self.dataset, dict):
             assert self.dataset.keys() == {"name", "queries", "db", "imgdir"}
             imgdir = self.dataset["imgdir"]
@@ -74,7 +80,7 @@ class CirDatasetAp:
             print(">> {}: database + query images, rank {} of {}...".format(self.dataset, *_rank_world()))
             averages, scores_per_query = sharded_retrieval_map(
                 network, self.images, self.qimages, self.bbxs, self.gnd, self.dataset, self.image_size,
-                self.transforms, device, lap=stopwatch.lap)
+                self.transforms, device, lap=stopwatch.lap, storage=self.storage)
             self._log(logger, stopwatch, averages, scores_per_query)
             return
         print(">> {}: database images...".format(self.dataset))
@@ -90,7 +96,7 @@ class CirDatasetAp:
 
         print(">> {}: Evaluating...".format(self.dataset))
         with range_("%s/compute_score" % self.dataset):
-            index = ops.DescriptorIndex(vecs, "ND")
+            index = ops.DescriptorIndex(vecs, "ND", storage=self.storage)
             with range_("similarity"):
                 scores = index.scores(qvecs, "ND")                  # [Q,N] = (vecs.T @ qvecs).T
             if self.ranking == "full":

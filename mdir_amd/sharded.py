@@ -29,9 +29,9 @@ import torch.distributed as dist
 class HipBackend:
     """libmdx.so through mdir_amd.ops (the only backend the product ships)."""
 
-    def make_index(self, vecs, layout, row_offset):
+    def make_index(self, vecs, layout, row_offset, storage="f32"):
         from . import ops
-        return ops.DescriptorIndex(vecs, layout, row_offset)
+        return ops.DescriptorIndex(vecs, layout, row_offset, storage=storage)
 
     def rank_full(self, scores, id_offset=0):
         from . import ops
@@ -127,8 +127,10 @@ def chunk_bounds(lo, hi, chunks):
 
 
 class ShardedIndex:
-    def __init__(self, local_vecs, layout, n_total, group=None, backend=None):
+    def __init__(self, local_vecs, layout, n_total, group=None, backend=None, storage="f32"):
+        """``storage``: "f32" (exact chain) or "f16" (fp16 shard on the fp16 MFMA, BASELINE.json configs[4])."""
         self.group = group
+        self.storage = storage
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_total = int(n_total)
@@ -147,7 +149,8 @@ class ShardedIndex:
             else:
                 piece = (local_vecs[:, a - self.lo:b - self.lo] if dim_major else local_vecs[a - self.lo:b - self.lo])
                 piece = piece.contiguous()
-            self.parts.append((a, b, self.backend.make_index(piece, layout, a)))
+            self.parts.append((a, b, self.backend.make_index(piece, layout, a, storage) if storage != "f32"
+                               else self.backend.make_index(piece, layout, a)))
         self.index = self.parts[0][2] if self.chunks == 1 else None
         # RCCL moves device buffers directly; under gloo (CPU tests, or several ranks
         # sharing one GPU for a dry run) collectives are staged through host memory.
@@ -475,7 +478,7 @@ def _all_gather_uneven(pieces, mine, group):
 
 
 def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, transform, device,
-                          group=None, backend=None, lap=None, **kwargs):
+                          group=None, backend=None, lap=None, storage="f32", **kwargs):
     """Distributed form of ``CirDatasetAp.__call__`` (cirscore.py:49-71): every rank extracts its
     slice of the database (which stays resident as its shard) and its slice of the queries, query
     descriptors are all-gathered, similarities are computed against the local shard, and mAP comes
@@ -500,7 +503,7 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
     qvecs = gather_query_vectors(qlocal, len(qimages), group)
     if lap:
         lap("extract_descriptors")
-    index = ShardedIndex(vecs, "ND", len(images), group=group, backend=backend)
+    index = ShardedIndex(vecs, "ND", len(images), group=group, backend=backend, storage=storage)
     s_local = index.local_scores(qvecs.contiguous(), "ND")
 
     def one_map(g, kappas):

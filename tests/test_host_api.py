@@ -69,6 +69,9 @@ def test_eval_scenarios_parse_and_overlay():
         "whitening": "/tmp/mdir_synth/whiten.pkl", "dimensions": None}
     assert sc["network"]["runtime"]["wrappers"]["eval"]["1_cirmultiscale"] == {"scales": True}
     assert sc["validation"]["rparis6k"] is False and sc["validation"]["roxford5k"]["criterion"]["image_size"] == 1024
+    sc16 = evalcli.load_scenarios(["eval.yml", "eval_synthetic.yml", "eval_fp16.yml"])          # BASELINE.json configs[4]
+    assert sc16["validation"]["247tokyo1k"]["criterion"]["storage"] == "f16"
+    assert "storage" not in sc16["validation"]["roxford5k"]["criterion"] and sc16["validation"]["rparis6k"] is False
     assert sorted(evalcli.SCORES) == ["247tokyo1k/validation/score:ap_avg.4",
                                       "roxford5k/validation/score:ap_medium_avg.4",
                                       "rparis6k/validation/score:ap_medium_avg.4"]
@@ -343,6 +346,20 @@ def test_extract_vectors_and_score_end_to_end(fops, tmp_path, monkeypatch, capsy
     with torch.no_grad():
         score2(net, "cpu", lambda it, size, label, value, dtype: rows2.append((label, value)))
     assert rows2[1][1] == got_avg
+    # criterion key `storage` (BASELINE.json configs[4]): an fp16 shard is asked for through the same surface; with 9
+    # well-separated images the averages survive the input rounding; anything but f32 / f16 is refused
+    score3 = initialize_score({"type": "cirdatasetap", "image_size": 224, "dataset": "roxford5k", "storage": "f16",
+                               "transforms": "pil2np | totensor | normalize",
+                               "mean_std": net.network_params.runtime["data"]["mean_std"]})
+    assert score3.storage == "f16" and score.storage == "f32"
+    rows3 = []
+    with torch.no_grad():
+        score3(net, "cpu", lambda it, size, label, value, dtype: rows3.append((label, value)))
+    for k in ("map_easy", "map_medium", "map_hard"):
+        np.testing.assert_allclose(rows3[1][1][k], got_avg[k], atol=0.05)
+    with pytest.raises(AssertionError):
+        initialize_score({"type": "cirdatasetap", "image_size": 224, "dataset": "roxford5k", "storage": "bf16",
+                          "transforms": "pil2np | totensor | normalize", "mean_std": net.network_params.runtime["data"]["mean_std"]})
 
 
 def test_checkpoint_roundtrip_and_validate_tree(fops, tmp_path, monkeypatch):
@@ -546,17 +563,30 @@ def test_embed_stage_on_upstream_checkpoint(fops, tmp_path, monkeypatch):
         C.embed({"net": ckpt, "imgdir": str(imgdir), "bogus": 1}, (imgs,), device="cpu")
 
 
-def test_resources_are_local_files(tmp_path):
+def test_resources_are_local_files(tmp_path, monkeypatch):
     """Checkpoints and whitening files are read from local paths; a URL (the reference would download it,
-    mdir/tools/utils.py:36-41) is refused with a message, never fetched."""
-    from mdir_amd.scenario import open_resource
+    mdir/tools/utils.py:36-41) is never fetched: it is answered from a local file of the same name under
+    $MDIR_AMD_MODELS, validated against the sha256 suffix of the name as the reference validates its download
+    (utils.py:27-34), or refused with a message."""
+    import hashlib
+    from mdir_amd.scenario import open_resource, validate_hash
     from mdir_amd.wrapper import load_path
     payload = {"m": np.zeros((2, 1)), "P": np.eye(2)}
     with open(tmp_path / "lw.pkl", "wb") as f:
         pickle.dump(payload, f)
     assert np.array_equal(load_path(str(tmp_path / "lw.pkl"))["P"], np.eye(2))
+    monkeypatch.setenv("MDIR_AMD_MODELS", str(tmp_path / "models"))
     with pytest.raises(RuntimeError, match="is a URL"):
         open_resource("http://example.invalid/models/absent-12345678.pkl")
+    (tmp_path / "models").mkdir()
+    content = pickle.dumps(payload)
+    good = "lw-%s.pkl" % hashlib.sha256(content).hexdigest()[:8]
+    (tmp_path / "models" / good).write_bytes(content)
+    assert np.array_equal(load_path("https://example.invalid/whiten/" + good)["P"], np.eye(2))
+    (tmp_path / "models" / "lw-0123abcd.pkl").write_bytes(content)
+    with pytest.raises(ValueError, match="not consistent with stored hash"):
+        open_resource("https://example.invalid/whiten/lw-0123abcd.pkl")
+    validate_hash(content, "plain_name.pkl")            # no suffix, nothing to check
 
 
 def test_device_tail_detection_and_shape_order(tmp_path):

@@ -7,7 +7,7 @@
     <root>/whiten.pkl       {'P','m'} whitening
     <root>/eval_synth.yml   overlay for scenarios/eval.yml
 
-    python tools/make_synthetic_eval.py <root> [arch] && CIRTORCH_ROOT=<root> ./eval.py eval.yml <root>/eval_synth.yml
+    python tools/make_synthetic_eval.py <root> [arch [tokyo images]] && CIRTORCH_ROOT=<root> ./eval.py eval.yml <root>/eval_synth.yml
 """
 import os
 import pickle
@@ -34,7 +34,8 @@ def write_images(folder, names, rng, base):
         Image.fromarray(img).save(os.path.join(folder, name + ".jpg"), quality=92)
 
 
-def main(root, arch="alexnet"):
+def main(root, arch="alexnet", tokyo_n=15):
+    tokyo_n = int(tokyo_n)
     from mdir_amd.network import CirNetwork, SingleNetwork
     from mdir_amd.networks import init_network
     rng = np.random.default_rng(0)
@@ -51,9 +52,10 @@ def main(root, arch="alexnet"):
     with open(os.path.join(rox, "gnd_roxford5k.pkl"), "wb") as f:
         pickle.dump({"imlist": names, "qimlist": names[:nq], "gnd": gnd}, f)
     tok = os.path.join(root, "data", "test", "247tokyo1k")
-    tnames = ["tk%03d" % i for i in range(15)]
+    tnames = ["tk%03d" % i for i in range(tokyo_n)]
     write_images(os.path.join(tok, "jpg"), tnames, rng, base)
-    tgnd = [{"ok": [j for j in range(15) if j % len(base) == i % len(base) and j != i], "junk": [i], "bbx": None} for i in range(15)]
+    tgnd = [{"ok": [j for j in range(tokyo_n) if j % len(base) == i % len(base) and j != i], "junk": [i], "bbx": None}
+            for i in range(tokyo_n)]
     with open(os.path.join(tok, "gnd_247tokyo1k.pkl"), "wb") as f:
         pickle.dump({"imlist": tnames, "qimlist": tnames, "gnd": tgnd}, f)
 
