@@ -58,7 +58,7 @@ def test_f16_whitening_projection():
 
 def test_configs4_end_to_end_vgg16_multiscale_whitening_fp16(tmp_path):
     """BASELINE.json configs[4] through the product's scenario surface: VGG16-GeM (random init), 3 scales + learned
-    whitening (the cirwhiten / cirmultiscale wrapper chain), a 247tokyo1k-shaped set (query == database, the image
+    whitening (learned here from the set's descriptors; the cirwhiten / cirmultiscale wrapper chain), a 247tokyo1k-shaped set (query == database, the image
     itself in `junk`: cirscore.py:56-57), descriptors kept as fp16 (`criterion: {storage: f16}`, scenarios/eval_fp16.yml)
     against the fp32 shard.  Stated bounds: |mAP(fp16) - mAP(fp32)| <= 0.005; the two top-10 lists name the same ids in
     >= 97 % of the slots; every fp16 score within 2e-3 of the fp32 one."""
@@ -86,31 +86,43 @@ def test_configs4_end_to_end_vgg16_multiscale_whitening_fp16(tmp_path):
         sc["validation"].pop("roxford5k")               # configs[4] is the Tokyo 24/7 set
         return sc
 
+    # "learned whitening": PCA whitening (Arun's shrinkage) learned from the set's own multi-scale descriptors with the
+    # product's learner (whitenlearn.py:14-35 on mdx_gram_f64) -- a random-init trunk puts every image within 1e-3 of
+    # every other one, and only a whitening that removes the common mean makes this a retrieval problem
+    import pickle
+    from mdir_amd.whiten import pcawhitenlearn
+    raw = scenario(os.path.join(root, "eval_synth.yml"))
+    raw["network"]["runtime"]["wrappers"]["eval"].pop("0_cirwhiten")
+    cfg = configdataset("247tokyo1k", os.path.join(root, "data", "test"))
+    images = [cfg["im_fname"](cfg, i) for i in range(cfg["n"])]
+    net_raw = load_network(raw["network"], torch.device(DEV)).eval()
+    tr = initialize_transforms("pil2np | totensor | normalize", net_raw.network_params.runtime["data"]["mean_std"])
+    with torch.no_grad():
+        X = extract_vectors_device(net_raw, images, 320, tr, device=torch.device(DEV)).cpu().numpy().astype(np.float64).T
+    m, P = pcawhitenlearn(X, shrink=32, device=DEV)
+    with open(os.path.join(root, "whiten.pkl"), "wb") as f:
+        pickle.dump({"m": m, "P": np.real(P)}, f)
+
     key = "247tokyo1k/validation/score:ap_avg.4"
     map32 = stages.validate(scenario(os.path.join(root, "eval_synth.yml")), ())[0]["eval"][key]
     map16 = stages.validate(scenario(os.path.join(root, "eval_synth.yml"), "eval_fp16.yml"), ())[0]["eval"][key]
-    assert 0.05 < map32 < 0.999                                          # a non-trivial retrieval problem
-    assert abs(map16 - map32) <= 0.005, (map16, map32)
-
     # the same descriptors, both shards: score and top-10 agreement
     sc = scenario(os.path.join(root, "eval_synth.yml"))
     net = load_network(sc["network"], torch.device(DEV)).eval()
-    cfg = configdataset("247tokyo1k", os.path.join(root, "data", "test"))
-    images = [cfg["im_fname"](cfg, i) for i in range(cfg["n"])]
-    tr = initialize_transforms("pil2np | totensor | normalize", net.network_params.runtime["data"]["mean_std"]
-                               if "mean_std" in net.network_params.runtime.get("data", {}) else [net.meta["mean"], net.meta["std"]])
     with torch.no_grad():
         vecs = extract_vectors_device(net, images, 320, tr, device=torch.device(DEV))       # [N, 512]
     assert vecs.shape == (90, 512)
     s32 = ops.DescriptorIndex(vecs, "ND").scores(vecs, "ND")
     s16 = ops.DescriptorIndex(vecs, "ND", storage="f16").scores(vecs, "ND")
     worst = float((s32 - s16).abs().max())
-    assert worst <= 2e-3, worst
     t32, _ = ops.topk(s32, 10)
     t16, _ = ops.topk(s16, 10)
     agree = float((t32 == t16).float().mean())
-    assert agree >= 0.97, agree
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump({"map_fp32": map32, "map_fp16": map16, "max_abs_score_diff": worst, "top10_slot_agreement": agree},
                   open(os.path.join(out, "configs4_measured.json"), "w"))
+    assert 0.05 < map32 < 0.999, map32                                   # a non-trivial retrieval problem
+    assert abs(map16 - map32) <= 0.005, (map16, map32)
+    assert worst <= 2e-3, worst
+    assert agree >= 0.97, agree

@@ -1,4 +1,11 @@
-// The similarity kernel of libmdx.so (also built into tools/scores_ablate.hip for measurements).
+// PARKED (round 3): copy of mdir_amd/csrc/mdx_scores_kernel.h with the -DMDX_ABL_M32 switch: the 16x16x4 MFMAs of the
+// consumer loop replaced, TIMING ONLY (results are wrong), by the same cycles of v_mfma_f32_32x32x2_f32 with the same LDS
+// reads.  Measured on one box, same process, N = 1 004 993, Q = 70 (profiles/r03_summary.md): 2.55-2.56 ms (16x16x4, shipped)
+// against 2.67-2.72 ms (32x32x2); counter pass: MFMA pipe busy 77.9 % at 2.13 GHz against 77.0 % at 2.05 GHz.  Register
+// blocking, not the MFMA shape, sets the LDS bytes per flop ((rows + queries) / (rows x queries) per k), so the 32x32 form reads
+// exactly as much as the 16x16 form at the same 32 x 64 block per wave -- and it runs at a lower clock.  Not pursued.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools/attic_m32 ... : build tools/scores_ablate.hip with this file first on the
+//   include path as "mdx_scores_kernel.h" and -DMDX_ABL_M32.
 #pragma once
 #include "mdx_common.h"
 
@@ -171,6 +178,14 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     const int l_row = 4 * (lane >> 3) + (lane & 3);             // row inside the wave's 32 rows
     const int l_boff = (l_row >> 4) * KC * 64 + (l_row & 15);   // f32x4 offset of (tile, row) inside the wave's tiles
 
+#ifdef MDX_ABL_M32
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 big[(QT * R) / 4 > 0 ? (QT * R) / 4 : 1];
+#pragma unroll
+    for (int i = 0; i < (QT * R) / 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) big[i][e] = 0.f;
+#endif
     unsigned long long t_wait = 0, t_work = 0, ts0 = 0, ts1 = 0;      // STAMPS: diagnostic build only
     unsigned long long tr0 = 0, tc0 = 0;
     if (STAMPS) { tr0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory"); tc0 = ts0; }
@@ -205,6 +220,28 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                 // between the 16x16x4 MFMAs of step t+1, so that their operands (read at the top of the k-block)
                 // have landed long before; a small MFMA costs 8-9 cycles there, a dependent run of them 12.5 each
                 constexpr int PIN = 0x0002 | 0x0004 | 0x0070 | 0x0380 | 0x0400;
+#ifdef MDX_ABL_M32                  // tools/scores_ablate.hip -DMDX_ABL_M32, TIMING ONLY (wrong results): the R x QT 16x16x4 MFMAs of a
+                                   // k-step replaced by the same cycles of v_mfma_f32_32x32x2_f32 (QT/2 x R/2 tiles of 32 x 32, two
+                                   // k-pairs per step), same LDS reads, same interleaving of the one-k products
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int n_small = t == 0 ? 0 : (t == 3 ? 8 : 4);
+                    int done = 0;
+                    constexpr int NBIG = (QT * R) / 2;          // 32x32x2 MFMAs per k-step of 4 (64 cycles each)
+#pragma unroll
+                    for (int i = 0; i < NBIG; ++i) {
+                        big[i % ((QT * R) / 4)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i % QT][t], b[i % R][(t + i / QT) & 3], big[i % ((QT * R) / 4)], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(PIN);
+                        const int due = ((i + 1) * n_small) / NBIG;
+#pragma unroll
+                        for (; done < due; ++done) {
+                            const int st = (t == 3 && done >= 4) ? 3 : t - 1, g = done & 3;
+                            accl = __builtin_amdgcn_mfma_f32_4x4x1f32(al[g][st], bl[g][st], accl, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(PIN);
+                        }
+                    }
+                }
+#else
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int n_small = t == 0 ? 0 : (t == 3 ? 8 : 4);
@@ -224,12 +261,19 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                             }
                         }
                 }
+#endif
             }
         }
         // all LDS reads of this stage are consumed by the MFMAs above before the next barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (STAMPS) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); t_work += ts1 - ts0; ts0 = ts1; }
     }
+#ifdef MDX_ABL_M32
+#pragma unroll
+    for (int i = 0; i < (QT * R) / 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[(i * 4 + e / 4) / QT % R][(i * 4 + e / 4) % QT][e % 4] = big[i][e];
+#endif
     if (STAMPS && dbg && lane == 0) {       // diagnostic build only: wait / work cycles, loop cycles and 100 MHz ticks (in-kernel clock)
         unsigned long long *d = dbg + ((int64_t)blockIdx.x * CW + wave) * 8;
         d[0] = t_wait; d[1] = t_work; d[2] = ts0 - tc0; d[3] = __builtin_amdgcn_s_memrealtime() - tr0;
