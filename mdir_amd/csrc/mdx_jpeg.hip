@@ -486,14 +486,20 @@ static bool decode_scans(const uint8_t *d, int64_t size, JpegHeader &hd, const m
         int64_t q = br.p;
         for (;;) {
             while (q + 1 < size && !(d[q] == 0xFF && d[q + 1] != 0x00 && d[q + 1] != 0xFF && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7))) ++q;
-            if (q + 1 >= size) return true;                 // no end-of-image marker: what was decoded stands (as libjpeg, with a warning)
+            // the data ends without an end-of-image marker: libjpeg would insert one with a warning, but Pillow -- what the
+            // reference's loader calls -- reports such a file as truncated (a progressive file cut between two scans would
+            // otherwise come out as a partially refined picture): declined, the host decoder decides
+            if (q + 1 >= size) return false;
             const int m = d[q + 1];
             if (m == 0xD9) return true;
-            if (q + 4 > size) return true;
+            if (q + 4 > size) return false;
             const int sl = be16(d + q + 2);
             if (sl < 2 || q + 2 + sl > size) return false;
             if (m == 0xDA) { pos = q + 2; break; }
-            if (!(m == 0xDB || m == 0xC4 || m == 0xDD || m == 0xFE || (m >= 0xE0 && m <= 0xEF))) return false;   // libjpeg: unsupported marker
+            // a quantisation table redefined BETWEEN scans: libjpeg latches a component's table at that component's first
+            // scan, the tables handed to the device were copied before the scans were walked -- rare enough to decline
+            if (m == 0xDB) return false;
+            if (!(m == 0xC4 || m == 0xDD || m == 0xFE || (m >= 0xE0 && m <= 0xEF))) return false;   // libjpeg: unsupported marker
             if (!table_segment(hd, m, d + q + 4, sl - 2)) return false;
             q += 2 + sl;
         }

@@ -66,6 +66,11 @@ class ImagesFromList(data.Dataset):
         self.root, self.images, self.imsize, self.images_fn = root, images, imsize, images_fn
         self.bbxs, self.transform, self.loader, self.ignore_errors = bbxs, transform, loader, ignore_errors
         self.resize_on_device = resize_on_device
+        # items decoded on the device leave this object as JPEG coefficients: no crop, no resize and NO transform is
+        # applied to them here, so the only transform that may be configured is the one the device tail replaces
+        if decode_on_device and not (transform is None or isinstance(transform, ToUint8HWC)):
+            raise ValueError("decode_on_device=True hands JPEG coefficients to the device pipeline and cannot apply "
+                             "transform %r to them: use ToUint8HWC (or None)" % (transform,))
         self.decode_on_device = decode_on_device and (resize_on_device or imsize is None) and loader is default_loader
 
     def _coefficients(self, index):

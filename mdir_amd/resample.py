@@ -46,11 +46,60 @@ def thumbnail_size(width, height, imsize):
     return x, y
 
 
+_PILLOW_OK = None
+
+
+def pillow_agrees():
+    """One-time self-check against the INSTALLED Pillow: the size rule, the one-step rule and the 22-bit taps above restate
+    Pillow 12's ``thumbnail`` (``reducing_gap=2.0``); another Pillow may shrink in a different size or in two steps.  A few
+    small images are thumbnailed both ways on the host (numpy with this module's taps = the arithmetic ``mdx_resample_u8``
+    runs); on any difference the device route is switched off for the process and the loader resizes with Pillow, as the
+    reference does."""
+    global _PILLOW_OK
+    if _PILLOW_OK is None:
+        try:
+            from PIL import Image
+            rng = np.random.default_rng(0)
+            ok = True
+            for (w, h, imsize) in ((61, 47, 40), (50, 90, 33), (120, 31, 64)):
+                img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+                pil = Image.fromarray(img)
+                pil.thumbnail((imsize, imsize), getattr(Image, "LANCZOS", None) or Image.Resampling.LANCZOS)
+                size = thumbnail_size(w, h, imsize)
+                ok = ok and size == pil.size and np.array_equal(_host_resample(img, size), np.asarray(pil))
+            _PILLOW_OK = bool(ok)
+        except Exception:
+            _PILLOW_OK = False
+        if not _PILLOW_OK:
+            import warnings
+            warnings.warn("mdir_amd.resample: the installed Pillow thumbnails differently from the restated rule; "
+                          "images are resized by Pillow on the host")
+    return _PILLOW_OK
+
+
+def _host_resample(img, size):
+    """numpy form of the two ``mdx_resample_u8`` passes (width, then height) on one uint8 ``[H,W,C]`` image."""
+    out = img
+    for axis, target in ((1, size[0]), (0, size[1])):
+        if out.shape[axis] == target:
+            continue
+        bounds, taps = lanczos_taps(out.shape[axis], target)
+        x = np.moveaxis(out.astype(np.int64), axis, 0)
+        res = np.empty((target,) + x.shape[1:], dtype=np.uint8)
+        for o, (lo, cnt) in enumerate(bounds):
+            acc = np.tensordot(taps[o, :cnt].astype(np.int64), x[lo:lo + cnt], axes=(0, 0)) + (1 << (PRECISION_BITS - 1))
+            res[o] = np.clip(acc >> PRECISION_BITS, 0, 255)
+        out = np.moveaxis(res, 0, axis)
+    return out
+
+
 def on_device(width, height, imsize):
-    """Target ``(w, h)`` when the device should make this thumbnail, else ``None`` (nothing to do, or a case Pillow
-    handles in more than one LANCZOS step)."""
+    """Target ``(w, h)`` when the device should make this thumbnail, else ``None`` (nothing to do, a case Pillow
+    handles in more than one LANCZOS step, or an installed Pillow this module does not restate: ``pillow_agrees``)."""
     size = thumbnail_size(width, height, imsize)
     if size is None or size == (width, height):
+        return None
+    if not pillow_agrees():
         return None
     if int(width / size[0] / REDUCING_GAP) > 1 or int(height / size[1] / REDUCING_GAP) > 1:
         return None             # Image.resize first reduces by an integer factor

@@ -160,6 +160,14 @@ class ShardedIndex:
         self.reuse_buffers = False
         self._recv = {}                    # (chunk, elements) -> receive buffer of the exchange (reuse_buffers only)
         self.phases = None                 # events of the last rank_queries(): see phase_ms()
+        # MDIR_AMD_COMM=mdx: the exchange goes through libmdx's own RCCL communicator (mdx_exchange_scores /
+        # mdx_allgather_scores: the C-ABI form a non-Python host would call) on a side stream, instead of
+        # torch.distributed's all_to_all_single; the process group is then only used to hand out the communicator id.
+        self._comm = self._comm_stream = None
+        if os.environ.get("MDIR_AMD_COMM") == "mdx" and self.device.type == "cuda" and not self._host_staged:
+            from . import ops
+            self._comm = ops.Comm.from_process_group(self.device, group)
+            self._comm_stream = torch.cuda.Stream(device=self.device)
         self._use_a2a = self._probe_all_to_all()
 
     def _probe_all_to_all(self):
@@ -221,6 +229,20 @@ class ShardedIndex:
         compute stream overlap with it."""
         nq = s_part.shape[0]
         qlo, qhi = query_bounds(nq, self.world, self.rank)
+        if self._comm is not None:
+            # libmdx's communicator: enqueue on the side stream once the compute stream has produced s_part
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ready)
+                if self._use_a2a:
+                    blocks, _ = self._comm.exchange_scores(s_part, widths)
+                else:
+                    blocks = [b[qlo:qhi] for b in self._comm.allgather_scores(s_part, widths)]
+                done = torch.cuda.Event()
+                done.record()
+            s_part.record_stream(self._comm_stream)
+            return "mdx", blocks, done, s_part
         in_split = [(query_bounds(nq, self.world, r)[1] - query_bounds(nq, self.world, r)[0]) * s_part.shape[1]
                     for r in range(self.world)]
         out_split = [(qhi - qlo) * w for w in widths]
@@ -255,6 +277,11 @@ class ShardedIndex:
 
     def _finish_exchange(self, pending, widths, nq_mine):
         work, recv, host_recv, _send = pending
+        if isinstance(work, str):                     # "mdx": recv = the blocks, host_recv = the side stream's event
+            torch.cuda.current_stream().wait_event(host_recv)
+            for b in recv:
+                b.record_stream(torch.cuda.current_stream())
+            return recv
         if work is not None:
             work.wait()                               # compute stream waits for the collective
         if host_recv is not None:
@@ -286,7 +313,7 @@ class ShardedIndex:
         """Similarities of MY queries against ALL rows, as the column blocks the exchange delivers (global row order:
         peer-major, chunk-minor; block = ``[Q_mine, rows of that chunk]``): per chunk, similarity kernel then
         all-to-all, with chunk c's transfer overlapping chunk c+1's kernel."""
-        if self.world == 1:
+        if self.world == 1 and self._comm is None:
             s = self.local_scores(queries, qlayout)
             return [s], (0, s.shape[0])
         pending, nq = [], None
@@ -328,7 +355,7 @@ class ShardedIndex:
 
     def _events(self):
         """Four events on the compute stream around the phases of ``rank_queries`` (GPU only)."""
-        if self.device.type != "cuda" or self.world == 1:
+        if self.device.type != "cuda" or (self.world == 1 and self._comm is None):
             self.phases = None
         elif self.phases is None:
             self.phases = [torch.cuda.Event(enable_timing=True) for _ in range(4)]

@@ -194,3 +194,36 @@ def test_ranking_under_graph_capture(warm):
     LDS-order probe has not run: the ballot kernels are captured) and after an eager call -- replays bit-exact."""
     proc = subprocess.run([sys.executable, "-c", _CAPTURE_SCRIPT % {"root": ROOT, "warm": warm}], text=True, capture_output=True, timeout=900)
     assert proc.returncode == 0 and "CAPTURE-OK" in proc.stdout, proc.stderr[-3000:]
+
+
+_COMM_PATH_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from mdir_amd import ops
+from mdir_amd.sharded import ShardedIndex
+from oracle import chain as OC
+dev = "cuda:0"
+rng = np.random.default_rng(2)
+n, d, nq = 5000, 64, 9
+rows = rng.standard_normal((n, d)).astype(np.float32)
+rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+q = np.ascontiguousarray(rows[:nq].T + 0.01)
+sh = ShardedIndex(torch.from_numpy(rows).to(dev), "ND", n)
+assert sh._comm is not None and sh.chunks == 2
+for rep in range(3):
+    rk, sc, (qlo, qhi) = sh.rank_queries(torch.from_numpy(q).to(dev), "DN")
+    torch.cuda.synchronize()
+    want = OC.scores_chain(np.ascontiguousarray(rows.T), q)
+    assert (qlo, qhi) == (0, nq) and len(sc.blocks) == 2
+    assert np.array_equal(sc.dense().cpu().numpy(), want) and np.array_equal(rk.cpu().numpy(), OC.rank_full(want))
+assert sh.phase_ms() is not None
+print("COMM-PATH-OK")
+"""
+
+
+def test_sharded_index_through_the_mdx_communicator():
+    """MDIR_AMD_COMM=mdx: ShardedIndex moves its blocks with mdx_exchange_scores on a side stream (event-ordered with the
+    compute stream) -- exercised here with the one rank a 1-GPU box can hold and two row chunks."""
+    env = dict(os.environ, MDIR_AMD_COMM="mdx", MDIR_AMD_EXCHANGE_CHUNKS="2")
+    proc = subprocess.run([sys.executable, "-c", _COMM_PATH_SCRIPT % {"root": ROOT}], env=env, text=True, capture_output=True, timeout=600)
+    assert proc.returncode == 0 and "COMM-PATH-OK" in proc.stdout, proc.stderr[-3000:]

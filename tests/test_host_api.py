@@ -766,6 +766,14 @@ def test_loader_hands_jpeg_files_over_as_coefficients(tmp_path):
         assert torch.equal(ds[i], plain[i])
     assert isinstance(ImagesFromList(str(tmp_path), names, imsize=None, transform=ToUint8HWC(), decode_on_device=True)[0], JpegCoefficients)
     assert not isinstance(ImagesFromList(str(tmp_path), names, imsize=256, transform=ToUint8HWC(), decode_on_device=True)[0], JpegCoefficients)
+    # coefficients leave the loader untransformed: any transform but the one the device tail replaces is refused
+    from mdir_amd.datasets import initialize_transforms
+    with pytest.raises(ValueError, match="decode_on_device"):
+        ImagesFromList(str(tmp_path), names, imsize=None, decode_on_device=True,
+                       transform=initialize_transforms("pil2np | totensor | normalize", [[0.5] * 3, [0.2] * 3]))
+    # the size / one-step / taps rules restate THIS Pillow (checked once per process on small images)
+    from mdir_amd import resample
+    assert resample.pillow_agrees() is True
 
 
 def test_embedding_output_golden(golden):

@@ -373,6 +373,18 @@ def test_jpeg_restatement_is_pillow():
     whole = cases[12][1]                                                  # 640x480
     for cut in (len(whole) // 2, len(whole) - 3, 700):
         assert declined(whole[:cut])                                      # data runs out inside the scan
+    # a progressive file that ends after a complete scan (no further SOS, no EOI): Pillow calls it truncated, so does the
+    # host stage; same for a file that only lacks its end-of-image marker
+    prog = [d for name, d in cases if "prog" in name][0]
+    sos = [i for i in range(len(prog) - 1) if prog[i] == 0xFF and prog[i + 1] == 0xDA]
+    assert len(sos) >= 4
+    assert declined(prog[:sos[3]])
+    assert whole[-2:] == b"\xff\xd9" and declined(whole[:-2])
+    # a quantisation table redefined between two scans (libjpeg latches tables per component at its first scan)
+    dqt = prog.index(b"\xff\xdb")
+    seg = prog[dqt:dqt + 2 + int.from_bytes(prog[dqt + 2:dqt + 4], "big")]
+    assert declined(prog[:sos[1]] + seg + prog[sos[1]:])
+    assert not declined(prog)
     broken = bytearray(whole)
     for i in range(1000, len(broken), 997):
         broken[i] ^= 0x5A
