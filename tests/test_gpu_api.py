@@ -192,9 +192,9 @@ def test_full_size_ranking_properties(big):
     assert bool((rk[:, 1:][tie] > rk[:, :-1][tie]).all())
     # every query retrieves its (noisy) source row first
     assert bool((rk[:, 0].cpu() == big["qid"]).all())
-    # three full columns against the CPU oracle, bit-exact
-    for qi in (0, 33, 69):
-        np.testing.assert_array_equal(rk[qi].cpu().numpy(), OC.rank_full(sc[qi:qi + 1].cpu().numpy())[0])
+    # ALL 70 rankings against the C oracle, bit-exact (it sorts a million-row column in ~50 ms)
+    for q0 in range(0, nq, 14):
+        np.testing.assert_array_equal(rk[q0:q0 + 14].cpu().numpy(), OC.rank_full(sc[q0:q0 + 14].cpu().numpy()))
 
 
 def test_full_size_topk_rank_of_and_map(big):
