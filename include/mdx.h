@@ -105,6 +105,20 @@ int mdx_l2n_rows(float *x, int64_t R, int64_t D, const float *bias, float eps, v
 int mdx_bn_act(float *x, const float *residual, int64_t N, int64_t C, int64_t HW, const float *mean,
                const float *var, const float *weight, const float *bias, float eps, int relu, void *stream);
 
+/* 1x1 convolution with its epilogue, one kernel (stride 1, no padding, no groups, no conv bias):
+ *   out[b,co,p] = act( (sum_ci w[co,ci] * x[b,ci,p] - mean[co]) * weight[co] / sqrt(var[co] + eps) + bias[co]  (+ residual[b,co,p]) )
+ * = `self.bn1(self.conv1(x))` + relu and `self.bn3(self.conv3(out)); out += identity; relu` of the torchvision Bottleneck
+ * that cirtorch keeps as `features` (cirtorch/networks/imageretrievalnet.py:172-173; mdir_amd/backbones.py): the GEMM on
+ * the f32 matrix cores (v_mfma_f32_32x32x2_f32), the arithmetic of mdx_bn_act applied to the accumulators on their way out.
+ *   x [N,Cin,HW], out / residual [N,Cout,HW] (NCHW, contiguous; out must not alias x);  Cin % 16 == 0, Cout % 64 == 0
+ *   wt [Cin,Cout]: the weights TRANSPOSED, made once per convolution by mdx_conv1x1_transpose_weights(w [Cout,Cin])
+ *   mean/var, weight, bias, residual: optional as in mdx_bn_act.
+ * Accumulation order: ci ascending from +0 (a fixed order; the library convolution's differs by fp32 rounding). */
+int mdx_conv1x1_transpose_weights(const float *w, int64_t Cout, int64_t Cin, float *wt, void *stream);
+int mdx_conv1x1_bn_act(const float *x, const float *wt, int64_t N, int64_t Cin, int64_t Cout, int64_t HW, const float *mean,
+                       const float *var, const float *weight, const float *bias, float eps, const float *residual, int relu,
+                       float *out, void *stream);
+
 /* Input conversion: uint8 images [B,H,W,C] (C = 1 or 3, interleaved) -> fp32 [B,C,H,W] with
  *   out = (u / 255 - mean[c]) / std[c]            (fp32, IEEE divisions, this operation order)
  * = the `pil2np | totensor | normalize` transform chain of the scenarios (mdir/components/data/transform/

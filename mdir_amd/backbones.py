@@ -37,6 +37,27 @@ def _fused_trunk():
     return os.environ.get("MDIR_AMD_FUSED_TRUNK", "1") != "0"
 
 
+def _conv_bn_act(conv, bn, x, residual=None, relu=True):
+    """``relu(bn(conv(x)) + residual)``.  ``MDIR_AMD_CONV1X1=1`` sends stride-1 1x1 convolutions through libmdx's own
+    GEMM with the epilogue fused (``mdx_conv1x1_bn_act``: the convolution output is written once, finished).  OFF by
+    default: measured on the ResNet101 shapes (``tools/conv1x1_bench.py``, ``profiles/r03_conv1x1.md``) the library
+    GEMM behind MIOpen's 1x1 convolution runs at 75-133 TFLOP/s and the hand-written one at 47-93, which costs more
+    than the saved epilogue pass gains except on the memory-bound first layers."""
+    if (os.environ.get("MDIR_AMD_CONV1X1") == "1" and x.is_cuda and x.dtype == torch.float32 and not bn.training
+            and not torch.is_grad_enabled() and bn.track_running_stats and _fused_trunk()
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.bias is None):
+        from . import ops
+        if ops.conv1x1_supported(conv.in_channels, conv.out_channels):
+            wt = getattr(conv, "_mdx_wt", None)
+            if wt is None or wt[0] != conv.weight._version or wt[1].device != x.device:
+                wt = (conv.weight._version, ops.conv1x1_transpose_weights(conv.weight.detach().contiguous()))
+                conv._mdx_wt = wt
+            res = residual.contiguous() if residual is not None else None
+            return ops.conv1x1_bn_act(x.contiguous(), wt[1], bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, res, relu)
+    return _bn_act(conv(x), bn, residual, relu)
+
+
 def _downsample(mod, x):
     if isinstance(mod, nn.Sequential) and len(mod) == 2 and isinstance(mod[1], nn.BatchNorm2d):
         return _bn_act(mod[0](x), mod[1], None, relu=False)
@@ -77,9 +98,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else _downsample(self.downsample, x)
-        out = _bn_act(self.conv1(x), self.bn1)
+        out = _conv_bn_act(self.conv1, self.bn1, x)
         out = _bn_act(self.conv2(out), self.bn2)
-        return _bn_act(self.conv3(out), self.bn3, idt)
+        return _conv_bn_act(self.conv3, self.bn3, out, idt)
 
 
 class TrunkSequential(nn.Sequential):

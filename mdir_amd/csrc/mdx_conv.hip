@@ -1,0 +1,191 @@
+// 1x1 convolution of the trunk with its epilogue fused: conv -> inference batch-norm -> (+ residual) -> ReLU in ONE
+// kernel, fp32 on the f32-input matrix cores.
+//
+// A 1x1 convolution is a GEMM per image, out[b] [Cout, HW] = W [Cout, Cin] . x[b] [Cin, HW]: two of the three
+// convolutions of every torchvision Bottleneck (mdir_amd/backbones.py; the `features` cirtorch keeps,
+// cirtorch/networks/imageretrievalnet.py:172-173) and, on ResNet101, 30 % of the trunk's GPU time in library GEMMs of
+// 15-70 us each plus a full-tensor epilogue pass (mdx_bn_act) behind every one of them.  Here the accumulators go
+// through (v - mean) * gamma / sqrt(var + eps) + beta (+ identity) and ReLU on their way out: the convolution output is
+// written once, finished.
+//
+// Shapes are small (1-7 GFLOP per call), so what matters is filling 256 CUs evenly, not a steady state: tiles of
+// 64 output channels x 64 or 128 pixels, picked per call for the smaller imbalance; 4 waves = 2 x 2, each owning a
+// 32 x (32 or 64) block of v_mfma_f32_32x32x2_f32 accumulators; K in steps of 16 through double-buffered LDS, the next
+// step's global loads in flight under the current step's MFMAs (one barrier per step).  Both operands are held K-MAJOR
+// with the tile dimension contiguous -- x is [Cin][HW] already, the weights are transposed ONCE by the caller to
+// [Cin][Cout] -- so a fragment read is 32 consecutive words per k (row stride = 32 mod 64 words: the two k of a
+// step in different bank halves).  Accumulation order: ci ascending, one fma per ci from +0 (the MFMA is bitwise an fmaf
+// chain), i.e. a fixed order, not MIOpen's: results agree with the library path to fp32 rounding (tests: 2e-5 of the
+// output scale through a whole ResNet).
+#include "mdx_common.h"
+
+namespace mdx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte access at dword alignment
+
+constexpr int CV_MT = 64;       // output channels per workgroup
+constexpr int CV_KS = 16;       // input channels per step
+
+struct ConvBn {
+    const float *mean, *var, *weight, *bias;
+    float eps;
+};
+
+template <int NT>       // pixels per workgroup: 64 or 128
+__global__ __launch_bounds__(256, NT == 64 ? 3 : 2) void conv1x1_bn_act_kernel(
+    const float *__restrict__ x, const float *__restrict__ wt, const float *__restrict__ res, float *__restrict__ out,
+    int Cin, int Cout, int HW, int ntiles_p, ConvBn bn, int relu)
+{
+    constexpr int WS = CV_MT + 32;              // LDS row strides (words): = 32 mod 64
+    constexpr int XS = NT + 32;
+    constexpr int TN = NT / 64;                 // 32-column MFMA tiles per wave
+    constexpr int XV = NT / 64;                 // float4 loads of x per thread and step
+    __shared__ float Ws[2][CV_KS][WS];
+    __shared__ float Xs[2][CV_KS][XS];
+    __shared__ float s_mean[CV_MT], s_scale[CV_MT], s_shift[CV_MT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // blockIdx.x = (image, pixel tile) fastest over the channel tiles: the workgroups that share an x tile are neighbours
+    const int tile_m = blockIdx.x % (Cout / CV_MT);
+    const int tile_bp = blockIdx.x / (Cout / CV_MT);
+    const int b = tile_bp / ntiles_p, tp = tile_bp % ntiles_p;
+    const int co0 = tile_m * CV_MT, p0 = tp * NT;
+    const float *xb = x + (int64_t)b * Cin * HW;
+
+    if (tid < CV_MT) {
+        const int c = co0 + tid;
+        const float invstd = bn.var ? 1.0f / sqrtf(bn.var[c] + bn.eps) : 1.0f;
+        s_mean[tid] = bn.mean ? bn.mean[c] : 0.0f;
+        s_scale[tid] = bn.weight ? invstd * bn.weight[c] : invstd;
+        s_shift[tid] = bn.bias ? bn.bias[c] : 0.0f;
+    }
+
+    // loader roles: weights 16 rows x 64 channels = one float4 per thread; x 16 rows x NT pixels = XV float4 per thread
+    const int w_row = tid >> 4, w_col = (tid & 15) * 4;
+    const int x_col = (tid % (NT / 4)) * 4, x_row0 = tid / (NT / 4);          // rows x_row0 + v * (1024 / NT)
+    const bool x_full = p0 + x_col + 3 < HW;
+    f32x4u rw, rx[XV];
+    auto fetch = [&](int k0) {
+        rw = *(const f32x4u *)(wt + (int64_t)(k0 + w_row) * Cout + co0 + w_col);
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+            const float *src = xb + (int64_t)(k0 + x_row0 + v * (1024 / NT)) * HW + p0 + x_col;
+            if (x_full) {
+                rx[v] = *(const f32x4u *)src;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rx[v][e] = (p0 + x_col + e < HW) ? src[e] : 0.0f;
+            }
+        }
+    };
+    auto park = [&](int buf) {
+        *(float4 *)&Ws[buf][w_row][w_col] = *(float4 *)&rw;
+#pragma unroll
+        for (int v = 0; v < XV; ++v) *(float4 *)&Xs[buf][x_row0 + v * (1024 / NT)][x_col] = *(float4 *)&rx[v];
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+    const int nk = Cin / CV_KS;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    const int kh = lane >> 5, c32 = lane & 31;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) fetch((ks + 1) * CV_KS);           // in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < CV_KS / 2; ++kk) {
+            const float a = Ws[buf][2 * kk + kh][wm * 32 + c32];
+            float bv[TN];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bv[t] = Xs[buf][2 * kk + kh][wn * (NT / 2) + t * 32 + c32];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+        }
+        if (ks + 1 < nk) park(buf ^ 1);
+        __syncthreads();
+    }
+
+    // C/D of the 32x32 MFMA: col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (channel)
+    const int64_t ob = (int64_t)b * Cout * HW;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int p = p0 + wn * (NT / 2) + t * 32 + c32;
+        if (p >= HW) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int cl = wm * 32 + (v & 3) + 8 * (v >> 2) + 4 * kh;
+            const int64_t o = ob + (int64_t)(co0 + cl) * HW + p;
+            float y = fmaf(acc[t][v] - s_mean[cl], s_scale[cl], s_shift[cl]);
+            if (res) y += res[o];
+            out[o] = relu ? fmaxf(y, 0.0f) : y;
+        }
+    }
+}
+
+// [Cout, Cin] -> [Cin, Cout] (once per convolution, by the caller that owns the weights)
+__global__ void transpose_weights_kernel(const float *__restrict__ w, float *__restrict__ wt, int Cout, int Cin)
+{
+    __shared__ float tile[32][33];
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int co = co0 + r, ci = ci0 + threadIdx.x;
+        tile[r][threadIdx.x] = (co < Cout && ci < Cin) ? w[(int64_t)co * Cin + ci] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int ci = ci0 + r, co = co0 + threadIdx.x;
+        if (ci < Cin && co < Cout) wt[(int64_t)ci * Cout + co] = tile[threadIdx.x][r];
+    }
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+extern "C" {
+
+int mdx_conv1x1_transpose_weights(const float *w, int64_t Cout, int64_t Cin, float *wt, void *stream)
+{
+    MDX_CHECK_ARG(w && wt && Cout > 0 && Cin > 0 && Cout < (1 << 20) && Cin < (1 << 20), "mdx_conv1x1_transpose_weights: bad arguments");
+    hipLaunchKernelGGL(transpose_weights_kernel, dim3((unsigned)ceil_div(Cin, 32), (unsigned)ceil_div(Cout, 32)), dim3(32, 8), 0,
+                       (hipStream_t)stream, w, wt, (int)Cout, (int)Cin);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+int mdx_conv1x1_bn_act(const float *x, const float *wt, int64_t N, int64_t Cin, int64_t Cout, int64_t HW, const float *mean,
+                       const float *var, const float *weight, const float *bias, float eps, const float *residual, int relu,
+                       float *out, void *stream)
+{
+    MDX_CHECK_ARG(x && wt && out, "mdx_conv1x1_bn_act: NULL pointer");
+    MDX_CHECK_ARG((mean == nullptr) == (var == nullptr), "mdx_conv1x1_bn_act: mean and var must both be given or both be NULL");
+    MDX_CHECK_ARG(N > 0 && HW > 0 && Cin > 0 && Cout > 0, "mdx_conv1x1_bn_act: sizes must be positive");
+    MDX_CHECK_ARG(Cin % CV_KS == 0 && Cout % CV_MT == 0, "mdx_conv1x1_bn_act: Cin %% 16 and Cout %% 64 must be 0 (Cin=%lld Cout=%lld)",
+                  (long long)Cin, (long long)Cout);
+    MDX_CHECK_ARG(HW < (1ll << 30) && N * Cout * HW < (1ll << 40) && eps >= 0.0f, "mdx_conv1x1_bn_act: out of range");
+    const ConvBn bn{mean, var, weight, bias, eps};
+    // 64- or 128-pixel tiles: the one whose workgroups spread more evenly over the 256 CUs (rounds of 256 x occupancy)
+    const int64_t mt = Cout / CV_MT;
+    const int64_t g64 = N * ceil_div(HW, 64) * mt, g128 = N * ceil_div(HW, 128) * mt;
+    auto cost = [](int64_t wgs, int per_cu, double work) { return (double)ceil_div(wgs, (int64_t)256 * per_cu) * per_cu * work; };
+    const bool use128 = g128 >= 512 && cost(g128, 2, 2.0) <= cost(g64, 3, 1.0) * 1.02;
+    MDX_CHECK_ARG((use128 ? g128 : g64) < (1ll << 31), "mdx_conv1x1_bn_act: too many tiles");
+    if (use128)
+        hipLaunchKernelGGL(conv1x1_bn_act_kernel<128>, dim3((unsigned)g128), dim3(256), 0, (hipStream_t)stream, x, wt, residual, out,
+                           (int)Cin, (int)Cout, (int)HW, (int)ceil_div(HW, 128), bn, relu);
+    else
+        hipLaunchKernelGGL(conv1x1_bn_act_kernel<64>, dim3((unsigned)g64), dim3(256), 0, (hipStream_t)stream, x, wt, residual, out,
+                           (int)Cin, (int)Cout, (int)HW, (int)ceil_div(HW, 64), bn, relu);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+}  // extern "C"

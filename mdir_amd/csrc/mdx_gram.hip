@@ -44,26 +44,38 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double *__restrict_
     const double ca = (MODE == 0 && center && arow < M) ? center[arow] : 0.0;
     const double cb = (MODE == 0 && center && brow < N) ? center[brow] : 0.0;
 
+    typedef double f64x4u __attribute__((ext_vector_type(4), aligned(8)));    // one 32-byte access at 8-byte alignment
     double ra[4], rb[4];
-    auto fetch = [&](int64_t k0) {
+    // a row of 4 consecutive k (K-contiguous operand); whole quads take ONE 32-byte load instead of four guarded ones
+    auto quad = [&](const double *base, int64_t row, int64_t rows, int64_t k, double c, double (&r)[4]) {
+        if (row < rows && k + 3 < K) {
+            const f64x4u v = *(const f64x4u *)(base + row * K + k);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int64_t k = k0 + lk + e;
-            ra[e] = (arow < M && k < K) ? a[arow * K + k] - ca : 0.0;
+            for (int e = 0; e < 4; ++e) r[e] = v[e] - c;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (row < rows && k + e < K) ? base[row * K + k + e] - c : 0.0;
         }
+    };
+    auto fetch = [&](int64_t k0) {
+        quad(a, arow, M, k0 + lk, ca, ra);
         if (MODE == 0) {
+            if (bi == bj) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t k = k0 + lk + e;
-                rb[e] = (brow < N && k < K) ? a[brow * K + k] - cb : 0.0;
+                for (int e = 0; e < 4; ++e) rb[e] = ra[e];              // a diagonal tile multiplies its rows with themselves
+            } else {
+                quad(a, brow, N, k0 + lk, cb, rb);
             }
         } else {
-            const int64_t k = k0 + pk;
+            const int64_t k = k0 + pk, j = col0 + pj;
             const double ck = (center && k < K) ? center[k] : 0.0;
+            if (k < K && j + 3 < N) {
+                const f64x4u v = *(const f64x4u *)(b + k * N + j);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t j = col0 + pj + e;
-                rb[e] = (k < K && j < N) ? b[k * N + j] - ck : 0.0;
+                for (int e = 0; e < 4; ++e) rb[e] = v[e] - ck;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[e] = (k < K && j + e < N) ? b[k * N + j + e] - ck : 0.0;
             }
         }
     };

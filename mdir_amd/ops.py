@@ -268,6 +268,55 @@ def bn_act_(x, running_mean, running_var, weight=None, bias=None, eps=1e-5, resi
     return x
 
 
+def conv1x1_transpose_weights(weight):
+    """``[Cout, Cin(,1,1)]`` convolution weights -> the ``[Cin, Cout]`` copy ``conv1x1_bn_act`` reads (made once)."""
+    w = weight.reshape(weight.shape[0], -1)
+    wp = _dev(w, torch.float32, "weight")
+    wt = torch.empty((w.shape[1], w.shape[0]), dtype=torch.float32, device=w.device)
+    with _on(w):
+        check(_lib.lib().mdx_conv1x1_transpose_weights(wp, w.shape[0], w.shape[1], wt.data_ptr(), _stream()),
+              "mdx_conv1x1_transpose_weights")
+    return wt
+
+
+def conv1x1_supported(cin, cout):
+    return cin % 16 == 0 and cout % 64 == 0
+
+
+def conv1x1_bn_act(x, weight_t, running_mean, running_var, weight=None, bias=None, eps=1e-5, residual=None, relu=True):
+    """1x1 convolution + inference batch-norm (+ residual) (+ ReLU) in one kernel (``mdx_conv1x1_bn_act``).
+    ``x [N,Cin,H,W]`` contiguous fp32; ``weight_t [Cin,Cout]`` from ``conv1x1_transpose_weights``; returns ``[N,Cout,H,W]``."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise ValueError("conv1x1_bn_act expects a contiguous fp32 [N,C,H,W] CUDA/ROCm tensor (no CPU fallback)")
+    n, cin, h, w = x.shape
+    if weight_t.dim() != 2 or weight_t.shape[0] != cin or weight_t.dtype != torch.float32 or weight_t.device != x.device \
+            or not weight_t.is_contiguous():
+        raise ValueError("weight_t must be contiguous fp32 [Cin=%d, Cout] on %s" % (cin, x.device))
+    cout = weight_t.shape[1]
+    ptrs = []
+    for name, t in (("running_mean", running_mean), ("running_var", running_var), ("weight", weight), ("bias", bias)):
+        if t is None:
+            ptrs.append(None)
+            continue
+        if t.numel() != cout or t.dtype != torch.float32 or t.device != x.device or not t.is_contiguous():
+            raise ValueError("%s must be %d contiguous fp32 values on %s" % (name, cout, x.device))
+        ptrs.append(t.data_ptr())
+    rp = None
+    if residual is not None:
+        if tuple(residual.shape) != (n, cout, h, w) or residual.dtype != torch.float32 or residual.device != x.device \
+                or not residual.is_contiguous():
+            raise ValueError("residual must be contiguous fp32 [%d,%d,%d,%d]" % (n, cout, h, w))
+        rp = residual.data_ptr()
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    if out.numel() == 0:
+        return out
+    with _on(x):
+        check(_lib.lib().mdx_conv1x1_bn_act(x.data_ptr(), weight_t.data_ptr(), n, cin, cout, h * w, ptrs[0], ptrs[1], ptrs[2],
+                                            ptrs[3], float(eps), rp, 1 if relu else 0, out.data_ptr(), _stream()),
+              "mdx_conv1x1_bn_act")
+    return out
+
+
 # ----------------------------------------------------------------------- index
 
 class DescriptorIndex:

@@ -227,3 +227,52 @@ def test_sharded_index_through_the_mdx_communicator():
     env = dict(os.environ, MDIR_AMD_COMM="mdx", MDIR_AMD_EXCHANGE_CHUNKS="2")
     proc = subprocess.run([sys.executable, "-c", _COMM_PATH_SCRIPT % {"root": ROOT}], env=env, text=True, capture_output=True, timeout=600)
     assert proc.returncode == 0 and "COMM-PATH-OK" in proc.stdout, proc.stderr[-3000:]
+
+
+# ---------------------------------------------------------------- 1x1 convolution with the fused epilogue
+
+@pytest.mark.parametrize("n,cin,cout,h,w,res,relu,bn", [(1, 64, 64, 7, 9, False, True, True), (2, 256, 64, 33, 31, False, True, True),
+                                                       (4, 64, 256, 16, 16, True, True, True), (1, 1024, 256, 48, 64, False, True, True),
+                                                       (3, 256, 1024, 23, 17, True, False, True), (2, 16, 128, 5, 3, False, False, False),
+                                                       (1, 128, 512, 128, 96, True, True, True)])
+def test_conv1x1_bn_act_vs_float64(n, cin, cout, h, w, res, relu, bn):
+    """mdx_conv1x1_bn_act = relu(bn(conv1x1(x)) + identity) of the torchvision Bottleneck cirtorch keeps
+    (imageretrievalnet.py:172-173), against the same arithmetic in float64: fp32 rounding of a Cin-long fma chain."""
+    import torch.nn.functional as F
+    from mdir_amd import ops
+    torch.manual_seed(n + cin + cout)
+    x = torch.randn(n, cin, h, w, device=DEV)
+    wt = torch.randn(cout, cin, 1, 1, device=DEV) / cin ** 0.5
+    mean, var = (torch.randn(cout, device=DEV) * 0.1, torch.rand(cout, device=DEV) + 0.5) if bn else (None, None)
+    gamma, beta = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.1
+    idt = torch.randn(n, cout, h, w, device=DEV) if res else None
+    got = ops.conv1x1_bn_act(x, ops.conv1x1_transpose_weights(wt), mean, var, gamma, beta, 1e-5, idt, relu)
+    y = F.conv2d(x.double(), wt.double())
+    scale = gamma.double() / torch.sqrt(var.double() + 1e-5) if bn else gamma.double()
+    y = (y - (mean.double() if bn else torch.zeros(cout, device=DEV, dtype=torch.float64)).view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) \
+        + beta.double().view(1, -1, 1, 1)
+    if res:
+        y = y + idt.double()
+    if relu:
+        y = y.clamp_min(0)
+    assert float((got.double() - y).abs().max() / y.abs().max()) < 3e-6
+    with pytest.raises(ValueError):
+        ops.conv1x1_bn_act(x, ops.conv1x1_transpose_weights(wt)[:, :cout - 1].contiguous(), None, None)      # Cout % 64
+
+
+def test_trunk_with_own_1x1_convolutions_equals_library_trunk(monkeypatch):
+    """MDIR_AMD_CONV1X1=1 (opt-in): ResNet50 with its 1x1 convolutions on mdx_conv1x1_bn_act == the MIOpen trunk."""
+    from mdir_amd.backbones import TrunkSequential, build_features
+    torch.manual_seed(5)
+    feats = TrunkSequential(*build_features("resnet50")).eval()
+    for m in feats.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.2); m.bias.data.normal_(0, 0.1)
+    feats = feats.to(DEV)
+    x = torch.randn(2, 3, 203, 157, device=DEV)
+    with torch.no_grad():
+        plain = feats(x)
+        monkeypatch.setenv("MDIR_AMD_CONV1X1", "1")
+        own = feats(x)
+    assert float((own - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
+    assert not torch.equal(own, plain)                   # a different summation order: the own kernels did run
