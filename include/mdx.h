@@ -126,6 +126,19 @@ int mdx_conv1x1_bn_act(const float *x, const float *wt, int64_t N, int64_t Cin, 
 int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W, int C, const float *mean,
                   const float *std, float *out, void *stream);
 
+/* The paper's CLAHE pre-processing + input conversion: uint8 RGB images [B,H,W,3] -> normalised fp32 [B,3,H,W]
+ * = the `pil2np | apply_clahe[:clip[:lab[:grid]]] | totensor | normalize` chain of the CLAHE networks' checkpoints
+ * (mdir/components/data/transform/photometric_transforms.py:28-36 -> functional.ImageClahe.apply, functional.py:106-129):
+ * RGB -> Lab, CLAHE (clip limit, tiles_x x tiles_y grid) on the uint8 lightness, Lab -> RGB, (x - mean) / std.
+ * The reference calls OpenCV for all three steps; this restates OpenCV 4's published algorithms (clahe.cpp, color_lab.cpp)
+ * and is pinned against the same restatement in numpy (oracle.apply_clahe_rgb) only -- PARITY UNPINNED against OpenCV, which
+ * is absent from the build image.  mean, std: HOST arrays of 3 floats.  workspace: device scratch of
+ * mdx_clahe_workspace(B, H, W, tiles_x, tiles_y) bytes (the uint8 lightness plane, then the per-tile look-up tables
+ * [B, tiles_y, tiles_x, 256], both readable by the caller afterwards). */
+int64_t mdx_clahe_workspace(int64_t B, int64_t H, int64_t W, int tiles_x, int tiles_y);
+int mdx_clahe_u8_to_chw(const uint8_t *rgb, int64_t B, int64_t H, int64_t W, int clip_limit, int tiles_x, int tiles_y,
+                        const float *mean, const float *std, void *workspace, int64_t workspace_bytes, float *out, void *stream);
+
 /* The scaled copies of an image batch, every level in ONE launch:  src [B,C,H,W] fp32 -> outs[l] [B,C,floor(H*s_l),floor(W*s_l)]
  * = `F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False)` of CirMultiscaleAggregation.preprocess
  * (mdir/components/data/wrapper.py:104-107) and extract_ms (cirtorch/networks/imageretrievalnet.py:315), torch >= 1.6

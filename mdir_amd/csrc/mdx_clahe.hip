@@ -1,0 +1,246 @@
+// CLAHE pre-processing of the paper's "CLAHE N/D" networks on the device.
+//
+// Replaces the `apply_clahe` transform of the scenarios -- mdir/components/data/transform/photometric_transforms.py:28-36
+// -> functional.ImageClahe.apply (functional.py:106-129): on what `pil2np` makes of the image (float32 RGB in [0,1])
+//     spc = (cv2.cvtColor(img, COLOR_RGB2LAB) + [0,128,128]) / [100,255,255]
+//     spc[:,:,0] = cv2.createCLAHE(clipLimit, tileGridSize).apply((spc[:,:,0]*255).astype(uint8)) / 255
+//     img = cv2.cvtColor(spc*[100,255,255] - [0,128,128], COLOR_LAB2RGB)
+// followed by `totensor | normalize`.  OpenCV is third-party arithmetic that is neither under /root/reference nor in the
+// build image: the kernels restate OpenCV 4's published algorithms (imgproc/src/clahe.cpp: padding rule of
+// CLAHE_Impl::apply, CLAHE_CalcLut_Body, CLAHE_Interpolation_Body; color_lab.cpp: RGB2Lab_f / Lab2RGB_f, sRGB gamma, D65)
+// with exact transfer functions where OpenCV interpolates spline tables.  PARITY UNPINNED against OpenCV itself (no copy of
+// it exists here to generate vectors with); pinned against oracle.apply_clahe_rgb, the same restatement in numpy.
+//
+// Three launches per batch, all HBM / latency bound byte work:
+//   lightness   rgb u8 [B,H,W,3] -> L8 [B,H,W]           (1 read, 1/3 write)
+//   luts        L8 -> per-tile LUT u8 [B,ty,tx,256]      (one workgroup per tile: LDS histogram, clip, spread, prefix)
+//   apply       rgb + L8 + LUTs -> normalised fp32 CHW   (bilinear LUT blend, Lab -> RGB, (x - mean) / std)
+#include "mdx_common.h"
+
+namespace mdx {
+
+struct Lab { float L, a, b; };
+
+__device__ __forceinline__ float srgb_to_linear(float c)
+{
+    return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
+}
+
+__device__ __forceinline__ float linear_to_srgb(float c)
+{
+    return c <= 0.0031308f ? c * 12.92f : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+}
+
+__device__ __forceinline__ float lab_f(float t) { return t > 0.008856f ? cbrtf(t) : 7.787f * t + (float)(16.0 / 116.0); }
+
+// RGB2Lab_f on u8 / 255 (the values pil2np hands over); matrix rows divided by the D65 white point, in float as OpenCV does
+__device__ __forceinline__ Lab rgb8_to_lab(uint8_t r8, uint8_t g8, uint8_t b8)
+{
+    const float r = srgb_to_linear((float)r8 / 255.0f), g = srgb_to_linear((float)g8 / 255.0f), b = srgb_to_linear((float)b8 / 255.0f);
+    constexpr float m00 = (float)(0.412453 / 0.950456), m01 = (float)(0.357580 / 0.950456), m02 = (float)(0.180423 / 0.950456);
+    constexpr float m10 = 0.212671f, m11 = 0.715160f, m12 = 0.072169f;
+    constexpr float m20 = (float)(0.019334 / 1.088754), m21 = (float)(0.119193 / 1.088754), m22 = (float)(0.950227 / 1.088754);
+    // products summed left to right, each rounded to fp32 (no contraction: the numpy restatement does the same)
+    const float x = __fadd_rn(__fadd_rn(__fmul_rn(r, m00), __fmul_rn(g, m01)), __fmul_rn(b, m02));
+    const float y = __fadd_rn(__fadd_rn(__fmul_rn(r, m10), __fmul_rn(g, m11)), __fmul_rn(b, m12));
+    const float z = __fadd_rn(__fadd_rn(__fmul_rn(r, m20), __fmul_rn(g, m21)), __fmul_rn(b, m22));
+    const float fx = lab_f(x), fy = lab_f(y), fz = lab_f(z);
+    Lab o;
+    o.L = y > 0.008856f ? __fsub_rn(__fmul_rn(116.0f, fy), 16.0f) : __fmul_rn(903.3f, y);
+    o.a = __fmul_rn(500.0f, __fsub_rn(fx, fy));
+    o.b = __fmul_rn(200.0f, __fsub_rn(fy, fz));
+    return o;
+}
+
+// the uint8 lightness CLAHE sees: ((L + 0) / 100 * 255).astype(uint8) -- truncation (functional.py:117)
+__device__ __forceinline__ uint8_t lab_l8(float L) { return (uint8_t)(int)__fmul_rn(__fdiv_rn(L, 100.0f), 255.0f); }
+
+__global__ __launch_bounds__(256) void clahe_lightness_kernel(const uint8_t *__restrict__ rgb, int64_t npix, uint8_t *__restrict__ l8)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const Lab v = rgb8_to_lab(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    l8[i] = lab_l8(v.L);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i = (i < 0 ? -i : i) % period;
+    return i >= n ? period - i : i;
+}
+
+// one workgroup per (image, tile): histogram of the tile of the (virtually) padded plane, clip, spread, cumulative LUT
+__global__ __launch_bounds__(256) void clahe_lut_kernel(const uint8_t *__restrict__ l8, int H, int W, int tiles_x, int tiles_y,
+                                                        int tile_w, int tile_h, int clip, uint8_t *__restrict__ luts)
+{
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    __shared__ int s_clipped;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % (tiles_x * tiles_y), img = blockIdx.x / (tiles_x * tiles_y);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint8_t *plane = l8 + (int64_t)img * H * W;
+    hist[tid] = 0;
+    if (tid == 0) s_clipped = 0;
+    __syncthreads();
+    const int area = tile_w * tile_h;
+    for (int e = tid; e < area; e += 256) {
+        const int y = reflect101(ty * tile_h + e / tile_w, H), x = reflect101(tx * tile_w + e % tile_w, W);
+        atomicAdd(&hist[plane[(int64_t)y * W + x]], 1);
+    }
+    __syncthreads();
+    int v = hist[tid];
+    if (clip > 0) {
+        if (v > clip) {
+            atomicAdd(&s_clipped, v - clip);
+            v = clip;
+        }
+        __syncthreads();
+        const int clipped = s_clipped;
+        const int batch = clipped / 256, residual = clipped - batch * 256;
+        v += batch;
+        if (residual != 0) {
+            const int step = 256 / residual > 1 ? 256 / residual : 1;
+            // bins 0, step, 2 step, ... get one more, `residual` of them at most (and none beyond bin 255)
+            if (tid % step == 0 && tid / step < residual) v += 1;
+        }
+    }
+    // inclusive prefix over the 256 bins (Hillis-Steele in LDS: 8 steps)
+    scan[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int add = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    const float lut_scale = 255.0f / (float)area;
+    const float r = rintf(__fmul_rn((float)scan[tid], lut_scale));          // saturate_cast<uchar>: round half to even, clamp
+    luts[(int64_t)blockIdx.x * 256 + tid] = (uint8_t)fminf(fmaxf(r, 0.0f), 255.0f);
+}
+
+struct ClaheNorm { float mean[3], std[3]; };
+
+__global__ __launch_bounds__(256) void clahe_apply_kernel(const uint8_t *__restrict__ rgb, const uint8_t *__restrict__ l8,
+                                                          const uint8_t *__restrict__ luts, int H, int W, int tiles_x, int tiles_y,
+                                                          int tile_w, int tile_h, ClaheNorm nrm, float *__restrict__ out)
+{
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int img = blockIdx.y;
+    if (i >= hw) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    const int64_t pix = (int64_t)img * hw + i;
+    // CLAHE_Interpolation_Body
+    const float txf = __fsub_rn(__fmul_rn((float)x, 1.0f / (float)tile_w), 0.5f), tyf = __fsub_rn(__fmul_rn((float)y, 1.0f / (float)tile_h), 0.5f);
+    int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
+    const float xa = __fsub_rn(txf, (float)tx1), ya = __fsub_rn(tyf, (float)ty1);
+    const float xa1 = __fsub_rn(1.0f, xa), ya1 = __fsub_rn(1.0f, ya);
+    int tx2 = tx1 + 1, ty2 = ty1 + 1;
+    tx1 = tx1 < 0 ? 0 : tx1;
+    ty1 = ty1 < 0 ? 0 : ty1;
+    tx2 = tx2 > tiles_x - 1 ? tiles_x - 1 : tx2;
+    ty2 = ty2 > tiles_y - 1 ? tiles_y - 1 : ty2;
+    const int v = l8[pix];
+    const uint8_t *lt = luts + (int64_t)img * tiles_x * tiles_y * 256 + v;
+    const float l11 = lt[(ty1 * tiles_x + tx1) * 256], l12 = lt[(ty1 * tiles_x + tx2) * 256];
+    const float l21 = lt[(ty2 * tiles_x + tx1) * 256], l22 = lt[(ty2 * tiles_x + tx2) * 256];
+    const float top = __fadd_rn(__fmul_rn(l11, xa1), __fmul_rn(l12, xa)), bot = __fadd_rn(__fmul_rn(l21, xa1), __fmul_rn(l22, xa));
+    const float res = __fadd_rn(__fmul_rn(top, ya1), __fmul_rn(bot, ya));
+    const float l_new8 = fminf(fmaxf(rintf(res), 0.0f), 255.0f);
+    // back through the reference's normalised space: spc = (lab + [0,128,128]) / [100,255,255]; spc[0] = clahe / 255;
+    // lab' = spc * [100,255,255] - [0,128,128]   (float32 steps as written there)
+    const Lab lab = rgb8_to_lab(rgb[3 * pix], rgb[3 * pix + 1], rgb[3 * pix + 2]);
+    const float L = __fmul_rn(__fdiv_rn(l_new8, 255.0f), 100.0f);
+    const float a = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn(lab.a, 128.0f), 255.0f), 255.0f), 128.0f);
+    const float b = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn(lab.b, 128.0f), 255.0f), 255.0f), 128.0f);
+    // Lab2RGB_f
+    constexpr float lthresh = (float)(0.008856 * 903.3), fthresh = (float)(7.787 * 0.008856 + 16.0 / 116.0);
+    float fy, yy;
+    if (L <= lthresh) {
+        yy = __fdiv_rn(L, 903.3f);
+        fy = __fadd_rn(__fmul_rn(7.787f, yy), (float)(16.0 / 116.0));
+    } else {
+        fy = __fdiv_rn(__fadd_rn(L, 16.0f), 116.0f);
+        yy = __fmul_rn(__fmul_rn(fy, fy), fy);
+    }
+    const float fx = __fadd_rn(__fdiv_rn(a, 500.0f), fy), fz = __fsub_rn(fy, __fdiv_rn(b, 200.0f));
+    const float xx = fx <= fthresh ? __fdiv_rn(__fsub_rn(fx, (float)(16.0 / 116.0)), 7.787f) : __fmul_rn(__fmul_rn(fx, fx), fx);
+    const float zz = fz <= fthresh ? __fdiv_rn(__fsub_rn(fz, (float)(16.0 / 116.0)), 7.787f) : __fmul_rn(__fmul_rn(fz, fz), fz);
+    constexpr float k00 = (float)(3.240479 * 0.950456), k01 = -1.53715f, k02 = (float)(-0.498535 * 1.088754);
+    constexpr float k10 = (float)(-0.969256 * 0.950456), k11 = 1.875991f, k12 = (float)(0.041556 * 1.088754);
+    constexpr float k20 = (float)(0.055648 * 0.950456), k21 = -0.204043f, k22 = (float)(1.057311 * 1.088754);
+    float c[3];
+    c[0] = __fadd_rn(__fadd_rn(__fmul_rn(xx, k00), __fmul_rn(yy, k01)), __fmul_rn(zz, k02));
+    c[1] = __fadd_rn(__fadd_rn(__fmul_rn(xx, k10), __fmul_rn(yy, k11)), __fmul_rn(zz, k12));
+    c[2] = __fadd_rn(__fadd_rn(__fmul_rn(xx, k20), __fmul_rn(yy, k21)), __fmul_rn(zz, k22));
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float s = linear_to_srgb(fminf(fmaxf(c[ch], 0.0f), 1.0f));
+        // totensor (no scaling of a float image) | normalize: (x - mean) / std
+        out[((int64_t)img * 3 + ch) * hw + i] = __fdiv_rn(__fsub_rn(s, nrm.mean[ch]), nrm.std[ch]);
+    }
+}
+
+static void clahe_geometry(int H, int W, int tiles_x, int tiles_y, int *tile_w, int *tile_h)
+{
+    int eh = H, ew = W;
+    if (!(W % tiles_x == 0 && H % tiles_y == 0)) {      // OpenCV pads BOTH sides as soon as one does not divide
+        eh = H + (tiles_y - H % tiles_y);
+        ew = W + (tiles_x - W % tiles_x);
+    }
+    *tile_w = ew / tiles_x;
+    *tile_h = eh / tiles_y;
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+extern "C" {
+
+int64_t mdx_clahe_workspace(int64_t B, int64_t H, int64_t W, int tiles_x, int tiles_y)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || tiles_x <= 0 || tiles_y <= 0) return 0;
+    return round_up(B * H * W, 256) + round_up(B * (int64_t)tiles_x * tiles_y * 256, 256);
+}
+
+int mdx_clahe_u8_to_chw(const uint8_t *rgb, int64_t B, int64_t H, int64_t W, int clip_limit, int tiles_x, int tiles_y,
+                        const float *mean, const float *std, void *workspace, int64_t workspace_bytes, float *out, void *stream)
+{
+    MDX_CHECK_ARG(rgb && out && mean && std, "mdx_clahe_u8_to_chw: NULL pointer");
+    MDX_CHECK_ARG(B > 0 && H > 0 && W > 0 && H < (1 << 24) && W < (1 << 24) && B < 65536, "mdx_clahe_u8_to_chw: bad sizes");
+    MDX_CHECK_ARG(tiles_x >= 1 && tiles_y >= 1 && tiles_x <= 256 && tiles_y <= 256 && clip_limit >= 0, "mdx_clahe_u8_to_chw: bad grid or clip limit");
+    const int64_t need = mdx_clahe_workspace(B, H, W, tiles_x, tiles_y);
+    if (!workspace || workspace_bytes < need) {
+        set_error("mdx_clahe_u8_to_chw: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+        return MDX_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *l8 = (uint8_t *)workspace, *luts = l8 + round_up(B * H * W, 256);
+    int tw = 0, th = 0;
+    clahe_geometry((int)H, (int)W, tiles_x, tiles_y, &tw, &th);
+    const int area = tw * th;
+    int clip = 0;
+    if (clip_limit > 0) {
+        clip = (int)((double)clip_limit * area / 256);          // static_cast<int>(clipLimit_ * tileSizeTotal / histSize)
+        clip = clip > 1 ? clip : 1;
+    }
+    const int64_t npix = B * H * W;
+    hipLaunchKernelGGL(clahe_lightness_kernel, dim3((unsigned)ceil_div(npix, 256)), dim3(256), 0, s, rgb, npix, l8);
+    hipLaunchKernelGGL(clahe_lut_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(256), 0, s, l8, (int)H, (int)W, tiles_x, tiles_y, tw, th,
+                       clip, luts);
+    ClaheNorm nrm;
+    for (int c = 0; c < 3; ++c) {
+        nrm.mean[c] = mean[c];
+        nrm.std[c] = std[c];
+    }
+    hipLaunchKernelGGL(clahe_apply_kernel, dim3((unsigned)ceil_div(H * W, 256), (unsigned)B), dim3(256), 0, s, rgb, l8, luts, (int)H, (int)W,
+                       tiles_x, tiles_y, tw, th, nrm, out);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+}  // extern "C"

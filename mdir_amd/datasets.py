@@ -255,6 +255,25 @@ class Normalize:
         return out
 
 
+class ApplyClahe:
+    """``apply_clahe[:clip_limit[:colorspace[:grid_size]]]`` of the scenario DSL (``photometric_transforms.ApplyClahe``,
+    photometric_transforms.py:28-36; defaults 4 / lab / 8): CLAHE on the lightness of the image.  The reference runs it in
+    the loader workers through OpenCV; here it is device work (``mdx_clahe_u8_to_chw``, fused with ``totensor | normalize``,
+    see :meth:`Compose.device_tail`), so this object only carries the parameters: calling it on the host -- a transform
+    chain the device tail does not cover, or ``MDIR_AMD_GPU_PREPROCESS=0`` -- raises (no CPU fallback, and no OpenCV)."""
+
+    def __init__(self, clip_limit=4, colorspace="lab", grid_size=8):
+        self.clip_limit = int(clip_limit)
+        self.colorspace = str(colorspace).lower()
+        if self.colorspace != "lab":
+            raise NotImplementedError("apply_clahe: colorspace %r (only 'lab', the one the iccv19 scenarios use)" % colorspace)
+        self.grid_size = tuple(int(g) for g in grid_size) if isinstance(grid_size, (tuple, list)) else (int(grid_size), int(grid_size))
+
+    def __call__(self, *pics):
+        raise RuntimeError("apply_clahe runs on the MI355X only (chain `pil2np | apply_clahe | totensor | normalize` with "
+                           "MDIR_AMD_GPU_PREPROCESS on): there is no CPU fallback")
+
+
 class Compose:
     def __init__(self, transforms):
         self.transforms = transforms
@@ -270,11 +289,15 @@ class Compose:
         extraction then ships uint8 pixels and does this arithmetic on the GPU (``mdx_u8_to_chw``,
         same fp32 operation order).  ``None`` for any other chain."""
         t = list(self.transforms)
-        if len(t) == 3 and isinstance(t[0], Pil2Numpy):
+        clahe = None
+        if len(t) == 4 and isinstance(t[0], Pil2Numpy) and isinstance(t[1], ApplyClahe):
+            # the CLAHE networks' chain: a third element carries the CLAHE parameters (mdx_clahe_u8_to_chw does all of it)
+            clahe, t = {"clip_limit": t[1].clip_limit, "grid": t[1].grid_size}, t[2:]
+        elif len(t) == 3 and isinstance(t[0], Pil2Numpy):
             t = t[1:]
         if len(t) == 2 and isinstance(t[0], ToTensor) and isinstance(t[1], Normalize) and len(t[1].mean) == 3 \
                 and t[1].strict_shape:
-            return list(t[1].mean), list(t[1].std)
+            return (list(t[1].mean), list(t[1].std), clahe) if clahe else (list(t[1].mean), list(t[1].std))
         return None
 
 
@@ -285,7 +308,16 @@ class ToUint8HWC:
         return torch.from_numpy(np.array(pic.convert("RGB")))
 
 
-TRANSFORMS = {"totensor": ToTensor, "normalize": Normalize, "pil2np": Pil2Numpy}
+TRANSFORMS = {"totensor": ToTensor, "normalize": Normalize, "pil2np": Pil2Numpy, "apply_clahe": ApplyClahe}
+
+
+def device_convert(tail):
+    """The device half of a transform chain ``Compose.device_tail()`` recognised: uint8 ``[B,H,W,3]`` -> normalised fp32
+    ``[B,3,H,W]`` (``mdx_u8_to_chw``, or ``mdx_clahe_u8_to_chw`` for the CLAHE networks' chain)."""
+    from . import ops
+    if len(tail) > 2 and tail[2]:
+        return lambda u8: ops.clahe_u8_to_chw(u8, tail[2]["clip_limit"], tail[2]["grid"], tail[0], tail[1])
+    return lambda u8: ops.u8_to_chw(u8, tail[0], tail[1])
 
 
 def initialize_transforms(augmentations, mean_std):

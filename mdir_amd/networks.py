@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .backbones import OUTPUT_DIM, TrunkSequential, build_features
-from .datasets import ImagesFromList, ToUint8HWC, get_data_root, make_loader
+from .datasets import ImagesFromList, ToUint8HWC, device_convert, get_data_root, make_loader
 from .graphs import ShapeGraphs, graphs_enabled, parallel_map
 from .layers import POOLING, L2N, pool_kind
 from .jpeg import pixels as pixels_of
@@ -326,7 +326,8 @@ def extract_vectors_device(net, images, image_size, transform, bbxs=None, ms=[1]
         transform, from_tensor = ToUint8HWC(), describe
         resize_on_device = image_size is not None and os.environ.get("MDIR_AMD_GPU_RESIZE", "1") != "0"
         shrink = DeviceThumbnail(image_size) if resize_on_device else (lambda u8: u8)
-        describe = lambda u8: from_tensor(ops.u8_to_chw(shrink(u8), tail[0], tail[1]))
+        convert = device_convert(tail)
+        describe = lambda u8: from_tensor(convert(shrink(u8)))
     order = _Sequential(len(images))
     if graphs_enabled(device):
         describe = ShapeGraphs(describe)      # per input shape: eager once, then one hipGraph replay per call

@@ -194,6 +194,32 @@ def u8_to_chw(images, mean, std):
     return out
 
 
+def clahe_u8_to_chw(images, clip_limit, grid, mean, std, return_intermediates=False):
+    """uint8 RGB ``[B,H,W,3]`` device images -> CLAHE on the Lab lightness -> normalised fp32 ``[B,3,H,W]``
+    (``mdx_clahe_u8_to_chw``): the scenarios' ``pil2np | apply_clahe | totensor | normalize``.  ``grid``: int or
+    ``(tiles_x, tiles_y)``.  ``return_intermediates``: also the uint8 lightness ``[B,H,W]`` and the LUTs
+    ``[B,tiles_y,tiles_x,256]`` the kernels left in the workspace (tests)."""
+    if not (images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.is_contiguous() and images.shape[3] == 3):
+        raise ValueError("clahe_u8_to_chw expects a contiguous uint8 [B,H,W,3] CUDA/ROCm tensor (no CPU fallback)")
+    b, h, w, _ = images.shape
+    tx, ty = (int(grid), int(grid)) if not isinstance(grid, (tuple, list)) else (int(grid[0]), int(grid[1]))
+    if len(mean) != 3 or len(std) != 3:
+        raise ValueError("mean / std need 3 values")
+    out = torch.empty((b, 3, h, w), dtype=torch.float32, device=images.device)
+    need = _lib.lib().mdx_clahe_workspace(b, h, w, tx, ty)
+    ws = _workspace(need, images.device)
+    if images.numel():
+        arr = ctypes.c_float * 3
+        with _on(images):
+            check(_lib.lib().mdx_clahe_u8_to_chw(images.data_ptr(), b, h, w, int(clip_limit), tx, ty, arr(*[float(v) for v in mean]),
+                                                 arr(*[float(v) for v in std]), ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()),
+                  "mdx_clahe_u8_to_chw")
+    if return_intermediates:
+        plane = -(-(b * h * w) // 256) * 256
+        return out, ws[:b * h * w].view(b, h, w), ws[plane:plane + b * ty * tx * 256].view(b, ty, tx, 256)
+    return out
+
+
 def bilinear_pyramid(x, scales):
     """``[F.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False) for s in scales]`` for an fp32
     ``[B,C,H,W]`` device tensor, all levels in ONE launch (``mdx_bilinear_pyramid``); a scale of exactly 1 returns ``x``."""

@@ -123,7 +123,9 @@ def infer(params, data, device=None):
         from .resample import DeviceThumbnail
         resize_on_device = image_size is not None and os.environ.get("MDIR_AMD_GPU_RESIZE", "1") != "0"
         shrink = DeviceThumbnail(image_size) if resize_on_device else (lambda u8: u8)       # the LANCZOS thumbnail on the device
-        transform, describe = ToUint8HWC(), (lambda u8: network(ops.u8_to_chw(shrink(u8), tail[0], tail[1])))
+        from .datasets import device_convert
+        convert = device_convert(tail)
+        transform, describe = ToUint8HWC(), (lambda u8: network(convert(shrink(u8))))
     order = _Sequential(len(paths))
     if graphs_enabled(device):
         describe, order = ShapeGraphs(describe), ShapeOrder(paths, bbxs)

@@ -587,6 +587,136 @@ def jpeg_pixels(coef, quant, info):
     return np.clip(np.stack([r, g, b], axis=2), 0, 255).astype(np.uint8)
 
 
+# ---- the paper's CLAHE pre-processing, restated.  PARITY UNPINNED: the reference calls OpenCV (transform/functional.py:24-48,
+# 106-129: cv2.cvtColor(.., COLOR_RGB2LAB) on float32 RGB in [0,1], cv2.createCLAHE(clipLimit, tileGridSize).apply on the
+# uint8 lightness, cv2.cvtColor(.., COLOR_LAB2RGB)); OpenCV is not in the build image and not under /root/reference, so there is
+# nothing to generate golden vectors with.  What follows restates OpenCV 4's published algorithms (modules/imgproc/src/clahe.cpp:
+# CLAHE_CalcLut_Body, CLAHE_Interpolation_Body, the padding rule of CLAHE_Impl::apply; color_lab.cpp: RGB2Lab_f / Lab2RGB_f with
+# sRGB gamma, D65 white point) with exact transfer functions where OpenCV interpolates 1024-entry spline tables (difference
+# ~1e-6 in L, far below the uint8 quantisation that follows).  It pins the DEVICE implementation to this restatement only. ----
+
+_XYZ_FROM_RGB = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]], dtype=np.float64)
+_RGB_FROM_XYZ = np.array([[3.240479, -1.53715, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]], dtype=np.float64)
+_D65 = np.array([0.950456, 1.0, 1.088754], dtype=np.float64)
+
+
+def rgb_to_lab(rgb):
+    """float32 RGB in [0,1] ``[H,W,3]`` -> float32 (L 0..100, a, b): cv2.cvtColor(.., COLOR_RGB2LAB) for CV_32F input
+    (RGB2Lab_f: clip, sRGB linearisation, XYZ / white point, f(t) = cbrt(t) above 0.008856 else 7.787 t + 16/116)."""
+    c = np.clip(rgb.astype(F32), 0, 1)
+    lin = np.where(c <= F32(0.04045), c / F32(12.92), np.power((c + F32(0.055)) / F32(1.055), F32(2.4))).astype(F32)
+    m = (_XYZ_FROM_RGB / _D65[:, None]).astype(F32)
+    xyz = [(lin[..., 0] * m[i, 0] + lin[..., 1] * m[i, 1] + lin[..., 2] * m[i, 2]).astype(F32) for i in range(3)]
+    f = [np.where(v > F32(0.008856), np.cbrt(v).astype(F32), (F32(7.787) * v + F32(16.0 / 116.0)).astype(F32)).astype(F32) for v in xyz]
+    L = np.where(xyz[1] > F32(0.008856), F32(116.0) * f[1] - F32(16.0), F32(903.3) * xyz[1]).astype(F32)
+    return np.stack([L, (F32(500.0) * (f[0] - f[1])).astype(F32), (F32(200.0) * (f[1] - f[2])).astype(F32)], axis=-1)
+
+
+def lab_to_rgb(lab):
+    """float32 Lab -> float32 RGB in [0,1]: cv2.cvtColor(.., COLOR_LAB2RGB) (Lab2RGB_f: inverse f, XYZ * white point -> linear RGB,
+    clip, sRGB gamma)."""
+    L, a, b = (lab[..., i].astype(F32) for i in range(3))
+    lthresh, fthresh = F32(0.008856 * 903.3), F32(7.787 * 0.008856 + 16.0 / 116.0)
+    fy_hi = ((L + F32(16.0)) / F32(116.0)).astype(F32)
+    y = np.where(L <= lthresh, L / F32(903.3), fy_hi * fy_hi * fy_hi).astype(F32)
+    fy = np.where(L <= lthresh, F32(7.787) * y + F32(16.0 / 116.0), fy_hi).astype(F32)
+    fx, fz = (a / F32(500.0) + fy).astype(F32), (fy - b / F32(200.0)).astype(F32)
+    x = np.where(fx <= fthresh, (fx - F32(16.0 / 116.0)) / F32(7.787), fx * fx * fx).astype(F32)
+    z = np.where(fz <= fthresh, (fz - F32(16.0 / 116.0)) / F32(7.787), fz * fz * fz).astype(F32)
+    m = (_RGB_FROM_XYZ * _D65[None, :]).astype(F32)
+    out = []
+    for i in range(3):
+        lin = np.clip((x * m[i, 0] + y * m[i, 1] + z * m[i, 2]).astype(F32), 0, 1)
+        out.append(np.where(lin <= F32(0.0031308), lin * F32(12.92),
+                            F32(1.055) * np.power(lin, F32(1.0 / 2.4)) - F32(0.055)).astype(F32))
+    return np.stack(out, axis=-1)
+
+
+def _reflect101(i, n):
+    if n == 1:
+        return np.zeros_like(i)
+    period = 2 * (n - 1)
+    i = np.abs(i) % period
+    return np.where(i >= n, period - i, i)
+
+
+def clahe_luts(l8, clip_limit=4, grid=(8, 8)):
+    """Per-tile look-up tables of cv2.createCLAHE(clip_limit, grid).apply for a uint8 plane ``[H,W]``: returns
+    ``(luts uint8 [tiles_y, tiles_x, 256], (tile_h, tile_w))``.  clahe.cpp: when either side is not a multiple of the grid
+    the plane is padded on the bottom by ``ty - H % ty`` and on the right by ``tx - W % tx`` (BORDER_REFLECT_101; a side that
+    IS a multiple still gets a whole extra ``t`` -- OpenCV's rule); histogram per tile, clip at
+    ``max(int(clip * area / 256), 1)``, the excess spread evenly with the remainder at stride ``256 / residual``, LUT =
+    saturate_cast<uchar>(cumsum * 255 / area)."""
+    tx, ty = int(grid[0]), int(grid[1])
+    h, w = l8.shape
+    if w % tx == 0 and h % ty == 0:
+        ext = l8
+    else:
+        pb, pr = ty - h % ty, tx - w % tx
+        rows = _reflect101(np.arange(h + pb), h)
+        cols = _reflect101(np.arange(w + pr), w)
+        ext = l8[rows][:, cols]
+    th, tw = ext.shape[0] // ty, ext.shape[1] // tx
+    area = th * tw
+    lut_scale = F32(255.0) / F32(area)
+    clip = max(int(float(clip_limit) * area / 256), 1) if clip_limit > 0 else 0
+    luts = np.empty((ty, tx, 256), dtype=np.uint8)
+    for j in range(ty):
+        for i in range(tx):
+            hist = np.bincount(ext[j * th:(j + 1) * th, i * tw:(i + 1) * tw].reshape(-1), minlength=256).astype(np.int64)
+            if clip > 0:
+                clipped = int(np.maximum(hist - clip, 0).sum())
+                hist = np.minimum(hist, clip)
+                batch, residual = clipped // 256, clipped % 256
+                hist += batch
+                if residual:
+                    step = max(256 // residual, 1)
+                    k = 0
+                    while k < 256 and residual > 0:
+                        hist[k] += 1
+                        k += step
+                        residual -= 1
+            cum = np.cumsum(hist).astype(F32) * lut_scale
+            luts[j, i] = np.clip(np.rint(cum), 0, 255).astype(np.uint8)
+    return luts, (th, tw)
+
+
+def clahe_apply(l8, luts, tile):
+    """CLAHE_Interpolation_Body: bilinear blend of the four neighbouring tiles' LUTs at every pixel (tile centres at
+    ``(t + 0.5) * tile``; clamped at the border), ``saturate_cast<uchar>`` of the float32 result."""
+    ty, tx = luts.shape[:2]
+    th, tw = tile
+    h, w = l8.shape
+    xf = np.arange(w, dtype=F32) * (F32(1.0) / F32(tw)) - F32(0.5)
+    yf = np.arange(h, dtype=F32) * (F32(1.0) / F32(th)) - F32(0.5)
+    x1, y1 = np.floor(xf).astype(np.int64), np.floor(yf).astype(np.int64)
+    xa, ya = (xf - x1.astype(F32)).astype(F32), (yf - y1.astype(F32)).astype(F32)
+    x2, y2 = np.minimum(x1 + 1, tx - 1), np.minimum(y1 + 1, ty - 1)
+    x1, y1 = np.maximum(x1, 0), np.maximum(y1, 0)
+    v = l8.astype(np.int64)
+    l11 = luts[y1[:, None], x1[None, :], v].astype(F32)
+    l12 = luts[y1[:, None], x2[None, :], v].astype(F32)
+    l21 = luts[y2[:, None], x1[None, :], v].astype(F32)
+    l22 = luts[y2[:, None], x2[None, :], v].astype(F32)
+    xa1, ya1 = (F32(1.0) - xa)[None, :], (F32(1.0) - ya)[:, None]
+    res = (l11 * xa1 + l12 * xa[None, :]) * ya1 + (l21 * xa1 + l22 * xa[None, :]) * ya[:, None]
+    return np.clip(np.rint(res.astype(F32)), 0, 255).astype(np.uint8)
+
+
+def apply_clahe_rgb(rgb_u8, clip_limit=4, grid=8):
+    """``ApplyClahe`` of the scenarios (photometric_transforms.py:28-36 -> functional.ImageClahe.apply, colorspace "lab") on what
+    ``pil2np`` makes of a uint8 RGB image: returns ``(float32 RGB [H,W,3] in [0,1], lightness uint8 [H,W] before CLAHE)``."""
+    grid = (int(grid), int(grid)) if not isinstance(grid, tuple) else grid
+    img = rgb_u8.astype(F32) / F32(255.0)
+    lab = rgb_to_lab(img)
+    spc = ((lab + np.array([0, 128, 128], dtype=F32)) / np.array([100.0, 255.0, 255.0], dtype=F32)).astype(F32)
+    l8 = (spc[..., 0] * F32(255.0)).astype(np.uint8)                       # (chan*255).astype(np.uint8): truncation
+    luts, tile = clahe_luts(l8, int(clip_limit), grid)
+    spc[..., 0] = clahe_apply(l8, luts, tile).astype(F32) / F32(255.0)
+    back = (spc * np.array([100.0, 255.0, 255.0], dtype=F32)).astype(F32) - np.array([0, 128, 128], dtype=F32)
+    return lab_to_rgb(back.astype(F32)), l8
+
+
 def nanmean_metric(per_query):
     """The number eval.py prints: nan-filtered mean of the per-query rows
     (``mdir/tools/eventprocessor.py:101-115``)."""

@@ -136,6 +136,14 @@ def rank_count_(cnt, scores, id_offset, ref_scores, ref_ids, off_t):
     return cnt
 
 
+def clahe_u8_to_chw(images, clip_limit, grid, mean, std, return_intermediates=False):
+    outs = []
+    for img in images.numpy():
+        rgb, _ = O.apply_clahe_rgb(img, clip_limit, tuple(grid) if isinstance(grid, (tuple, list)) else int(grid))
+        outs.append(((rgb - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)).astype(np.float32).transpose(2, 0, 1))
+    return torch.from_numpy(np.stack(outs))
+
+
 def gram_f64(a, center=None):
     x = a.detach().numpy()
     if center is not None:
@@ -150,7 +158,7 @@ def project_f64(p, x, center=None):
     return torch.from_numpy(p.detach().numpy() @ xv)
 
 
-NAMES = ("gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "rank_full", "topk", "rank_of",
+NAMES = ("clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 

@@ -276,3 +276,64 @@ def test_trunk_with_own_1x1_convolutions_equals_library_trunk(monkeypatch):
         own = feats(x)
     assert float((own - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
     assert not torch.equal(own, plain)                   # a different summation order: the own kernels did run
+
+
+# ---------------------------------------------------------------- CLAHE pre-processing (f4; parity unpinned against OpenCV)
+
+@pytest.mark.parametrize("b,h,w,clip,grid", [(1, 64, 96, 4, 8), (2, 37, 53, 4, 8), (1, 240, 320, 2, (4, 6)), (1, 60, 96, 4, 8),
+                                             (1, 9, 7, 4, 8), (3, 128, 128, 0, 8), (1, 768, 1024, 4, 8)])
+def test_clahe_kernels_vs_restatement(b, h, w, clip, grid):
+    """mdx_clahe_u8_to_chw against oracle.apply_clahe_rgb (the same restatement of OpenCV's algorithm in numpy): the uint8
+    lightness may differ by one level where powf / cbrtf differ in the last bit at a truncation boundary (< 0.1 % of the
+    pixels); GIVEN the device's lightness plane the per-tile LUTs are bit-exact (integer work) and the output is within 2e-5."""
+    from oracle import oracle as O
+    from mdir_amd import ops
+    rng = np.random.default_rng(h * w + b)
+    base = rng.integers(0, 256, (b, h // 8 + 1, w // 8 + 1, 3))
+    img = np.clip(np.kron(base, np.ones((1, 8, 8, 1)))[:, :h, :w] + rng.normal(0, 12, (b, h, w, 3)), 0, 255).astype(np.uint8)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    out, l8, luts = ops.clahe_u8_to_chw(dev(img), clip, grid, mean, std, return_intermediates=True)
+    out, l8, luts = out.cpu().numpy(), l8.cpu().numpy(), luts.cpu().numpy()
+    g = grid if isinstance(grid, tuple) else (grid, grid)
+    for i in range(b):
+        want_rgb, want_l8 = O.apply_clahe_rgb(img[i], clip, g)
+        diff = l8[i].astype(int) - want_l8.astype(int)
+        assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 1e-3
+        want_luts, tile = O.clahe_luts(l8[i], clip, g)
+        np.testing.assert_array_equal(luts[i], want_luts)
+        # the rest of the chain on the device's own lightness plane
+        lab = O.rgb_to_lab(img[i].astype(np.float32) / np.float32(255))
+        spc = ((lab + np.array([0, 128, 128], np.float32)) / np.array([100, 255, 255], np.float32)).astype(np.float32)
+        spc[..., 0] = O.clahe_apply(l8[i], want_luts, tile).astype(np.float32) / np.float32(255)
+        rgb = O.lab_to_rgb(((spc * np.array([100, 255, 255], np.float32)).astype(np.float32) - np.array([0, 128, 128], np.float32)).astype(np.float32))
+        want = ((rgb - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1)
+        np.testing.assert_allclose(out[i], want, rtol=0, atol=2e-5)
+        if (diff == 0).all():
+            np.testing.assert_allclose(out[i], ((want_rgb - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1), rtol=0, atol=2e-5)
+
+
+def test_extraction_through_the_clahe_chain(tmp_path, monkeypatch):
+    """extract_vectors with the transform chain the CLAHE networks' checkpoints carry: file -> JPEG decode -> thumbnail -> CLAHE
+    + normalise (all on the device) -> network; equal to the same network fed the restated chain's tensors one by one."""
+    from PIL import Image
+    from oracle import oracle as O
+    from mdir_amd.datasets import initialize_transforms
+    from mdir_amd.networks import extract_vectors, init_network
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "2")
+    rng = np.random.default_rng(8)
+    names = []
+    for i, (w, h) in enumerate(((320, 240), (240, 320), (320, 240))):
+        pic = np.clip(np.kron(rng.integers(0, 255, (h // 16, w // 16, 3)), np.ones((16, 16, 1))) + rng.normal(0, 20, (h, w, 3)), 0, 255).astype(np.uint8)
+        names.append(str(tmp_path / ("im%d.jpg" % i)))
+        Image.fromarray(pic).save(names[-1], quality=90)
+    torch.manual_seed(3)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False}).eval().to(DEV)
+    tr = initialize_transforms("pil2np | apply_clahe | totensor | normalize", [net.meta["mean"], net.meta["std"]])
+    with torch.no_grad():
+        got = extract_vectors(net, names, 256, tr, device=torch.device(DEV)).numpy()       # [D, N]
+        for i, path in enumerate(names):
+            img = Image.open(path).convert("RGB")
+            img.thumbnail((256, 256), Image.LANCZOS)
+            rgb, _ = O.apply_clahe_rgb(np.array(img), 4, 8)
+            x = torch.from_numpy(((rgb - np.float32(net.meta["mean"])) / np.float32(net.meta["std"])).transpose(2, 0, 1)[None].copy()).to(DEV)
+            np.testing.assert_allclose(got[:, i], net(x).cpu().numpy().reshape(-1), atol=2e-4)

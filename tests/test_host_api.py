@@ -589,6 +589,30 @@ def test_resources_are_local_files(tmp_path, monkeypatch):
     validate_hash(content, "plain_name.pkl")            # no suffix, nothing to check
 
 
+def test_apply_clahe_in_the_transform_dsl(fops):
+    """`pil2np | apply_clahe | totensor | normalize` (the chain the CLAHE networks' checkpoints carry; transform/__init__.py:27,
+    photometric_transforms.py:28-36) parses, keeps the reference's defaults and argument order, and is recognised as a device
+    chain with the CLAHE parameters; on the host the transform refuses to run (device work, no OpenCV)."""
+    from mdir_amd.datasets import ApplyClahe, device_convert, initialize_transforms
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    tr = initialize_transforms("pil2np | apply_clahe | totensor | normalize", [mean, std])
+    assert tr.device_tail() == (mean, std, {"clip_limit": 4, "grid": (8, 8)})
+    tr2 = initialize_transforms("pil2np | apply_clahe:2:lab:4 | totensor | normalize", [mean, std])
+    assert tr2.device_tail()[2] == {"clip_limit": 2, "grid": (4, 4)}
+    assert initialize_transforms("pil2np | apply_clahe | totensor", [mean, std]).device_tail() is None
+    with pytest.raises(NotImplementedError):
+        ApplyClahe(4, "luv", 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ApplyClahe()(np.zeros((4, 4, 3), np.float32))
+    # the device half (oracle standing in): equals the restated reference chain
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (2, 40, 56, 3), dtype=np.uint8)
+    got = device_convert(tr.device_tail())(torch.from_numpy(img)).numpy()
+    for b in range(2):
+        rgb, _ = O.apply_clahe_rgb(img[b], 4, 8)
+        np.testing.assert_allclose(got[b], ((rgb - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1), rtol=0, atol=1e-6)
+
+
 def test_device_tail_detection_and_shape_order(tmp_path):
     """Only the exact PIL -> normalised tensor conversions are moved behind the H2D copy; any other
     chain stays on the host.  Equal-sized images are visited consecutively."""

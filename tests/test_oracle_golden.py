@@ -449,3 +449,30 @@ def test_jpeg_host_stage_on_damaged_files():
     finally:
         ImageFile.LOAD_TRUNCATED_IMAGES = old
     assert declined > 100 and same > 50 and differ <= max(2, same // 50), (same, differ, declined)
+
+
+def test_clahe_restatement_properties():
+    """The CLAHE restatement (OpenCV's published algorithm; PARITY UNPINNED against OpenCV itself, which is absent here) at
+    least has the algorithm's defining properties: Lab round trip, LUTs monotone with the clip limit honoured, identity
+    blending on a constant plane, OpenCV's padding rule, output in range."""
+    rng = np.random.default_rng(3)
+    x = rng.random((31, 45, 3), dtype=np.float32)
+    np.testing.assert_allclose(O.lab_to_rgb(O.rgb_to_lab(x)), x, atol=5e-5)
+    lab = O.rgb_to_lab(np.array([[[1, 1, 1], [0, 0, 0], [1, 0, 0]]], dtype=np.float32))
+    np.testing.assert_allclose(lab[0, 0], [100, 0, 0], atol=2e-3)                 # white
+    np.testing.assert_allclose(lab[0, 1], [0, 0, 0], atol=1e-5)                   # black
+    np.testing.assert_allclose(lab[0, 2], [53.24, 80.09, 67.20], atol=2e-2)       # sRGB red (published Lab value)
+    l8 = rng.integers(0, 256, (64, 96), dtype=np.uint8)
+    luts, tile = O.clahe_luts(l8, 4, (8, 8))
+    assert tile == (8, 12) and luts.shape == (8, 8, 256)
+    assert (np.diff(luts.astype(np.int32), axis=2) >= 0).all() and (luts[..., -1] == 255).all()
+    # slope bound: a bin holds at most clip + spread pixels -> LUT steps of at most (clip + 2) * 255 / area
+    clip = max(int(4 * 96 / 256), 1)
+    assert np.diff(luts.astype(np.int32), axis=2).max() <= np.ceil((clip + 2) * 255 / 96) + 1
+    # a side that is not a multiple of the grid pads BOTH sides (OpenCV's rule): 60 x 96 -> tiles of (64/8, 104/8)
+    assert O.clahe_luts(rng.integers(0, 256, (60, 96), dtype=np.uint8), 4, (8, 8))[1] == (8, 13)
+    const = np.full((64, 64), 77, dtype=np.uint8)
+    lc, tc = O.clahe_luts(const, 4, (8, 8))
+    assert len(np.unique(O.clahe_apply(const, lc, tc))) == 1                       # every tile has the same LUT
+    out, _ = O.apply_clahe_rgb(rng.integers(0, 256, (37, 53, 3), dtype=np.uint8))
+    assert out.dtype == np.float32 and out.min() >= 0 and out.max() <= 1
