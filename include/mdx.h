@@ -133,8 +133,9 @@ int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W, int C, co
  * The reference calls OpenCV for all three steps; this restates OpenCV 4's published algorithms (clahe.cpp, color_lab.cpp)
  * and is pinned against the same restatement in numpy (oracle.apply_clahe_rgb) only -- PARITY UNPINNED against OpenCV, which
  * is absent from the build image.  mean, std: HOST arrays of 3 floats.  workspace: device scratch of
- * mdx_clahe_workspace(B, H, W, tiles_x, tiles_y) bytes (the uint8 lightness plane, then the per-tile look-up tables
- * [B, tiles_y, tiles_x, 256], both readable by the caller afterwards). */
+ * mdx_clahe_workspace(B, H, W, tiles_x, tiles_y) bytes (the uint8 lightness plane [B,H,W], the per-tile look-up tables
+ * [B, tiles_y, tiles_x, 256], the equalised lightness plane [B,H,W]; each region starts at a multiple of 256 bytes and is
+ * readable by the caller afterwards). */
 int64_t mdx_clahe_workspace(int64_t B, int64_t H, int64_t W, int tiles_x, int tiles_y);
 int mdx_clahe_u8_to_chw(const uint8_t *rgb, int64_t B, int64_t H, int64_t W, int clip_limit, int tiles_x, int tiles_y,
                         const float *mean, const float *std, void *workspace, int64_t workspace_bytes, float *out, void *stream);

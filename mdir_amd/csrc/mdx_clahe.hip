@@ -17,7 +17,18 @@
 //   apply       rgb + L8 + LUTs -> normalised fp32 CHW   (bilinear LUT blend, Lab -> RGB, (x - mean) / std)
 #include "mdx_common.h"
 
+// Every product and sum below is rounded on its own, as in OpenCV's scalar code (and in the numpy restatement): hipcc's
+// default contraction would fuse a*b + c*d into an fma and move the interpolation's exact .5 ties (HIP's __fmul_rn /
+// __fadd_rn are plain operators inlined from a header compiled WITH contraction, so they do not stop it: the helpers below do).
+#pragma clang fp contract(off)
+
 namespace mdx {
+
+// defined HERE, under the pragma (the HIP header versions are inlined with the contraction flags of their own scope)
+__device__ __forceinline__ float mul_(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_(float a, float b) { return a - b; }
+__device__ __forceinline__ float div_(float a, float b) { return a / b; }
 
 struct Lab { float L, a, b; };
 
@@ -41,19 +52,19 @@ __device__ __forceinline__ Lab rgb8_to_lab(uint8_t r8, uint8_t g8, uint8_t b8)
     constexpr float m10 = 0.212671f, m11 = 0.715160f, m12 = 0.072169f;
     constexpr float m20 = (float)(0.019334 / 1.088754), m21 = (float)(0.119193 / 1.088754), m22 = (float)(0.950227 / 1.088754);
     // products summed left to right, each rounded to fp32 (no contraction: the numpy restatement does the same)
-    const float x = __fadd_rn(__fadd_rn(__fmul_rn(r, m00), __fmul_rn(g, m01)), __fmul_rn(b, m02));
-    const float y = __fadd_rn(__fadd_rn(__fmul_rn(r, m10), __fmul_rn(g, m11)), __fmul_rn(b, m12));
-    const float z = __fadd_rn(__fadd_rn(__fmul_rn(r, m20), __fmul_rn(g, m21)), __fmul_rn(b, m22));
+    const float x = add_(add_(mul_(r, m00), mul_(g, m01)), mul_(b, m02));
+    const float y = add_(add_(mul_(r, m10), mul_(g, m11)), mul_(b, m12));
+    const float z = add_(add_(mul_(r, m20), mul_(g, m21)), mul_(b, m22));
     const float fx = lab_f(x), fy = lab_f(y), fz = lab_f(z);
     Lab o;
-    o.L = y > 0.008856f ? __fsub_rn(__fmul_rn(116.0f, fy), 16.0f) : __fmul_rn(903.3f, y);
-    o.a = __fmul_rn(500.0f, __fsub_rn(fx, fy));
-    o.b = __fmul_rn(200.0f, __fsub_rn(fy, fz));
+    o.L = y > 0.008856f ? sub_(mul_(116.0f, fy), 16.0f) : mul_(903.3f, y);
+    o.a = mul_(500.0f, sub_(fx, fy));
+    o.b = mul_(200.0f, sub_(fy, fz));
     return o;
 }
 
 // the uint8 lightness CLAHE sees: ((L + 0) / 100 * 255).astype(uint8) -- truncation (functional.py:117)
-__device__ __forceinline__ uint8_t lab_l8(float L) { return (uint8_t)(int)__fmul_rn(__fdiv_rn(L, 100.0f), 255.0f); }
+__device__ __forceinline__ uint8_t lab_l8(float L) { return (uint8_t)(int)mul_(div_(L, 100.0f), 255.0f); }
 
 __global__ __launch_bounds__(256) void clahe_lightness_kernel(const uint8_t *__restrict__ rgb, int64_t npix, uint8_t *__restrict__ l8)
 {
@@ -116,8 +127,8 @@ __global__ __launch_bounds__(256) void clahe_lut_kernel(const uint8_t *__restric
         scan[tid] += add;
         __syncthreads();
     }
-    const float lut_scale = 255.0f / (float)area;
-    const float r = rintf(__fmul_rn((float)scan[tid], lut_scale));          // saturate_cast<uchar>: round half to even, clamp
+    const float lut_scale = div_(255.0f, (float)area);
+    const float r = rintf(mul_((float)scan[tid], lut_scale));          // saturate_cast<uchar>: round half to even, clamp
     luts[(int64_t)blockIdx.x * 256 + tid] = (uint8_t)fminf(fmaxf(r, 0.0f), 255.0f);
 }
 
@@ -125,7 +136,8 @@ struct ClaheNorm { float mean[3], std[3]; };
 
 __global__ __launch_bounds__(256) void clahe_apply_kernel(const uint8_t *__restrict__ rgb, const uint8_t *__restrict__ l8,
                                                           const uint8_t *__restrict__ luts, int H, int W, int tiles_x, int tiles_y,
-                                                          int tile_w, int tile_h, ClaheNorm nrm, float *__restrict__ out)
+                                                          int tile_w, int tile_h, ClaheNorm nrm, uint8_t *__restrict__ l8_out,
+                                                          float *__restrict__ out)
 {
     const int64_t hw = (int64_t)H * W;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -134,10 +146,12 @@ __global__ __launch_bounds__(256) void clahe_apply_kernel(const uint8_t *__restr
     const int y = (int)(i / W), x = (int)(i % W);
     const int64_t pix = (int64_t)img * hw + i;
     // CLAHE_Interpolation_Body
-    const float txf = __fsub_rn(__fmul_rn((float)x, 1.0f / (float)tile_w), 0.5f), tyf = __fsub_rn(__fmul_rn((float)y, 1.0f / (float)tile_h), 0.5f);
+    // inv_tw = 1.0f / tileSize.width as an IEEE division (a plain `/` may become v_rcp_f32: one ulp off flips exact .5 ties below)
+    const float txf = sub_(mul_((float)x, div_(1.0f, (float)tile_w)), 0.5f);
+    const float tyf = sub_(mul_((float)y, div_(1.0f, (float)tile_h)), 0.5f);
     int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
-    const float xa = __fsub_rn(txf, (float)tx1), ya = __fsub_rn(tyf, (float)ty1);
-    const float xa1 = __fsub_rn(1.0f, xa), ya1 = __fsub_rn(1.0f, ya);
+    const float xa = sub_(txf, (float)tx1), ya = sub_(tyf, (float)ty1);
+    const float xa1 = sub_(1.0f, xa), ya1 = sub_(1.0f, ya);
     int tx2 = tx1 + 1, ty2 = ty1 + 1;
     tx1 = tx1 < 0 ? 0 : tx1;
     ty1 = ty1 < 0 ? 0 : ty1;
@@ -147,40 +161,41 @@ __global__ __launch_bounds__(256) void clahe_apply_kernel(const uint8_t *__restr
     const uint8_t *lt = luts + (int64_t)img * tiles_x * tiles_y * 256 + v;
     const float l11 = lt[(ty1 * tiles_x + tx1) * 256], l12 = lt[(ty1 * tiles_x + tx2) * 256];
     const float l21 = lt[(ty2 * tiles_x + tx1) * 256], l22 = lt[(ty2 * tiles_x + tx2) * 256];
-    const float top = __fadd_rn(__fmul_rn(l11, xa1), __fmul_rn(l12, xa)), bot = __fadd_rn(__fmul_rn(l21, xa1), __fmul_rn(l22, xa));
-    const float res = __fadd_rn(__fmul_rn(top, ya1), __fmul_rn(bot, ya));
+    const float top = add_(mul_(l11, xa1), mul_(l12, xa)), bot = add_(mul_(l21, xa1), mul_(l22, xa));
+    const float res = add_(mul_(top, ya1), mul_(bot, ya));
     const float l_new8 = fminf(fmaxf(rintf(res), 0.0f), 255.0f);
+    l8_out[pix] = (uint8_t)l_new8;                  // the equalised lightness, kept for the caller (1 byte per pixel)
     // back through the reference's normalised space: spc = (lab + [0,128,128]) / [100,255,255]; spc[0] = clahe / 255;
     // lab' = spc * [100,255,255] - [0,128,128]   (float32 steps as written there)
     const Lab lab = rgb8_to_lab(rgb[3 * pix], rgb[3 * pix + 1], rgb[3 * pix + 2]);
-    const float L = __fmul_rn(__fdiv_rn(l_new8, 255.0f), 100.0f);
-    const float a = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn(lab.a, 128.0f), 255.0f), 255.0f), 128.0f);
-    const float b = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn(lab.b, 128.0f), 255.0f), 255.0f), 128.0f);
+    const float L = mul_(div_(l_new8, 255.0f), 100.0f);
+    const float a = sub_(mul_(div_(add_(lab.a, 128.0f), 255.0f), 255.0f), 128.0f);
+    const float b = sub_(mul_(div_(add_(lab.b, 128.0f), 255.0f), 255.0f), 128.0f);
     // Lab2RGB_f
     constexpr float lthresh = (float)(0.008856 * 903.3), fthresh = (float)(7.787 * 0.008856 + 16.0 / 116.0);
     float fy, yy;
     if (L <= lthresh) {
-        yy = __fdiv_rn(L, 903.3f);
-        fy = __fadd_rn(__fmul_rn(7.787f, yy), (float)(16.0 / 116.0));
+        yy = div_(L, 903.3f);
+        fy = add_(mul_(7.787f, yy), (float)(16.0 / 116.0));
     } else {
-        fy = __fdiv_rn(__fadd_rn(L, 16.0f), 116.0f);
-        yy = __fmul_rn(__fmul_rn(fy, fy), fy);
+        fy = div_(add_(L, 16.0f), 116.0f);
+        yy = mul_(mul_(fy, fy), fy);
     }
-    const float fx = __fadd_rn(__fdiv_rn(a, 500.0f), fy), fz = __fsub_rn(fy, __fdiv_rn(b, 200.0f));
-    const float xx = fx <= fthresh ? __fdiv_rn(__fsub_rn(fx, (float)(16.0 / 116.0)), 7.787f) : __fmul_rn(__fmul_rn(fx, fx), fx);
-    const float zz = fz <= fthresh ? __fdiv_rn(__fsub_rn(fz, (float)(16.0 / 116.0)), 7.787f) : __fmul_rn(__fmul_rn(fz, fz), fz);
+    const float fx = add_(div_(a, 500.0f), fy), fz = sub_(fy, div_(b, 200.0f));
+    const float xx = fx <= fthresh ? div_(sub_(fx, (float)(16.0 / 116.0)), 7.787f) : mul_(mul_(fx, fx), fx);
+    const float zz = fz <= fthresh ? div_(sub_(fz, (float)(16.0 / 116.0)), 7.787f) : mul_(mul_(fz, fz), fz);
     constexpr float k00 = (float)(3.240479 * 0.950456), k01 = -1.53715f, k02 = (float)(-0.498535 * 1.088754);
     constexpr float k10 = (float)(-0.969256 * 0.950456), k11 = 1.875991f, k12 = (float)(0.041556 * 1.088754);
     constexpr float k20 = (float)(0.055648 * 0.950456), k21 = -0.204043f, k22 = (float)(1.057311 * 1.088754);
     float c[3];
-    c[0] = __fadd_rn(__fadd_rn(__fmul_rn(xx, k00), __fmul_rn(yy, k01)), __fmul_rn(zz, k02));
-    c[1] = __fadd_rn(__fadd_rn(__fmul_rn(xx, k10), __fmul_rn(yy, k11)), __fmul_rn(zz, k12));
-    c[2] = __fadd_rn(__fadd_rn(__fmul_rn(xx, k20), __fmul_rn(yy, k21)), __fmul_rn(zz, k22));
+    c[0] = add_(add_(mul_(xx, k00), mul_(yy, k01)), mul_(zz, k02));
+    c[1] = add_(add_(mul_(xx, k10), mul_(yy, k11)), mul_(zz, k12));
+    c[2] = add_(add_(mul_(xx, k20), mul_(yy, k21)), mul_(zz, k22));
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const float s = linear_to_srgb(fminf(fmaxf(c[ch], 0.0f), 1.0f));
         // totensor (no scaling of a float image) | normalize: (x - mean) / std
-        out[((int64_t)img * 3 + ch) * hw + i] = __fdiv_rn(__fsub_rn(s, nrm.mean[ch]), nrm.std[ch]);
+        out[((int64_t)img * 3 + ch) * hw + i] = div_(sub_(s, nrm.mean[ch]), nrm.std[ch]);
     }
 }
 
@@ -204,7 +219,7 @@ extern "C" {
 int64_t mdx_clahe_workspace(int64_t B, int64_t H, int64_t W, int tiles_x, int tiles_y)
 {
     if (B <= 0 || H <= 0 || W <= 0 || tiles_x <= 0 || tiles_y <= 0) return 0;
-    return round_up(B * H * W, 256) + round_up(B * (int64_t)tiles_x * tiles_y * 256, 256);
+    return 2 * round_up(B * H * W, 256) + round_up(B * (int64_t)tiles_x * tiles_y * 256, 256);
 }
 
 int mdx_clahe_u8_to_chw(const uint8_t *rgb, int64_t B, int64_t H, int64_t W, int clip_limit, int tiles_x, int tiles_y,
@@ -220,6 +235,7 @@ int mdx_clahe_u8_to_chw(const uint8_t *rgb, int64_t B, int64_t H, int64_t W, int
     }
     hipStream_t s = (hipStream_t)stream;
     uint8_t *l8 = (uint8_t *)workspace, *luts = l8 + round_up(B * H * W, 256);
+    uint8_t *l8_out = luts + round_up(B * (int64_t)tiles_x * tiles_y * 256, 256);
     int tw = 0, th = 0;
     clahe_geometry((int)H, (int)W, tiles_x, tiles_y, &tw, &th);
     const int area = tw * th;
@@ -238,7 +254,7 @@ int mdx_clahe_u8_to_chw(const uint8_t *rgb, int64_t B, int64_t H, int64_t W, int
         nrm.std[c] = std[c];
     }
     hipLaunchKernelGGL(clahe_apply_kernel, dim3((unsigned)ceil_div(H * W, 256), (unsigned)B), dim3(256), 0, s, rgb, l8, luts, (int)H, (int)W,
-                       tiles_x, tiles_y, tw, th, nrm, out);
+                       tiles_x, tiles_y, tw, th, nrm, l8_out, out);
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }

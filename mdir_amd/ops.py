@@ -197,8 +197,8 @@ def u8_to_chw(images, mean, std):
 def clahe_u8_to_chw(images, clip_limit, grid, mean, std, return_intermediates=False):
     """uint8 RGB ``[B,H,W,3]`` device images -> CLAHE on the Lab lightness -> normalised fp32 ``[B,3,H,W]``
     (``mdx_clahe_u8_to_chw``): the scenarios' ``pil2np | apply_clahe | totensor | normalize``.  ``grid``: int or
-    ``(tiles_x, tiles_y)``.  ``return_intermediates``: also the uint8 lightness ``[B,H,W]`` and the LUTs
-    ``[B,tiles_y,tiles_x,256]`` the kernels left in the workspace (tests)."""
+    ``(tiles_x, tiles_y)``.  ``return_intermediates``: also the uint8 lightness ``[B,H,W]``, the LUTs
+    ``[B,tiles_y,tiles_x,256]`` and the equalised lightness ``[B,H,W]`` the kernels left in the workspace (tests)."""
     if not (images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.is_contiguous() and images.shape[3] == 3):
         raise ValueError("clahe_u8_to_chw expects a contiguous uint8 [B,H,W,3] CUDA/ROCm tensor (no CPU fallback)")
     b, h, w, _ = images.shape
@@ -215,8 +215,9 @@ def clahe_u8_to_chw(images, clip_limit, grid, mean, std, return_intermediates=Fa
                                                  arr(*[float(v) for v in std]), ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()),
                   "mdx_clahe_u8_to_chw")
     if return_intermediates:
-        plane = -(-(b * h * w) // 256) * 256
-        return out, ws[:b * h * w].view(b, h, w), ws[plane:plane + b * ty * tx * 256].view(b, ty, tx, 256)
+        plane, tables = -(-(b * h * w) // 256) * 256, -(-(b * ty * tx * 256) // 256) * 256
+        return (out, ws[:b * h * w].view(b, h, w), ws[plane:plane + b * ty * tx * 256].view(b, ty, tx, 256),
+                ws[plane + tables:plane + tables + b * h * w].view(b, h, w))
     return out
 
 

@@ -285,15 +285,16 @@ def test_trunk_with_own_1x1_convolutions_equals_library_trunk(monkeypatch):
 def test_clahe_kernels_vs_restatement(b, h, w, clip, grid):
     """mdx_clahe_u8_to_chw against oracle.apply_clahe_rgb (the same restatement of OpenCV's algorithm in numpy): the uint8
     lightness may differ by one level where powf / cbrtf differ in the last bit at a truncation boundary (< 0.1 % of the
-    pixels); GIVEN the device's lightness plane the per-tile LUTs are bit-exact (integer work) and the output is within 2e-5."""
+    pixels); GIVEN the device's lightness plane the per-tile LUTs and the equalised lightness are bit-exact and the output is
+    within 1e-4 (normalised units: powf / cbrtf differ from numpy in the last bits, and 1 / std amplifies 4.4x)."""
     from oracle import oracle as O
     from mdir_amd import ops
     rng = np.random.default_rng(h * w + b)
     base = rng.integers(0, 256, (b, h // 8 + 1, w // 8 + 1, 3))
     img = np.clip(np.kron(base, np.ones((1, 8, 8, 1)))[:, :h, :w] + rng.normal(0, 12, (b, h, w, 3)), 0, 255).astype(np.uint8)
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
-    out, l8, luts = ops.clahe_u8_to_chw(dev(img), clip, grid, mean, std, return_intermediates=True)
-    out, l8, luts = out.cpu().numpy(), l8.cpu().numpy(), luts.cpu().numpy()
+    out, l8, luts, l8_eq = ops.clahe_u8_to_chw(dev(img), clip, grid, mean, std, return_intermediates=True)
+    out, l8, luts, l8_eq = out.cpu().numpy(), l8.cpu().numpy(), luts.cpu().numpy(), l8_eq.cpu().numpy()
     g = grid if isinstance(grid, tuple) else (grid, grid)
     for i in range(b):
         want_rgb, want_l8 = O.apply_clahe_rgb(img[i], clip, g)
@@ -301,15 +302,16 @@ def test_clahe_kernels_vs_restatement(b, h, w, clip, grid):
         assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 1e-3
         want_luts, tile = O.clahe_luts(l8[i], clip, g)
         np.testing.assert_array_equal(luts[i], want_luts)
+        np.testing.assert_array_equal(l8_eq[i], O.clahe_apply(l8[i], want_luts, tile))     # the blend, ties included: bit-exact
         # the rest of the chain on the device's own lightness plane
         lab = O.rgb_to_lab(img[i].astype(np.float32) / np.float32(255))
         spc = ((lab + np.array([0, 128, 128], np.float32)) / np.array([100, 255, 255], np.float32)).astype(np.float32)
         spc[..., 0] = O.clahe_apply(l8[i], want_luts, tile).astype(np.float32) / np.float32(255)
         rgb = O.lab_to_rgb(((spc * np.array([100, 255, 255], np.float32)).astype(np.float32) - np.array([0, 128, 128], np.float32)).astype(np.float32))
         want = ((rgb - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1)
-        np.testing.assert_allclose(out[i], want, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out[i], want, rtol=0, atol=1e-4)
         if (diff == 0).all():
-            np.testing.assert_allclose(out[i], ((want_rgb - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1), rtol=0, atol=2e-5)
+            np.testing.assert_allclose(out[i], ((want_rgb - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1), rtol=0, atol=1e-4)
 
 
 def test_extraction_through_the_clahe_chain(tmp_path, monkeypatch):
