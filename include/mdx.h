@@ -305,14 +305,21 @@ int mdx_rank_count(const float *scores, int64_t n, int64_t nq, int64_t id_offset
  * Gram matrix of the rows of a dimension-major matrix:
  *   a [d, n] row-major, center [d] or NULL  ->  out [d, d],  out[i][j] = sum_k (a[i][k] - center[i]) * (a[j][k] - center[j])
  * = `np.dot(Xc, Xc.T)` with `Xc = X - m` (whiten.py:21-22), `np.dot(df, df.T)` (whiten.py:42 and :46).  Only the
- * tiles on or above the diagonal are computed and each is stored twice: the result is exactly symmetric. */
-int mdx_gram_f64(const double *a, int64_t d, int64_t n, const double *center, double *out, void *stream);
+ * tiles on or above the diagonal are computed and each is stored twice: the result is exactly symmetric.  workspace:
+ * mdx_gram_f64_workspace(d, n) bytes of device scratch -- the centred input transposed to [n, d] (both operands of the GEMM
+ * are then read in 512-byte runs), then the partial results of up to 16 K ranges, which are added in range order: a fixed
+ * summation order, whatever the schedule. */
+int64_t mdx_gram_f64_workspace(int64_t d, int64_t n);
+int mdx_gram_f64(const double *a, int64_t d, int64_t n, const double *center, double *out, void *workspace,
+                 int64_t workspace_bytes, void *stream);
 
 /* Projection of centred descriptors:
  *   p [dout, d] row-major, x [d, n] row-major, center [d] or NULL  ->  out [dout, n] = p . (x - center)
- * = `df = np.dot(P, X-m)` (whiten.py:45). */
+ * = `df = np.dot(P, X-m)` (whiten.py:45).  workspace: mdx_project_f64_workspace(dout, d) bytes of device scratch (p
+ * transposed, so that both operands are read in 512-byte runs). */
+int64_t mdx_project_f64_workspace(int64_t dout, int64_t d);
 int mdx_project_f64(const double *p, int64_t dout, int64_t d, const double *x, int64_t n, const double *center,
-                    double *out, void *stream);
+                    double *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------- multi-GPU exchange (RCCL over xGMI) */
 

@@ -544,8 +544,10 @@ def gram_f64(a, center=None):
     if center is not None and center.numel() != d:
         raise ValueError("center has %d elements, expected %d" % (center.numel(), d))
     out = torch.empty((d, d), dtype=torch.float64, device=a.device)
+    need = _lib.lib().mdx_gram_f64_workspace(d, n)
+    ws = _workspace(need, a.device)
     with _on(a):
-        check(_lib.lib().mdx_gram_f64(ap, d, n, cp, _vp(out.data_ptr()), _stream()), "mdx_gram_f64")
+        check(_lib.lib().mdx_gram_f64(ap, d, n, cp, _vp(out.data_ptr()), _vp(ws.data_ptr()), need, _stream()), "mdx_gram_f64")
     return out
 
 
@@ -560,9 +562,11 @@ def project_f64(p, x, center=None):
     if center is not None and center.numel() != x.shape[0]:
         raise ValueError("center has %d elements, expected %d" % (center.numel(), x.shape[0]))
     out = torch.empty((p.shape[0], x.shape[1]), dtype=torch.float64, device=x.device)
+    need = _lib.lib().mdx_project_f64_workspace(p.shape[0], p.shape[1])
+    ws = _workspace(need, x.device)
     with _on(x):
-        check(_lib.lib().mdx_project_f64(pp, p.shape[0], p.shape[1], xp, x.shape[1], cp, _vp(out.data_ptr()), _stream()),
-              "mdx_project_f64")
+        check(_lib.lib().mdx_project_f64(pp, p.shape[0], p.shape[1], xp, x.shape[1], cp, _vp(out.data_ptr()), _vp(ws.data_ptr()), need,
+                                         _stream()), "mdx_project_f64")
     return out
 
 

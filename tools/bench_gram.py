@@ -28,8 +28,9 @@ t_gram = timed(lambda: ops.gram_f64(A))
 t_gram_blas = timed(lambda: A @ A.t())
 t_proj = timed(lambda: ops.project_f64(P, A, m))
 t_proj_blas = timed(lambda: P @ (A - m[:, None]))
-tiles = -(-D // 64)
-flops_gram_done = 2.0 * n * 64 * 64 * (tiles * (tiles + 1) // 2)        # tiles on or above the diagonal
+tile = 128 if D >= 1024 else 64                                            # gram_tile() of csrc/mdx_gram.hip
+tiles = -(-D // tile)
+flops_gram_done = 2.0 * n * tile * tile * (tiles * (tiles + 1) // 2)      # tiles on or above the diagonal
 flops_proj = 2.0 * D * D * n
 err = float((ops.gram_f64(A) - A @ A.t()).abs().max() / (A @ A.t()).abs().max())
 out = {"D": D, "n": n,
