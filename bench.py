@@ -497,6 +497,34 @@ def main():
                                                 "scores_us": round(1e3 * t_s, 1), "rank_us": round(1e3 * t_r, 1),
                                                 "queries_per_s": round(1125 / ((t_s + t_r) * 1e-3), 1), "bound": "launch latency"}
             tix.close()
+            # rows f3 / f4 of SURVEY.md section 8: the float64 products of whitening learning (whiten.py:22,42,45,46) at
+            # D = 2048 on 20 000 descriptors, and the CLAHE networks' input conversion on a batch of four 1024 x 768 images
+            g5 = torch.Generator(device=device)
+            g5.manual_seed(5)
+            A64 = torch.randn((DIM, 20000), generator=g5, device=device, dtype=torch.float64)
+            P64 = torch.randn((DIM, DIM), generator=g5, device=device, dtype=torch.float64)
+            m64 = torch.randn(DIM, generator=g5, device=device, dtype=torch.float64)
+            t_g, t_p = timed(lambda: ops.gram_f64(A64), reps=5), timed(lambda: ops.project_f64(P64, A64, m64), reps=5)
+            tri = (DIM // 128) * (DIM // 128 + 1) // 2
+            fl_g, fl_p = 2.0 * 20000 * 128 * 128 * tri, 2.0 * DIM * DIM * 20000
+            sec["whitening_learning_f64"] = {
+                "workload": "D=%d, n=20000 float64: mdx_gram_f64 (np.dot(df, df.T)) and mdx_project_f64 (np.dot(P, X-m))" % DIM,
+                "gram_ms": round(t_g, 3), "project_ms": round(t_p, 3),
+                "roofline_gram": {"bound": "mfma", "achieved": round(fl_g / t_g / 1e9, 2), "peak": 78.6, "unit": "TFLOP/s",
+                                  "frac": round(fl_g / t_g / 1e9 / 78.6, 4), "what": "flops executed: upper-triangle tiles only"},
+                "roofline_project": {"bound": "mfma", "achieved": round(fl_p / t_p / 1e9, 2), "peak": 78.6, "unit": "TFLOP/s",
+                                     "frac": round(fl_p / t_p / 1e9 / 78.6, 4)}}
+            del A64, P64
+            u8 = torch.randint(0, 256, (4, 768, 1024, 3), generator=g5, device=device, dtype=torch.uint8)
+            mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+            t_c, t_n = timed(lambda: ops.clahe_u8_to_chw(u8, 4, 8, mean, std)), timed(lambda: ops.u8_to_chw(u8, mean, std))
+            cb = 4 * 768 * 1024 * (3 + 1 + 3 + 1 + 1 + 12)          # rgb, L8 w/r, rgb again, L8', fp32 CHW out
+            sec["clahe_preprocess"] = {
+                "workload": "4 x 1024x768 uint8 RGB -> CLAHE (clip 4, 8x8 tiles) on the Lab lightness -> normalised fp32 CHW "
+                            "(parity unpinned: OpenCV's algorithm restated)",
+                "ms_per_batch": round(t_c, 4), "plain_u8_to_chw_ms_per_batch": round(t_n, 4),
+                "roofline": {"bound": "hbm", "achieved": round(cb / (t_c * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(cb / (t_c * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes": float(cb)}}
             extra["secondary_configs"] = sec
         except Exception as exc:
             extra["secondary_configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}

@@ -47,9 +47,22 @@ __global__ __launch_bounds__(256, NT == 64 ? 3 : 2) void conv1x1_bn_act_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // blockIdx.x = (image, pixel tile) fastest over the channel tiles: the workgroups that share an x tile are neighbours
-    const int tile_m = blockIdx.x % (Cout / CV_MT);
-    const int tile_bp = blockIdx.x / (Cout / CV_MT);
+    // The workgroups that share an x tile (same image and pixel tile, different output channels) must meet in ONE L2:
+    // workgroups are dealt to the 8 XCDs round-robin by id, so pixel tile t goes to XCD t % 8 and its channel tiles follow
+    // each other in THAT XCD's sequence: id = t % 8 + 8 * ((t / 8) * channel_tiles + m).  (With the channel tile fastest in
+    // the plain id, an x tile was fetched into up to 8 L2s.)  The last, partial group of pixel tiles keeps the plain order.
+    const int mt = Cout / CV_MT;
+    const int nbp = (int)(gridDim.x / mt);
+    int tile_m, tile_bp;
+    if ((int)blockIdx.x < (nbp / 8) * 8 * mt) {
+        const int xcd = blockIdx.x % 8, seq = blockIdx.x / 8;
+        tile_m = seq % mt;
+        tile_bp = (seq / mt) * 8 + xcd;
+    } else {
+        const int r = blockIdx.x - (nbp / 8) * 8 * mt;
+        tile_m = r % mt;
+        tile_bp = (nbp / 8) * 8 + r / mt;
+    }
     const int b = tile_bp / ntiles_p, tp = tile_bp % ntiles_p;
     const int co0 = tile_m * CV_MT, p0 = tp * NT;
     const float *xb = x + (int64_t)b * Cin * HW;
