@@ -13,7 +13,8 @@
 // RCCL is bound at run time (dlopen), not at link time: libmdx.so must load on a box without it and, inside
 // a PyTorch process, must use the librccl.so.1 that process has already mapped (torch ships its own copy; two
 // copies would each want their own HIP runtime state).  xGMI is point-to-point (7 links per GPU), so the
-// uneven forms are grouped ncclSend / ncclRecv pairs -- one transfer per link, no ring.
+// uneven forms are grouped ncclSend / ncclRecv pairs -- one transfer per link, no ring.  The exchange calls make no HIP call of
+// their own (tests/fake_rccl.c stands in for RCCL on a CPU box and runs them with host buffers, several ranks as threads).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -180,13 +181,10 @@ int mdx_allgather_scores(mdx_comm *c, const float *local, int64_t nq, const int6
     ncclResult_t first = ncclSuccess;
     for (int g = 0; g < c->nranks; ++g) {
         const size_t cnt = (size_t)(nq * widths[g]);
-        if (g == c->rank) {
-            if (cnt && hipMemcpyAsync(all + off, local, cnt * 4, hipMemcpyDeviceToDevice, s) != hipSuccess && first == ncclSuccess)
-                first = ncclUnhandledCudaError;
-        } else {
-            if (mine) { ncclResult_t r = R->Send(local, mine, ncclFloat, g, c->comm, s); if (first == ncclSuccess) first = r; }
-            if (cnt) { ncclResult_t r = R->Recv(all + off, cnt, ncclFloat, g, c->comm, s); if (first == ncclSuccess) first = r; }
-        }
+        // (the rank's own block travels the same way: a send and a receive to itself inside the group -- RCCL turns the
+        // pair into a device copy -- so that the exchange makes no HIP call of its own)
+        if (mine) { ncclResult_t r = R->Send(local, mine, ncclFloat, g, c->comm, s); if (first == ncclSuccess) first = r; }
+        if (cnt) { ncclResult_t r = R->Recv(all + off, cnt, ncclFloat, g, c->comm, s); if (first == ncclSuccess) first = r; }
         off += (int64_t)cnt;
     }
     MDX_NCCL(R->GroupEnd());            // always closed, also after a failed call inside the group
@@ -213,14 +211,8 @@ int mdx_exchange_scores(mdx_comm *c, const float *local, int64_t nq, const int64
         mdx_query_bounds(nq, c->nranks, g, &glo, &ghi);
         const size_t send_cnt = (size_t)((ghi - glo) * w_mine);          // rows of g's queries in my block: contiguous
         const size_t recv_cnt = (size_t)(nq_mine * widths[g]);
-        if (g == c->rank) {
-            if (recv_cnt && hipMemcpyAsync(mine_out + off, local + glo * w_mine, recv_cnt * 4, hipMemcpyDeviceToDevice, s) != hipSuccess &&
-                first == ncclSuccess)
-                first = ncclUnhandledCudaError;
-        } else {
-            if (send_cnt) { ncclResult_t r = R->Send(local + glo * w_mine, send_cnt, ncclFloat, g, c->comm, s); if (first == ncclSuccess) first = r; }
-            if (recv_cnt) { ncclResult_t r = R->Recv(mine_out + off, recv_cnt, ncclFloat, g, c->comm, s); if (first == ncclSuccess) first = r; }
-        }
+        if (send_cnt) { ncclResult_t r = R->Send(local + glo * w_mine, send_cnt, ncclFloat, g, c->comm, s); if (first == ncclSuccess) first = r; }
+        if (recv_cnt) { ncclResult_t r = R->Recv(mine_out + off, recv_cnt, ncclFloat, g, c->comm, s); if (first == ncclSuccess) first = r; }
         off += (int64_t)recv_cnt;
     }
     MDX_NCCL(R->GroupEnd());
