@@ -275,7 +275,7 @@ def test_images_from_list_contract(tmp_path):
     with pytest.raises(ValueError):
         configdataset("nosuchset", str(tmp_path))
     with pytest.raises(KeyError):
-        initialize_transforms("pil2np | apply_clahe", None)
+        initialize_transforms("pil2np | match_histogram:f3d_lab", None)        # a reference transform outside this path
 
 
 def _synthetic_dataset(tmp_path, monkeypatch, n=9, nq=3):
