@@ -47,6 +47,30 @@ def test_argument_errors_do_not_need_a_gpu():
     assert h.mdx_index_create(ctypes.byref(out), ctypes.c_void_p(16), -5, 8, 0, 0, None) == -1
 
 
+def test_round3_entry_points_check_their_arguments():
+    """The entry points added in round 3 refuse bad arguments before touching any device (no GPU here)."""
+    import ctypes
+    from mdir_amd import _lib
+    h = _lib.lib()
+    assert h.mdx_gram_f64(None, 4, 4, None, None, None, 0, None) == -1 and b"NULL" in h.mdx_last_error()
+    assert h.mdx_gram_f64(ctypes.c_void_p(16), 4, 4, None, ctypes.c_void_p(16), None, 0, None) == -4      # workspace too small
+    assert h.mdx_gram_f64_workspace(2048, 20000) >= 2048 * 20000 * 8 and h.mdx_gram_f64_workspace(0, 5) == 0
+    assert h.mdx_project_f64(ctypes.c_void_p(16), 4, 4, ctypes.c_void_p(16), 4, None, ctypes.c_void_p(16), None, 0, None) == -4
+    assert h.mdx_conv1x1_bn_act(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 24, 64, 9, None, None, None, None, 1e-5, None, 1,
+                                ctypes.c_void_p(16), None) == -1 and b"Cin" in h.mdx_last_error()        # Cin % 16
+    assert h.mdx_conv1x1_bn_act(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 32, 64, 9, ctypes.c_void_p(16), None, None, None, 1e-5,
+                                None, 1, ctypes.c_void_p(16), None) == -1                                 # mean without var
+    mean = (ctypes.c_float * 3)(0, 0, 0)
+    assert h.mdx_clahe_u8_to_chw(ctypes.c_void_p(16), 1, 8, 8, 4, 0, 8, mean, mean, ctypes.c_void_p(16), 1 << 20, ctypes.c_void_p(16), None) == -1
+    assert h.mdx_clahe_u8_to_chw(ctypes.c_void_p(16), 1, 8, 8, 4, 8, 8, mean, mean, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), None) == -4
+    assert h.mdx_clahe_workspace(2, 10, 10, 8, 8) == 2 * 256 + 2 * 64 * 256
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    assert h.mdx_query_bounds(70, 8, 3, ctypes.byref(lo), ctypes.byref(hi)) == 0 and (lo.value, hi.value) == (27, 36)
+    assert h.mdx_query_bounds(70, 8, 8, ctypes.byref(lo), ctypes.byref(hi)) == -1
+    assert h.mdx_comm_init(None, None, 1, 0) == -1
+    assert h.mdx_exchange_scores(None, None, 1, None, None, None) == -1 and h.mdx_comm_destroy(None) == 0
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from mdir_amd import ops
