@@ -37,16 +37,25 @@ def _fused_trunk():
     return os.environ.get("MDIR_AMD_FUSED_TRUNK", "1") != "0"
 
 
+def _own_conv1x1(conv, residual):
+    """Which stride-1 1x1 convolutions run on libmdx's GEMM with the epilogue fused (``mdx_conv1x1_bn_act``) instead of MIOpen +
+    ``mdx_bn_act``.  ``MDIR_AMD_CONV1X1``: ``auto`` (default) = where it is faster, by a FIXED rule (no run-time timing: results
+    do not depend on a measurement): the expand convolutions (the ones that add the identity: K is short and the epilogue pass
+    they save costs as much as the GEMM) and convolutions with <= 64 output channels (MIOpen's choice there runs at 40 TFLOP/s);
+    the long-K reduce convolutions stay with the library GEMM, which runs at 110-135 TFLOP/s against 95-100 here
+    (``profiles/r03_conv1x1.md``).  ``1`` = every supported one, ``0`` = none."""
+    mode = os.environ.get("MDIR_AMD_CONV1X1", "auto")
+    if mode == "0":
+        return False
+    return mode == "1" or residual is not None or conv.out_channels <= 64
+
+
 def _conv_bn_act(conv, bn, x, residual=None, relu=True):
-    """``relu(bn(conv(x)) + residual)``.  ``MDIR_AMD_CONV1X1=1`` sends stride-1 1x1 convolutions through libmdx's own
-    GEMM with the epilogue fused (``mdx_conv1x1_bn_act``: the convolution output is written once, finished).  OFF by
-    default: measured on the ResNet101 shapes (``tools/conv1x1_bench.py``, ``profiles/r03_conv1x1.md``) the library
-    GEMM behind MIOpen's 1x1 convolution runs at 75-133 TFLOP/s and the hand-written one at 47-93, which costs more
-    than the saved epilogue pass gains except on the memory-bound first layers."""
-    if (os.environ.get("MDIR_AMD_CONV1X1") == "1" and x.is_cuda and x.dtype == torch.float32 and not bn.training
-            and not torch.is_grad_enabled() and bn.track_running_stats and _fused_trunk()
-            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
-            and conv.bias is None):
+    """``relu(bn(conv(x)) + residual)`` of a Bottleneck's 1x1 convolutions: one kernel where ``_own_conv1x1`` says so (the
+    convolution output is written once, finished), else the library convolution followed by ``mdx_bn_act``."""
+    if (x.is_cuda and x.dtype == torch.float32 and not bn.training and not torch.is_grad_enabled() and bn.track_running_stats
+            and _fused_trunk() and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.groups == 1 and conv.bias is None and _own_conv1x1(conv, residual)):
         from . import ops
         if ops.conv1x1_supported(conv.in_channels, conv.out_channels):
             wt = getattr(conv, "_mdx_wt", None)

@@ -261,7 +261,8 @@ def test_conv1x1_bn_act_vs_float64(n, cin, cout, h, w, res, relu, bn):
 
 
 def test_trunk_with_own_1x1_convolutions_equals_library_trunk(monkeypatch):
-    """MDIR_AMD_CONV1X1=1 (opt-in): ResNet50 with its 1x1 convolutions on mdx_conv1x1_bn_act == the MIOpen trunk."""
+    """ResNet50 with its 1x1 convolutions on mdx_conv1x1_bn_act -- all of them (MDIR_AMD_CONV1X1=1) or the default subset
+    (auto: the expand convolutions and those with <= 64 output channels) -- equals the all-MIOpen trunk (=0) to fp32 rounding."""
     from mdir_amd.backbones import TrunkSequential, build_features
     torch.manual_seed(5)
     feats = TrunkSequential(*build_features("resnet50")).eval()
@@ -271,11 +272,16 @@ def test_trunk_with_own_1x1_convolutions_equals_library_trunk(monkeypatch):
     feats = feats.to(DEV)
     x = torch.randn(2, 3, 203, 157, device=DEV)
     with torch.no_grad():
+        monkeypatch.setenv("MDIR_AMD_CONV1X1", "0")
         plain = feats(x)
         monkeypatch.setenv("MDIR_AMD_CONV1X1", "1")
         own = feats(x)
-    assert float((own - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
-    assert not torch.equal(own, plain)                   # a different summation order: the own kernels did run
+        monkeypatch.delenv("MDIR_AMD_CONV1X1")
+        auto = feats(x)
+    for got in (own, auto):
+        assert float((got - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
+        assert not torch.equal(got, plain)               # a different summation order: the own kernels did run
+    assert not torch.equal(own, auto)                    # ... and `auto` is a proper subset
 
 
 # ---------------------------------------------------------------- CLAHE pre-processing (f4; parity unpinned against OpenCV)
