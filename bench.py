@@ -203,10 +203,12 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        limit = datetime.timedelta(seconds=300)       # a collective that cannot complete ends the run instead of hanging it
         if dryrun:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=limit)
         # communicator set-up (lazy peer connections) is not a step: ShardedIndex runs a small all-to-all when it is
         # built and all ranks agree there (all-reduce) on the exchange form -- see mdir_amd/sharded.py
 

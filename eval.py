@@ -57,13 +57,15 @@ def init_distributed():
     import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
+    limit = datetime.timedelta(minutes=30)            # extraction of a rank's slice happens between collectives
     if os.environ.get("MDIR_AMD_DRYRUN_ONE_GPU") == "1":
         # functional dry run on a 1-GPU box: every rank on cuda:0, collectives staged through gloo
         torch.cuda.set_device(0)
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=limit)
     else:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=limit)
     return dist.get_rank()
 
 
