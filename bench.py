@@ -204,7 +204,7 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import datetime
-        limit = datetime.timedelta(seconds=300)       # a collective that cannot complete ends the run instead of hanging it
+        limit = datetime.timedelta(seconds=900)       # a collective that cannot complete ends the run instead of hanging it
         if dryrun:
             dist.init_process_group("gloo", timeout=limit)
         else:
