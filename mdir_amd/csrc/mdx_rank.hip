@@ -469,10 +469,14 @@ __global__ __launch_bounds__(256) void rank_count_bsearch_kernel(
     const float *__restrict__ ref_scores, const int64_t *__restrict__ ref_ids,
     const int64_t *__restrict__ offsets, unsigned long long *__restrict__ cnt, int nblk)
 {
+    // the histogram of u in CNT_COPIES copies selected by LANE: with few labelled items (20 per query: 21 values of u) and
+    // many live rows, 64 lanes of one ds_add hit a handful of addresses; row stride 257 keeps the copies in different banks
+    constexpr int CNT_COPIES = 8;
     __shared__ uint64_t sref[CNTB_REFS];
+    __shared__ uint32_t histc[CNT_COPIES][CNTB_REFS + 1];
     __shared__ uint32_t hist[CNTB_REFS + 1];
     __shared__ uint32_t wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, copy = tid & (CNT_COPIES - 1);
     const int64_t q = blockIdx.y;
     const int64_t lo = offsets[q], hi = offsets[q + 1];
     for (int64_t r0 = lo; r0 < hi; r0 += CNTB_REFS) {
@@ -487,17 +491,33 @@ __global__ __launch_bounds__(256) void rank_count_bsearch_kernel(
             mine = ((uint64_t)desc_key(ref_scores[r0 + tid]) << 32) | idc;
         }
         sref[tid] = mine;
-        hist[tid] = 0;
-        if (tid == 0) hist[CNTB_REFS] = 0;
+        for (int e = tid; e < CNT_COPIES * (CNTB_REFS + 1); e += 256) (&histc[0][0])[e] = 0;
         __syncthreads();
         bitonic_sort_lds(sref, CNTB_REFS, tid, 256);
         for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
             const int64_t t0 = (int64_t)b * CNT_TILE;
             uint64_t el[CNT_ITEMS];
+            // a lane takes 4 consecutive rows with one 16-byte load (dword-aligned: rows of an odd length start anywhere); all
+            // loads of the tile are issued before the first use, whole tiles without a range check
+            typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            const uint32_t *row = (const uint32_t *)scores + q * n;
+            if (t0 + CNT_TILE <= n) {
+                u32x4u w[CNT_ITEMS / 4];
 #pragma unroll
-            for (int e = 0; e < CNT_ITEMS; ++e) {
-                const int64_t i = t0 + e * 256 + tid;
-                el[e] = i < n ? ((uint64_t)desc_key(scores[q * n + i]) << 32) | (uint32_t)(i + id_offset) : ~0ull;
+                for (int v = 0; v < CNT_ITEMS / 4; ++v) w[v] = *(const u32x4u *)(row + t0 + (v * 256 + tid) * 4);
+#pragma unroll
+                for (int v = 0; v < CNT_ITEMS / 4; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t i = t0 + (v * 256 + tid) * 4 + j;
+                        el[v * 4 + j] = ((uint64_t)desc_key(__uint_as_float(w[v][j])) << 32) | (uint32_t)(i + id_offset);
+                    }
+            } else {
+#pragma unroll
+                for (int e = 0; e < CNT_ITEMS; ++e) {
+                    const int64_t i = t0 + (e / 4 * 256 + tid) * 4 + e % 4;
+                    el[e] = i < n ? ((uint64_t)desc_key(scores[q * n + i]) << 32) | (uint32_t)(i + id_offset) : ~0ull;
+                }
             }
             const uint64_t last = sref[nref - 1];                   // broadcast: rows behind every item are skipped
 #pragma unroll
@@ -508,12 +528,14 @@ __global__ __launch_bounds__(256) void rank_count_bsearch_kernel(
                 uint32_t u = 0;
                 for (int step = P >> 1; step > 0; step >>= 1)
                     u += (sref[u + step - 1] <= el[e]) ? (uint32_t)step : 0u;
-                if (live) atomicAdd(&hist[u], 1u);
+                if (live) atomicAdd(&histc[copy][u], 1u);
             }
         }
         __syncthreads();
         // inclusive prefix over u (thread = position in the sorted order)
-        uint32_t inc = hist[tid];
+        uint32_t inc = 0;
+#pragma unroll
+        for (int c = 0; c < CNT_COPIES; ++c) inc += histc[c][tid];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(inc, o, 64);

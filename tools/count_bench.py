@@ -8,8 +8,9 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
 sc = torch.randn((nq, n), generator=g, device=dev) * 0.022
 rng = np.random.default_rng(1)
-for per in (4, 12, 20, 200):
-    lists = [rng.choice(4993, per, replace=False) for _ in range(nq)]
+top = torch.topk(sc, 200, dim=1).indices.cpu().numpy()          # labelled rows that rank near the top (the retrieval case: few rows precede them)
+for per, kind in ((20, "top"), (200, "top"), (4, "random"), (20, "random"), (200, "random")):
+    lists = [np.sort(top[q][rng.choice(200, per, replace=False)]) if kind == "top" else rng.choice(4993, per, replace=False) for q in range(nq)]
     pos, _, off = ops.rank_of(sc, lists)
     torch.cuda.synchronize()
     ids_t, off_t, _ = ops._csr(lists, dev)
@@ -24,4 +25,4 @@ for per in (4, 12, 20, 200):
     # check one query against a direct count
     q = 3; s = sc[q]; ids = torch.as_tensor(lists[q], device=dev)
     want = [(int((s > s[i]).sum()) + int(((s == s[i]) & (torch.arange(n, device=dev) < i)).sum())) for i in ids[:5]]
-    print("refs/query %3d: rank_count kernel %.3f ms; check %s" % (per, a.elapsed_time(b) / 10, want == [int(x) for x in pos[off[q]:off[q] + len(want)]]), flush=True)
+    print("refs/query %3d (%s): rank_count kernel %.3f ms; check %s" % (per, kind, a.elapsed_time(b) / 10, want == [int(x) for x in pos[off[q]:off[q] + len(want)]]), flush=True)
