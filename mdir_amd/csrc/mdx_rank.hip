@@ -936,17 +936,31 @@ __global__ __launch_bounds__(SORT_THREADS) void select_hist_kernel(const float *
     for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
         for (int e = tid; e < (SORT_WAVES / 2) * RADIX; e += SORT_THREADS) (&h[0][0])[e] = 0;
         uint32_t k[SORT_ITEMS];
+        bool ok[SORT_ITEMS];
+        if ((b + 1) * SORT_TILE <= n) {
+            // whole tile: a lane takes 4 consecutive rows per 16-byte load (a histogram does not care which lane counts which row)
+            typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            const uint32_t *row = (const uint32_t *)scores + q * n + b * SORT_TILE;
+            u32x4u w[SORT_ITEMS / 4];
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = b * SORT_TILE + r * SORT_THREADS + tid;
-            k[r] = i < n ? desc_key(scores[q * n + i]) : 0u;
+            for (int v = 0; v < SORT_ITEMS / 4; ++v) w[v] = *(const u32x4u *)(row + (v * SORT_THREADS + tid) * 4);
+#pragma unroll
+            for (int r = 0; r < SORT_ITEMS; ++r) {
+                k[r] = desc_key(__uint_as_float(w[r / 4][r % 4]));
+                ok[r] = true;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < SORT_ITEMS; ++r) {
+                const int64_t i = b * SORT_TILE + r * SORT_THREADS + tid;
+                ok[r] = i < n;
+                k[r] = ok[r] ? desc_key(scores[q * n + i]) : 0u;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = b * SORT_TILE + r * SORT_THREADS + tid;
-            if (i < n && (k[r] & s.mask) == s.prefix) atomicAdd(&h[wave >> 1][(k[r] >> shift) & 255u], 1u);
-        }
+        for (int r = 0; r < SORT_ITEMS; ++r)
+            if (ok[r] && (k[r] & s.mask) == s.prefix) atomicAdd(&h[wave >> 1][(k[r] >> shift) & 255u], 1u);
         __syncthreads();
         if (tid < RADIX) {
             uint32_t tot = 0;
@@ -1286,10 +1300,24 @@ __global__ __launch_bounds__(256) void tks_compact_kernel(const float *__restric
     const uint64_t T = thr[q];
     if (tid == 0) lcount = 0;
     uint64_t c[16];
+    // a lane takes 4 consecutive rows per 16-byte load (dword-aligned); whole tiles without a range check, all loads in flight
+    // together (which lane holds which row does not matter: the composite carries the order)
+    if (t0 + 4096 <= n) {
+        typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const uint32_t *row = (const uint32_t *)scores + q * n + t0;
+        u32x4u w[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int64_t i = t0 + e * 256 + tid;
-        c[e] = i < n ? tk_comp(scores[q * n + i], (uint32_t)i) : ~0ull;
+        for (int v = 0; v < 4; ++v) w[v] = *(const u32x4u *)(row + (v * 256 + tid) * 4);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[v * 4 + j] = tk_comp(__uint_as_float(w[v][j]), (uint32_t)(t0 + (v * 256 + tid) * 4 + j));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t i = t0 + e * 256 + tid;
+            c[e] = i < n ? tk_comp(scores[q * n + i], (uint32_t)i) : ~0ull;
+        }
     }
     __syncthreads();
     uint64_t *mine = cand + (q * nblk + blockIdx.x) * TKS_SLOTS;
