@@ -166,7 +166,13 @@ int mdx_resample_u8(const uint8_t *src, int64_t B, int H, int W, int C, int axis
  * configures it (Huffman decoding; jidctint.c islow IDCT; jdsample.c fancy upsampling; jdcolor.c YCbCr -> RGB), bit for bit.
  *   mdx_jpeg_probe          HOST.  Geometry of the file; info->supported = 0 for what stays with the host decoder
  *                           (arithmetic, 12-bit, lossless, CMYK / RGB-coded, other sampling factors).  Sequential and
- *                           progressive Huffman files are covered.
+ *                           progressive Huffman files are covered.  The file is UNTRUSTED input: every table index,
+ *                           code length, component / table id, spectral band and block index derived from its bytes is
+ *                           range-checked, a Huffman table whose codes do not fit their lengths is refused as libjpeg
+ *                           refuses it (jdhuff.c), and a frame header that announces more picture than the file can hold
+ *                           (size < width * height / 512 bytes: one bit per block) is "unsupported", so nobody sizes a
+ *                           buffer from it.  These two functions run under ASan + UBSan over mutated and hand-made
+ *                           hostile files in tests/test_fuzz_asan.py (`make -C mdir_amd/csrc asan`).
  *   mdx_jpeg_coefficients   HOST (no device call; thread-safe, so loader threads run it in parallel).  Entropy decoding
  *                           of all scans (an error for a stream whose data runs out inside a scan: leave it to Pillow):
  *                           coef [nblocks][64] int16, quantised, natural order, component after component, every

@@ -45,14 +45,15 @@ static bool build_table(HuffTable &t)
         t.valptr[l] = k;
         t.mincode[l] = code;
         for (int i = 0; i < t.bits[l]; ++i, ++k, ++code) {
-            if (k >= 256) return false;
+            // an l-bit code must fit l bits (jdhuff.c jpeg_make_d_derived_tbl: "if (code >= (1 << si)) ERREXIT") -- checked per
+            // symbol BEFORE the lookahead table is written: `first + j` below indexes fast[512] only when code < 2^l
+            if (k >= 256 || code >= (1 << l)) return false;
             if (l <= 9) {
                 const int first = code << (9 - l), n = 1 << (9 - l);
                 for (int j = 0; j < n; ++j) t.fast[first + j] = (uint16_t)((l << 8) | t.vals[k]);
             }
         }
         t.maxcode[l] = t.bits[l] ? code - 1 : -1;
-        if (code > (1 << l)) return false;
         code <<= 1;
     }
     t.maxcode[17] = 0x7FFFFFFF;
@@ -198,6 +199,10 @@ static bool parse_header(const uint8_t *d, int64_t size, JpegHeader &hd)
         if (!hd.qdef[hd.tq[c]]) { hd.why = "missing quantisation table"; return false; }
     // Pillow refuses images beyond twice its MAX_IMAGE_PIXELS (a decompression bomb): leave those to it
     if ((int64_t)hd.width * hd.height > 2 * (int64_t)89478485) { hd.why = "too many pixels"; return false; }
+    // The frame header is untrusted and the caller sizes its coefficient buffer (128 B per block) from it: every block costs
+    // the first scan that covers it at least one Huffman code, i.e. one bit, so a file shorter than blocks / 8 bytes cannot
+    // hold the picture it announces (a 200-byte file claiming 65 535 x 2 700 pixels must not reserve half a gigabyte)
+    if ((int64_t)hd.width * hd.height / 64 / 8 > size) { hd.why = "file too short for its dimensions"; return false; }
     hd.mcux = (hd.width + 8 * hd.hmax - 1) / (8 * hd.hmax);
     hd.mcuy = (hd.height + 8 * hd.vmax - 1) / (8 * hd.vmax);
     hd.supported = true;
@@ -297,6 +302,12 @@ static inline int huff_decode(BitReader &br, const HuffTable &t)
 
 static inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
+// The DC predictor is a running sum over every block of a scan: a crafted file can push it past 2^31, so it is added and
+// scaled in unsigned arithmetic (wraps, never undefined -- libjpeg-turbo does the same); what a sound file produces is
+// unchanged, what a damaged one produces is caught by the coefficient range check of mdx_jpeg_coefficients.
+static inline int wrap_add(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+static inline int wrap_shl(int a, int n) { return (int)((uint32_t)a << n); }
+
 // one block of a sequential scan (all 64 coefficients)
 static inline bool block_sequential(BitReader &br, const HuffTable &dct, const HuffTable &act, int &pred, int16_t *blk)
 {
@@ -304,7 +315,7 @@ static inline bool block_sequential(BitReader &br, const HuffTable &dct, const H
     if (s < 0 || s > 15) return false;
     if (s) {
         br.fill();
-        pred += extend(br.get(s), s);
+        pred = wrap_add(pred, extend(br.get(s), s));
     }
     blk[0] = (int16_t)pred;
     for (int k = 1; k < 64;) {
@@ -347,7 +358,7 @@ static inline bool block_ac_first(BitReader &br, const HuffTable &act, int ss, i
             k += r;
             if (k > 63) return false;
             br.fill();
-            blk[ZIGZAG[k]] = (int16_t)(extend(br.get(s), s) * (1 << al));
+            blk[ZIGZAG[k]] = (int16_t)wrap_shl(extend(br.get(s), s), al);
         } else if (r == 15) {
             k += 15;
         } else {
@@ -465,8 +476,8 @@ static bool decode_scans(const uint8_t *d, int64_t size, JpegHeader &hd, const m
                             if (ah == 0) {                  // DC, first pass
                                 const int t = huff_decode(br, hd.dc[td[i]]);
                                 if (t < 0 || t > 15) return false;
-                                if (t) { br.fill(); pred[c] += extend(br.get(t), t); }
-                                blk[0] = (int16_t)(pred[c] * (1 << al));
+                                if (t) { br.fill(); pred[c] = wrap_add(pred[c], extend(br.get(t), t)); }
+                                blk[0] = (int16_t)wrap_shl(pred[c], al);
                             } else {                        // DC, one more bit
                                 br.fill();
                                 if (br.get(1)) blk[0] = (int16_t)(blk[0] | (1 << al));

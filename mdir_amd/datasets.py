@@ -74,26 +74,33 @@ class ImagesFromList(data.Dataset):
         self.decode_on_device = decode_on_device and (resize_on_device or imsize is None) and loader is default_loader
 
     def _coefficients(self, index):
-        """The file as JPEG coefficients for the device, or None (not such a file, or a case for the host route)."""
+        """The file as JPEG coefficients for the device, or None (not such a file, or a case for the host route).
+
+        Never raises and never decides an error: whatever is wrong with a file -- unreadable, not an image, a header Pillow
+        refuses, a stream the entropy decoder gives up on -- sends the item down the host route, where ``self.loader``
+        reports it exactly as the reference does (genericdataset.py:52-59: the OSError re-raised, or ``{}`` under
+        ``ignore_errors``).  Pillow parses the header FIRST (``Image.open`` reads no pixel data): the library's own parser
+        only ever sees files Pillow has accepted as JPEG of a sane size, on top of its own checks (bounds-checked and fuzzed
+        under ASan/UBSan, tests/test_fuzz_asan.py)."""
         from . import jpeg
         from .resample import on_device
         try:
             with open(self.images_fn[index], "rb") as f:
                 data = f.read()
-        except OSError:
-            return None                                     # the host route reports it
-        if data[:2] != b"\xff\xd8":
-            return None
-        item = jpeg.entropy_decode(data, self.bbxs[index] if self.bbxs else None)
-        if item is None:
-            return None
-        try:                                                # Pillow must at least recognise the file the same way (header parse only)
+            if data[:2] != b"\xff\xd8":
+                return None
             import io
-            with Image.open(io.BytesIO(data)) as seen:
-                if seen.format != "JPEG" or seen.size != item.size or seen.mode not in ("RGB", "L"):
+            with Image.open(io.BytesIO(data)) as seen:      # raises for what Pillow does not recognise, and for decompression bombs
+                if seen.format != "JPEG" or seen.mode not in ("RGB", "L"):
                     return None
+                seen_size = seen.size
+            if seen_size[0] * seen_size[1] > (Image.MAX_IMAGE_PIXELS or 89478485):
+                return None                                 # Pillow warns about such a picture: let it (the host route decodes it)
+            item = jpeg.entropy_decode(data, self.bbxs[index] if self.bbxs else None)
+            if item is None or item.size != seen_size:
+                return None
         except Exception:
-            return None                                     # the host route raises what the reference raises
+            return None
         w, h = item.size
         if item.box:
             if not jpeg.box_on_device(item.box, w, h):

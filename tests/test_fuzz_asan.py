@@ -1,0 +1,84 @@
+"""Host-side native code under AddressSanitizer + UBSan (SURVEY section 5 "race detection / sanitizers"; VERDICT round 3,
+item 1).  The JPEG header parser and entropy decoder of libmdx walk untrusted file bytes on the DEFAULT loader route
+(``mdir_amd/datasets.py`` -> ``mdx_jpeg_probe`` / ``mdx_jpeg_coefficients``), in the evaluating process itself: a memory
+error there is a dead evaluation, not a dead worker.  ``make -C mdir_amd/csrc asan`` builds the library with the host code
+instrumented (never the GPU code: GPU ASan is unavailable on this pool) and ``tests/fuzz_jpeg.py`` runs in a subprocess with
+the sanitizer runtime preloaded.  Done = zero reports over >= 60 000 mutated baseline / progressive files, the hand-made
+hostile headers and the 224-byte proof of concept of VERDICT round 3 -- and a planted overflow IS reported (the harness is live).
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ASAN_LIB = os.path.join(ROOT, "mdir_amd", "libmdx_asan.so")
+FUZZ = os.path.join(ROOT, "tests", "fuzz_jpeg.py")
+
+
+def _runtime():
+    out = subprocess.run([HIPCC, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
+@pytest.fixture(scope="module")
+def asan_env():
+    if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+        pytest.skip("no hipcc: the sanitizer build cannot be made here")
+    rt = _runtime()
+    if rt is None:
+        pytest.skip("hipcc ships no shared ASan runtime")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "mdir_amd", "csrc"), "asan"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    return env
+
+
+def _fuzz(env, *args):
+    return subprocess.run([sys.executable, FUZZ, "--lib", ASAN_LIB] + list(args), env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_planted_overflow_is_reported(asan_env):
+    """A coefficient buffer one block short of what the caller claims: the sanitizer build must say so (else a clean fuzz run
+    below would prove nothing)."""
+    r = _fuzz(asan_env, "--selftest")
+    assert r.returncode != 0 and "AddressSanitizer: heap-buffer-overflow" in r.stderr and "not caught" not in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_jpeg_parser_fuzz_is_clean(asan_env, seed):
+    r = _fuzz(asan_env, "--files", "24000", "--seed", str(seed))
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    stats = json.loads(r.stdout.strip().splitlines()[-1])
+    assert stats["files"] >= 24000 and stats["hostile"] > 1000
+    # the run must reach the entropy decoder, not die at the first header check
+    assert stats["supported"] > 10000 and stats["decoded"] > 3000, stats
+
+
+def test_verdict_r3_poc_through_the_shipped_library():
+    """The 224-byte file that segfaulted eval.py (DHT with bits[1] = 200), against the ordinary build: refused, process alive."""
+    import ctypes
+    import numpy as np
+    from mdir_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fuzz_jpeg
+    lib = _lib.lib()
+    data = b"\xff\xd8" + fuzz_jpeg.dht(0x10, [200] + [0] * 15, [0] * 200) + b"\xff\xd9"
+    assert len(data) == 225 - 0 or len(data) > 200
+    buf = np.frombuffer(data, dtype=np.uint8)
+    info = _lib.JpegInfo()
+    assert lib.mdx_jpeg_probe(buf.ctypes.data, buf.size, ctypes.byref(info)) == 0
+    assert info.supported == 0 and b"Huffman" in lib.mdx_last_error()
+    # a frame header that announces more picture than the file can hold is refused at the probe: nobody sizes a buffer from it
+    hdr = fuzz_jpeg.segment(0xC0, bytes([8]) + (65535).to_bytes(2, "big") + (2700).to_bytes(2, "big") + bytes([3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1]))
+    data = b"\xff\xd8" + fuzz_jpeg.segment(0xDB, bytes([0]) + bytes([1] * 64)) + fuzz_jpeg.segment(0xDB, bytes([1]) + bytes([1] * 64)) \
+        + hdr + fuzz_jpeg.segment(0xDA, bytes([3, 1, 0, 2, 0x11, 3, 0x11, 0, 63, 0])) + bytes(64) + b"\xff\xd9"
+    buf = np.frombuffer(data, dtype=np.uint8)
+    assert lib.mdx_jpeg_probe(buf.ctypes.data, buf.size, ctypes.byref(info)) == 0
+    assert info.supported == 0 and b"too short" in lib.mdx_last_error(), lib.mdx_last_error()
