@@ -9,7 +9,11 @@ axis=0)` (mdir/components/optim/score/cirscore.py:69-70).  Inputs are resident i
 HBM when the timed region starts.  With --gpus N the 1M database is row-sharded
 (strong scaling); see mdir_amd/sharded.py for the exchange.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows ROWS] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows ROWS] [--no-cpu-baseline] [--no-secondary]
+                    [--no-pipelined] [--extract-images M] [--profile] [--comm torch|mdx]
+
+`--profile` = the headline loop alone (no CPU baseline, side legs, two-stream leg or extraction): the form
+tools/profile_round.sh runs under rocprofv3, so that the per-kernel averages of the committed profile add up to the step.
 
 Prints ONE JSON line on rank 0.
 """
@@ -135,6 +139,27 @@ def scores_source_sha16():
     return h.hexdigest()[:16]
 
 
+def rank_source_sha16():
+    """Hash of the ranking kernels' source: ties the committed PMC traffic of the sort to the code it was measured on."""
+    import hashlib
+    with open(os.path.join(ROOT, "mdir_amd", "csrc", "mdx_rank.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def ranking_traffic(prof):
+    """HBM bytes of ONE full ranking from a committed PMC summary: the 4 histogram, 4 scan and 4 scatter launches of the
+    LSD sort (per-launch figures of profiles/rNN_traffic.json; the scan kernel runs once per pass)."""
+    if prof.get("ranking_hbm_bytes_per_ranking"):
+        return prof["ranking_hbm_bytes_per_ranking"]
+    total, seen = 0.0, 0
+    for name, t in prof.get("per_kernel", {}).items():
+        if "::sort_hist_kernel" in name or "::sort_scatter_kernel" in name:
+            total, seen = total + t["total_bytes"], seen + 1
+        elif "::sort_scan_kernel" in name:
+            total, seen = total + 4 * t["total_bytes"], seen + 1
+    return total if seen == 9 else None
+
+
 def verify_ranking(sc, rk):
     """Device-side check of a full ranking at any size: every row of `rk` is a permutation of 0..n-1, scores are
     non-increasing along it, and ids ascend inside every run of equal scores (the tie rule) -- the properties a
@@ -148,6 +173,61 @@ def verify_ranking(sc, rk):
         s = sc[q][rk[q]]
         ok_order = ok_order and bool((s[:-1] >= s[1:]).all()) and bool(((s[:-1] != s[1:]) | (rk[q, :-1] < rk[q, 1:])).all())
     return ok_perm, ok_order
+
+
+def side_legs(args, sharded, qvecs, sc, rk, ws, gnd, device, extra):
+    """Two side legs of the single-GPU run that launch the headline's kernels in other arrangements (skipped by
+    --no-pipelined / --profile: overlapped launches blur a kernel trace of the run)."""
+    from mdir_amd import ops
+    # the same evaluation without materialising a ranking: similarity + rank positions of the labelled
+    # ids (mdx_rank_of) -- what compute_map actually needs; identical mAP (asserted above), reported beside
+    from mdir_amd.ops import _csr
+    lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
+    ids_t, off_t, _ = _csr(lists, device)
+    cnt = torch.zeros(ids_t.numel(), dtype=torch.int64, device=device)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        sharded.index.scores(qvecs, "DN", out=sc)
+        cnt.zero_()
+        ops.rank_count_(cnt, sc, 0, ops.gather_scores(sc, ids_t, off_t), ids_t, off_t)
+    torch.cuda.synchronize()
+    t_pos = (time.perf_counter() - t1) / args.steps
+    extra["sort_free_map_route"] = {"value": round(NQ / t_pos, 2), "unit": "queries/s", "ms_per_step": round(t_pos * 1e3, 4),
+                                    "what": "similarity + rank positions of the %d labelled ids (no full ranking), same mAP"
+                                            % int(ids_t.numel())}
+    # throughput form for a stream of batches: the ranking of batch k on a second stream while the similarity of batch
+    # k+1 runs (two score / rank buffers).  Reported beside the headline, which stays the one-stream step: overlapped,
+    # the two kernels share HBM and neither's own duration is a clean roofline figure any more.
+    sc2, rk2, ws2 = torch.empty_like(sc), torch.empty_like(rk), torch.empty_like(ws)
+    bufs, side, cur = ((sc, rk, ws), (sc2, rk2, ws2)), torch.cuda.Stream(device=device), torch.cuda.current_stream(device)
+
+    def piped(steps):
+        done = [None, None]
+        for k in range(steps):
+            b = k & 1
+            if done[b] is not None:
+                cur.wait_event(done[b])            # the ranking that read this score buffer two batches ago is finished
+            sharded.index.scores(qvecs, "DN", out=bufs[b][0])
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                ops.rank_full(bufs[b][0], out=bufs[b][1], workspace=bufs[b][2])
+                done[b] = torch.cuda.Event()
+                done[b].record(side)
+        cur.wait_stream(side)
+    piped(4)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    piped(args.steps)
+    torch.cuda.synchronize()
+    t_pipe = (time.perf_counter() - t1) / args.steps
+    assert bool((rk2 == rk).all())
+    extra["pipelined_two_streams"] = {"value": round(NQ / t_pipe, 2), "unit": "queries/s", "ms_per_step": round(t_pipe * 1e3, 4),
+                                      "what": "same kernels and work per batch; ranking of batch k overlapped with the similarity "
+                                              "of batch k+1 on a second stream (not the headline: see bench.py)"}
+    del sc2, rk2, ws2
 
 
 def launch_ranks(n):
@@ -181,7 +261,18 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] side legs")
     ap.add_argument("--extract-images", type=int, default=40,
                     help="images PER SIZE (16 sizes) of the (untimed) descriptors/sec leg: ResNet101-GeM, 3 scales + whitening; 0 = skip")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-stream throughput leg and the sort-free leg (side legs "
+                    "that launch the same kernels overlapped: they blur a kernel trace of the run)")
+    ap.add_argument("--profile", action="store_true", help="the headline loop only: --no-cpu-baseline --no-secondary --no-pipelined --extract-images 0")
+    ap.add_argument("--comm", choices=("torch", "mdx"), default=None,
+                    help="N > 1: the exchange of partial scores through torch.distributed (default) or through the C-ABI communicator "
+                         "(mdx_comm_* / mdx_exchange_scores over RCCL; same as MDIR_AMD_COMM=mdx)")
     args = ap.parse_args()
+    if args.profile:
+        args.no_cpu_baseline = args.no_secondary = args.no_pipelined = True
+        args.extract_images = 0
+    if args.comm:
+        os.environ["MDIR_AMD_COMM"] = args.comm
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` on its own: start the N rank processes as CHILDREN (one per GPU, RCCL) and relay
@@ -232,7 +323,7 @@ def main():
         sc = torch.empty((NQ, n_total), dtype=torch.float32, device=device)
         rk = torch.empty((NQ, n_total), dtype=torch.int64, device=device)
         ws = torch.empty(ops.rank_workspace_bytes(n_total, NQ), dtype=torch.uint8, device=device)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
 
         def step(i=None):
             if i is not None:
@@ -241,6 +332,8 @@ def main():
             if i is not None:
                 ev[i][1].record()
             ops.rank_full(sc, out=rk, workspace=ws)
+            if i is not None:
+                ev[i][2].record()
     else:
         ev = []
         keep = {}
@@ -281,7 +374,8 @@ def main():
         extra["ranking_verified_on_device"] = "all %d rows: permutation, non-increasing scores, ascending ids inside ties" % NQ
         assert bool((rk[:, 0].cpu() == torch.from_numpy(qid)).all()), "every query must retrieve its source row first"
         extra["map_medium"] = avg_r["map_medium"]
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+        rank_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev]))          # the 12 launches of one full ranking, HIP events
         flops = 2.0 * NQ * n_total * DIM
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         algo_bytes = 4.0 * n_total * DIM + 4.0 * NQ * DIM + 4.0 * NQ * n_total
@@ -319,56 +413,30 @@ def main():
             roofline["profiled_mfma_pipe_busy"] = prof.get("scores_kernel_mfma_pipe_busy")
             roofline["frac_of_peak_at_profiled_clock"] = round(achieved / (PEAK_F32_MFMA_TFLOPS * ghz / 2.4), 4)
         extra["roofline"] = roofline
-        extra["rank_ms_per_step"] = round(elapsed / args.steps * 1e3 - kernel_ms, 4)
-        # the same evaluation without materialising a ranking: similarity + rank positions of the labelled
-        # ids (mdx_rank_of) -- what compute_map actually needs; identical mAP (asserted above), reported beside
-        from mdir_amd.ops import _csr
-        lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
-        ids_t, off_t, _ = _csr(lists, device)
-        cnt = torch.zeros(ids_t.numel(), dtype=torch.int64, device=device)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            sharded.index.scores(qvecs, "DN", out=sc)
-            cnt.zero_()
-            ops.rank_count_(cnt, sc, 0, ops.gather_scores(sc, ids_t, off_t), ids_t, off_t)
-        torch.cuda.synchronize()
-        t_pos = (time.perf_counter() - t1) / args.steps
-        extra["sort_free_map_route"] = {"value": round(NQ / t_pos, 2), "unit": "queries/s", "ms_per_step": round(t_pos * 1e3, 4),
-                                        "what": "similarity + rank positions of the %d labelled ids (no full ranking), same mAP"
-                                                % int(ids_t.numel())}
-        # throughput form for a stream of batches: the ranking of batch k on a second stream while the similarity of batch
-        # k+1 runs (two score / rank buffers).  Reported beside the headline, which stays the one-stream step: overlapped,
-        # the two kernels share HBM and neither's own duration is a clean roofline figure any more.
-        sc2, rk2, ws2 = torch.empty_like(sc), torch.empty_like(rk), torch.empty_like(ws)
-        bufs, side, cur = ((sc, rk, ws), (sc2, rk2, ws2)), torch.cuda.Stream(device=device), torch.cuda.current_stream(device)
-
-        def piped(steps):
-            done = [None, None]
-            for k in range(steps):
-                b = k & 1
-                if done[b] is not None:
-                    cur.wait_event(done[b])            # the ranking that read this score buffer two batches ago is finished
-                sharded.index.scores(qvecs, "DN", out=bufs[b][0])
-                ready = torch.cuda.Event()
-                ready.record(cur)
-                side.wait_event(ready)
-                with torch.cuda.stream(side):
-                    ops.rank_full(bufs[b][0], out=bufs[b][1], workspace=bufs[b][2])
-                    done[b] = torch.cuda.Event()
-                    done[b].record(side)
-            cur.wait_stream(side)
-        piped(4)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        piped(args.steps)
-        torch.cuda.synchronize()
-        t_pipe = (time.perf_counter() - t1) / args.steps
-        assert bool((rk2 == rk).all())
-        extra["pipelined_two_streams"] = {"value": round(NQ / t_pipe, 2), "unit": "queries/s", "ms_per_step": round(t_pipe * 1e3, 4),
-                                          "what": "same kernels and work per batch; ranking of batch k overlapped with the similarity "
-                                                  "of batch k+1 on a second stream (not the headline: see bench.py)"}
-        del sc2, rk2, ws2
+        extra["rank_ms_per_step"] = round(rank_ms, 4)
+        extra["step_ms_minus_kernels"] = round(elapsed / args.steps * 1e3 - kernel_ms - rank_ms, 4)     # host / launch gaps: ~0
+        # the second kernel family of the step: np.argsort(-scores, axis=0) (cirscore.py:70) as a 4-pass LSD radix sort.
+        # HBM-bound; algorithmic bytes = the argsort itself (4 B read + 8 B written per element), traffic = what
+        # the four passes really move (committed PMC summary, like the similarity kernel's)
+        rank_algo = 12.0 * NQ * n_total
+        rank_traffic = rank_src = None
+        if tf:
+            whole = json.load(open(tf[-1]))
+            rank_traffic = ranking_traffic(whole)
+            rank_src = "committed PMC summary %s (not measured in this run)" % os.path.relpath(tf[-1], ROOT)
+            if whole.get("rank_source_sha16") not in (None, rank_source_sha16()):
+                rank_traffic, rank_src = None, rank_src + ": STALE (mdx_rank.hip changed since)"
+        extra["roofline_rank"] = {
+            "kernel": "mdx::sort_hist_kernel / sort_scan_kernel / sort_scatter_kernel x 4 passes (8-bit LSD radix, packed intermediates)",
+            "bound": "hbm", "achieved": round(rank_algo / (rank_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(rank_algo / (rank_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": rank_traffic, "traffic_source": rank_src,
+            "kernel_ms": round(rank_ms, 4), "algorithmic_bytes": rank_algo,
+            "traffic_over_algorithmic": round(rank_traffic / rank_algo, 2) if rank_traffic else None,
+            "hbm_GBps_at_real_traffic": round(rank_traffic / (rank_ms * 1e-3) / 1e9, 1) if rank_traffic else None,
+            "what": "12 launches per ranking; the 4-pass form moves ~4.8x the bytes of an ideal one-pass argsort and streams them at the "
+                    "rate HBM gives a read+write mix (DESIGN section 4): only fewer passes would help, and the MSD / one-sweep forms measured slower"}
+        if not args.no_pipelined:
+            side_legs(args, sharded, qvecs, sc, rk, ws, gnd, device, extra)
     else:
         rk_mine, sc_mine, (qlo, qhi) = keep["rk"], keep["sc"], keep["q"]
         ok = torch.tensor([1], device="cpu" if dryrun else device)

@@ -247,6 +247,26 @@ int mdx_scores(const mdx_index *index, const float *queries, int64_t nq, int qla
                const float *center, float *scores, void *workspace, int64_t workspace_bytes,
                void *stream);
 
+/* How mdx_scores_ex multiplies an fp32 shard.
+ *   MDX_F32_CHAIN   the exact path of mdx_scores (k-ordered fp32 fma chain on the fp32 MFMA; the parity contract).
+ *   MDX_F32_SPLIT3  split precision, a LABELLED second mode for the same statement (cirscore.py:69) on the SAME shard
+ *                   (nothing is re-quantised or copied): every fp32 operand is written as three bf16 pieces
+ *                   x = h + m + l (round to nearest even, residuals exact; the shard's tiles are split in registers by
+ *                   the waves that multiply them, the queries once per call) and a product as the six piece products
+ *                   hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- dropped terms
+ *                   <= 2^-23 of a product, below fp32's own rounding.  6/16 of the fp32 MFMA time: the kernel is bound
+ *                   by the shard stream (HBM) instead of the matrix pipe.  NOT bit-equal to the chain: the accumulation
+ *                   order differs (measured ~1e-7 on unit-norm descriptors; tests/test_gpu_round4.py bounds it by 2e-6,
+ *                   the summation-order bound bench.py holds the reference's own BLAS path to).  fp32 range (bf16 has
+ *                   fp32's exponent); an infinite operand gives NaN. */
+typedef enum mdx_compute { MDX_F32_CHAIN = 0, MDX_F32_SPLIT3 = 1 } mdx_compute;
+
+/* mdx_scores with an explicit compute mode; workspace of at least mdx_scores_workspace_ex(nq, d, compute) bytes
+ * (MDX_F32_SPLIT3: 6 bytes per padded query element).  MDX_F32_SPLIT3 needs an MDX_F32 shard. */
+int64_t mdx_scores_workspace_ex(int64_t nq, int64_t d, int compute);
+int mdx_scores_ex(const mdx_index *index, const float *queries, int64_t nq, int qlayout, const float *center,
+                  float *scores, void *workspace, int64_t workspace_bytes, int compute, void *stream);
+
 /* ------------------------------------------------------------------ ranking */
 
 int64_t mdx_rank_workspace(int64_t n, int64_t nq);

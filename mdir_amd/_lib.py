@@ -15,6 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 MDX_DIM_MAJOR, MDX_ROW_MAJOR = 0, 1
 MDX_POOL_GEM, MDX_POOL_MAC, MDX_POOL_SPOC = 0, 1, 2
 MDX_F32, MDX_F16 = 0, 1
+MDX_F32_CHAIN, MDX_F32_SPLIT3 = 0, 1
+COMPUTE = {"chain": MDX_F32_CHAIN, "exact": MDX_F32_CHAIN, "split3": MDX_F32_SPLIT3}
 STORAGE = {"f32": MDX_F32, "f16": MDX_F16}
 POOL_KINDS = {"gem": MDX_POOL_GEM, "mac": MDX_POOL_MAC, "spoc": MDX_POOL_SPOC}
 
@@ -75,6 +77,8 @@ def _declare(lib):
         "mdx_index_info": (i32, [p, pi64, pi64, pi64, pi64]),
         "mdx_scores_workspace": (i64, [i64, i64]),
         "mdx_scores": (i32, [p, p, i64, i32, p, p, p, i64, p]),
+        "mdx_scores_workspace_ex": (i64, [i64, i64, i32]),
+        "mdx_scores_ex": (i32, [p, p, i64, i32, p, p, p, i64, i32, p]),
         "mdx_rank_workspace": (i64, [i64, i64]),
         "mdx_rank_full": (i32, [p, i64, i64, i64, p, p, i64, p]),
         "mdx_rank_full_segments": (i32, [pp, pi64, i32, i64, i64, p, p, i64, p]),
@@ -105,7 +109,7 @@ def _declare(lib):
 EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
            "mdx_ms_aggregate_batch", "mdx_pool_multi", "mdx_l2n_aggregate", "mdx_bn_act", "mdx_u8_to_chw", "mdx_resample_u8", "mdx_bilinear_pyramid", "mdx_jpeg_probe", "mdx_jpeg_coefficients", "mdx_jpeg_pixels",
            "mdx_index_create", "mdx_index_create_ex", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
-           "mdx_scores", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of",
+           "mdx_scores", "mdx_scores_workspace_ex", "mdx_scores_ex", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of",
            "mdx_gather_scores", "mdx_rank_count", "mdx_conv1x1_transpose_weights", "mdx_conv1x1_bn_act", "mdx_clahe_workspace", "mdx_clahe_u8_to_chw", "mdx_gram_f64_workspace", "mdx_gram_f64", "mdx_project_f64_workspace", "mdx_project_f64", "mdx_comm_unique_id", "mdx_comm_init",
            "mdx_comm_destroy", "mdx_comm_info", "mdx_query_bounds", "mdx_allgather_scores", "mdx_exchange_scores")
 

@@ -15,6 +15,7 @@
 
 #include "mdx_common.h"
 #include "mdx_scores_kernel.h"
+#include "mdx_scores_split_kernel.h"
 
 namespace mdx {
 
@@ -173,6 +174,38 @@ static int dispatch_qt(int qt, int mode, const f32x4 *db, const f32x4 *q, float 
     }
 }
 
+// Split-precision launches (mdx_scores_split_kernel.h): 8 consumer waves x R row tiles + 4 loader waves, one workgroup
+// per CU, ring of 3 stages of (3 QT + 16 R) KiB.  Up to SPLIT_QT query tiles per workgroup; more queries = more passes (grid.y).
+constexpr int SPLIT_CW = 8, SPLIT_NSTAGE = 3, SPLIT_QT = 5;
+
+template <int QT, int R>
+static int launch_split3(const f32x4 *db, const u32x4 *qp, float *out, int64_t n, int64_t RT, int KB, int QT_total,
+                         int qt_first, int nq_valid, hipStream_t s, int passes)
+{
+    auto kern = scores_split3_kernel<QT, R, SPLIT_NSTAGE, SPLIT_CW>;
+    constexpr int lds = SPLIT_NSTAGE * (3 * QT + 2 * SPLIT_CW * R) * 1024;
+    static bool opted[64];
+    int rc = lds_opt_in((const void *)kern, lds, opted);
+    if (rc != MDX_OK) return rc;
+    const int64_t blocks = ceil_div(RT, (int64_t)SPLIT_CW * R);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(SPLIT_CW * 64 + 256), lds, s, db, qp, out, n, KB,
+                       QT_total, qt_first, nq_valid);
+    return MDX_OK;
+}
+
+template <int R>
+static int dispatch_split3(int qt, const f32x4 *db, const u32x4 *qp, float *out, int64_t n, int64_t RT, int KB, int QT_total,
+                           int qt_first, int nq_valid, hipStream_t s, int passes)
+{
+    switch (qt) {
+        case 1: return launch_split3<1, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, s, passes);
+        case 2: return launch_split3<2, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, s, passes);
+        case 3: return launch_split3<3, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, s, passes);
+        case 4: return launch_split3<4, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, s, passes);
+        default: return launch_split3<5, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, s, passes);
+    }
+}
+
 }  // namespace mdx
 
 using namespace mdx;
@@ -228,7 +261,7 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
     ix->d_pad = round_up(d, 64);                                  // 4 fp32 or 2 fp16 k-blocks
     ix->KB = ix->d_pad / (storage == MDX_F16 ? 32 : TILE_K);
     ix->RT = ceil_div(n, TILE_ROWS);
-    ix->RT_pad = round_up(ix->RT, 8);  // every wave of every workgroup has a tile to read
+    ix->RT_pad = round_up(ix->RT, 16); // every wave of every workgroup has a tile to read (16 row tiles: the split-precision workgroup)
     ix->row_offset = row_offset;
     ix->bytes = ix->RT_pad * ix->KB * 1024;
     hipError_t e = hipMalloc((void **)&ix->tiles, (size_t)ix->bytes);
@@ -344,6 +377,50 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
         if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK();
     }
+    return MDX_OK;
+}
+
+int64_t mdx_scores_workspace_ex(int64_t nq, int64_t d, int compute)
+{
+    if (nq <= 0 || d <= 0) return 0;
+    if (compute == MDX_F32_SPLIT3) return round_up(nq, TILE_ROWS) * round_up(d, 64) * 6;      // three bf16 pieces per element
+    return mdx_scores_workspace(nq, d);
+}
+
+int mdx_scores_ex(const mdx_index *ix, const float *queries, int64_t nq, int qlayout, const float *center, float *scores,
+                  void *workspace, int64_t workspace_bytes, int compute, void *stream)
+{
+    if (compute == MDX_F32_CHAIN) return mdx_scores(ix, queries, nq, qlayout, center, scores, workspace, workspace_bytes, stream);
+    MDX_CHECK_ARG(compute == MDX_F32_SPLIT3, "mdx_scores_ex: compute mode %d", compute);
+    MDX_CHECK_ARG(ix && queries && scores, "mdx_scores_ex: NULL pointer");
+    MDX_CHECK_ARG(ix->storage == MDX_F32, "mdx_scores_ex: MDX_F32_SPLIT3 multiplies an fp32 shard (this one is stored as fp16)");
+    MDX_CHECK_ARG(nq > 0 && nq < (1 << 20), "mdx_scores_ex: nq=%lld", (long long)nq);
+    MDX_CHECK_ARG(qlayout == MDX_DIM_MAJOR || qlayout == MDX_ROW_MAJOR, "mdx_scores_ex: qlayout %d", qlayout);
+    const int64_t need = mdx_scores_workspace_ex(nq, ix->d, compute);
+    if (!workspace || workspace_bytes < need) {
+        set_error("mdx_scores_ex: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+        return MDX_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    u32x4 *qp = (u32x4 *)workspace;
+    const int64_t QT_total = ceil_div(nq, TILE_ROWS), NC = ix->KB / 2;
+    const int64_t rs = qlayout == MDX_DIM_MAJOR ? 1 : ix->d, ks = qlayout == MDX_DIM_MAJOR ? nq : 1;
+    hipLaunchKernelGGL(retile_split3_kernel, dim3((unsigned)ceil_div(QT_total * NC, (int64_t)4)), dim3(256), 0, s, queries, rs, ks, nq, ix->d,
+                       center, qp, QT_total, NC);
+    MDX_LAUNCH_CHECK();
+    const bool small = ix->RT < 4096;                 // < 65 536 rows: 128-row workgroups, so that the shard still spreads over the CUs
+    const int64_t full = QT_total / SPLIT_QT, rem = QT_total % SPLIT_QT;
+    int rc = MDX_OK;
+    for (int64_t g0 = 0; g0 < full && rc == MDX_OK; g0 += 32768) {      // grid.y < 65 536
+        const int passes = (int)((full - g0) < 32768 ? (full - g0) : 32768);
+        rc = small ? dispatch_split3<1>(SPLIT_QT, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)(g0 * SPLIT_QT), (int)nq, s, passes)
+                   : dispatch_split3<2>(SPLIT_QT, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)(g0 * SPLIT_QT), (int)nq, s, passes);
+    }
+    if (rc == MDX_OK && rem)
+        rc = small ? dispatch_split3<1>((int)rem, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)(full * SPLIT_QT), (int)nq, s, 1)
+                   : dispatch_split3<2>((int)rem, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)(full * SPLIT_QT), (int)nq, s, 1);
+    if (rc != MDX_OK) return rc;
+    MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
 

@@ -374,10 +374,13 @@ class DescriptorIndex:
         check(_lib.lib().mdx_index_info(self._h, None, None, None, ctypes.byref(b)), "mdx_index_info")
         return b.value
 
-    def scores(self, queries, qlayout="DN", center=None, out=None):
+    def scores(self, queries, qlayout="DN", center=None, out=None, compute="chain"):
         """fp32 ``[nq, n]``: row q = similarities of query q to every shard row.
 
-        The transpose of ``np.dot(vecs.T, qvecs)`` (cirscore.py:69)."""
+        The transpose of ``np.dot(vecs.T, qvecs)`` (cirscore.py:69).  ``compute="chain"`` (default): the exact k-ordered
+        fp32 fma chain; ``"split3"``: the labelled split-precision mode on the same fp32 shard (three bf16 pieces per
+        operand, six products on the bf16 MFMA, fp32 accumulation: HBM-bound instead of fp32-MFMA-bound; scores within
+        the summation-order bound 2e-6 of the chain, ``include/mdx.h`` ``MDX_F32_SPLIT3``)."""
         if self._h is None:
             raise RuntimeError("index is closed")
         nq, d, lay = _layout(queries, qlayout, "queries")
@@ -391,11 +394,16 @@ class DescriptorIndex:
             out = torch.empty((nq, self.n), dtype=torch.float32, device=self.device)
         elif tuple(out.shape) != (nq, self.n):
             raise ValueError("out must be [%d,%d]" % (nq, self.n))
-        need = _lib.lib().mdx_scores_workspace(nq, d)
+        if compute not in _lib.COMPUTE:
+            raise ValueError("compute %r (one of %s)" % (compute, sorted(_lib.COMPUTE)))
+        mode = _lib.COMPUTE[compute]
+        if mode != _lib.MDX_F32_CHAIN and self.storage != "f32":
+            raise ValueError("compute=%r multiplies an fp32 shard; this one is stored as %s" % (compute, self.storage))
+        need = _lib.lib().mdx_scores_workspace_ex(nq, d, mode)
         ws = _workspace(need, self.device)
         with torch.cuda.device(self.device):
-            check(_lib.lib().mdx_scores(self._h, qp, nq, lay, cp, _dev(out, torch.float32, "out"),
-                                        _vp(ws.data_ptr()), need, _stream()), "mdx_scores")
+            check(_lib.lib().mdx_scores_ex(self._h, qp, nq, lay, cp, _dev(out, torch.float32, "out"),
+                                           _vp(ws.data_ptr()), need, mode, _stream()), "mdx_scores_ex")
         return out
 
     def close(self):

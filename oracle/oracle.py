@@ -174,6 +174,35 @@ def scores(vecs, qvecs):
     return np.dot(np.asarray(vecs, dtype=F32).T, np.asarray(qvecs, dtype=F32))
 
 
+def bf16_round(x):
+    """fp32 -> the nearest bfloat16 (ties to even), returned as fp32: what ``v_cvt_pk_bf16_f32`` does to a finite value."""
+    u = np.ascontiguousarray(x, dtype=F32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(F32).reshape(np.shape(x))
+
+
+def split3_bf16(x):
+    """``x = h + m + l + e`` with bf16 pieces ``h = bf16(x)``, ``m = bf16(x - h)``, ``l = bf16(x - h - m)`` (the
+    residuals are exact in fp32) -- the operand split of the library's labelled split-precision similarity
+    (``MDX_F32_SPLIT3``, include/mdx.h; mdir_amd/csrc/mdx_scores_split_kernel.h).  Test infrastructure."""
+    x = np.asarray(x, dtype=F32)
+    h = bf16_round(x)
+    r = x - h
+    m = bf16_round(r)
+    l = bf16_round(r - m)
+    return h, m, l
+
+
+def scores_split3(vecs, qvecs):
+    """The split-precision form of ``np.dot(vecs.T, qvecs)`` (cirscore.py:69) as the library computes it, up to the
+    order of the fp32 accumulation (here: every product exact, summed in float64): the six piece products
+    ``hh + hm + mh + hl + lh + mm``.  ``[D,N]``, ``[D,Q]`` -> fp32 ``[N,Q]``."""
+    dh, dm, dl = (p.astype(np.float64) for p in split3_bf16(vecs))
+    qh, qm, ql = (p.astype(np.float64) for p in split3_bf16(qvecs))
+    s = dh.T @ qh + (dh.T @ qm + dm.T @ qh) + (dh.T @ ql + dl.T @ qh + dm.T @ qm)
+    return s.astype(F32)
+
+
 def ranks(sc):
     """Per-query descending ranking ``[N,Q] -> int64 [N,Q]``.
 

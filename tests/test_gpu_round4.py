@@ -90,3 +90,69 @@ def test_malformed_jpeg_through_extraction_and_infer(tmp_path, monkeypatch):
     with torch.no_grad():
         again = extract_vectors(gpu_net, clean, 224, tr, device=DEV).numpy()
     np.testing.assert_array_equal(again, want)
+
+
+# ------------------------------------------------------------------------------------------------ split precision
+SUM_ORDER_TOL = 2e-6        # bench.py: two correct fp32 evaluations of a 2048-term dot product of unit vectors differ by less
+
+# the 21 shapes of tests/test_gpu_kernels.py::test_scores_bit_exact_vs_chain
+SPLIT_SHAPES = [(4993, 2048, 70), (6322, 2048, 70), (1000, 512, 1), (333, 100, 17), (16, 64, 16), (5000, 256, 130), (70, 2048, 70),
+                (40000, 128, 24), (32768, 32, 33), (33000, 64, 100), (50000, 48, 120), (70000, 64, 1), (66001, 100, 17),
+                (70001, 256, 130), (65600, 2048, 70), (65537, 32, 128), (131072, 96, 33),
+                (1125, 512, 1125), (3000, 128, 300), (40000, 64, 389), (2000, 256, 256)]
+
+
+def _unit_rows(rng, n, d):
+    v = rng.standard_normal((n, d)).astype(np.float32)
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("n,d,nq", SPLIT_SHAPES)
+def test_split3_scores_within_summation_order_of_the_chain(n, d, nq):
+    """MDX_F32_SPLIT3 (cirscore.py:69 on the bf16 MFMA, three bf16 pieces per fp32 operand) against the exact chain oracle:
+    |score - chain| <= 2e-6, the bound bench.py holds the reference's own BLAS path to; against the float64 dot product it
+    is as good as the chain itself; both input layouts give the same bits; the same shard serves both modes."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(n + d + nq)
+    db, qv = _unit_rows(rng, n, d), _unit_rows(rng, nq, d)
+    vecs, qvecs = np.ascontiguousarray(db.T), np.ascontiguousarray(qv.T)
+    chain = OC.scores_chain(vecs, qvecs)
+    ix = ops.DescriptorIndex(dev(vecs), "DN")
+    got = ix.scores(dev(qvecs), "DN", compute="split3").cpu().numpy()
+    assert got.shape == chain.shape and np.isfinite(got).all()
+    assert np.abs(got - chain).max() <= SUM_ORDER_TOL
+    exact = (qv.astype(np.float64) @ db.astype(np.float64).T)
+    err_split, err_chain = np.abs(got - exact).max(), np.abs(chain - exact).max()
+    assert err_split <= max(2.0 * err_chain, 2e-7), (err_split, err_chain)
+    # the restatement of the split (every product exact, float64 sums) differs only by fp32 accumulation
+    if n * nq <= 2_000_000:
+        np.testing.assert_allclose(got.T, O.scores_split3(vecs, qvecs), rtol=0, atol=1e-6)
+    got2 = ops.DescriptorIndex(dev(db), "ND").scores(dev(qv), "ND", compute="split3").cpu().numpy()
+    np.testing.assert_array_equal(got2, got)
+    np.testing.assert_array_equal(ix.scores(dev(qvecs), "DN").cpu().numpy(), chain)      # the exact mode of the same index
+
+
+def test_split3_edge_values_center_and_errors():
+    from mdir_amd import ops
+    rng = np.random.default_rng(9)
+    n, d, nq = 700, 200, 21
+    db = rng.standard_normal((n, d)).astype(np.float32) * np.float32(1e3)        # not unit norm: fp32 range, not fp16's
+    db[3] = 0
+    db[5] *= np.float32(1e-20)
+    db[7, :4] = [3.0e30, -3.0e30, 1e-38, 1.5]                                       # near the ends of the fp32 range
+    qv = rng.standard_normal((nq, d)).astype(np.float32)
+    qv[2] = 0
+    m = rng.standard_normal(d).astype(np.float32)
+    ix = ops.DescriptorIndex(dev(db), "ND")
+    got = ix.scores(dev(qv), "ND", center=dev(m), compute="split3").cpu().numpy()
+    want = (qv - m).astype(np.float64) @ db.astype(np.float64).T
+    assert np.isfinite(got).all() and (got[:, 3] == 0).all()
+    scale = np.abs((qv - m).astype(np.float64)) @ np.abs(db.astype(np.float64)).T + 1e-300
+    assert (np.abs(got - want) / scale).max() < 3e-7                              # relative to sum |q_k||x_k|: fp32-grade
+    exactm = ix.scores(dev(qv), "ND", center=dev(m)).cpu().numpy()
+    assert (np.abs(exactm - want) / scale).max() < 3e-7
+    half = ops.DescriptorIndex(dev(db[:64] * np.float32(1e-3)), "ND", storage="f16")
+    with pytest.raises(ValueError, match="fp32 shard"):
+        half.scores(dev(qv), "ND", compute="split3")
+    with pytest.raises(ValueError, match="compute"):
+        ix.scores(dev(qv), "ND", compute="tf32")

@@ -1,0 +1,66 @@
+// Timing harness for the split-precision similarity kernel (mdx_scores_split_kernel.h): shapes of the workgroup and
+// timing-only ablations (ABL != 0: results wrong), all variants interleaved in one process on gaussian data of the real
+// magnitude (low-entropy data runs faster through DVFS and misleads).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdir_amd/csrc tools/split_ablate.hip -o tools/split_ablate_bin
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <vector>
+#include "mdx_scores_split_kernel.h"
+namespace mdx { void set_error(const char *, ...) {} }
+using namespace mdx;
+
+int main(int argc, char **argv)
+{
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 1004993, d = 2048;
+    const int KB = d / 16, NC = KB / 2, QTT = 5, NQ = 70;
+    const int64_t RT = (n + 15) / 16, RTp = (RT + 31) / 32 * 32;
+    f32x4 *db; u32x4 *qp; float *out;
+    hipMalloc(&db, (size_t)RTp * KB * 1024); hipMalloc(&qp, (size_t)3 * QTT * NC * 1024); hipMalloc(&out, (size_t)80 * n * 4);
+    {
+        std::vector<float> h((size_t)RTp * KB * 256);
+        unsigned long long st = 88172645463325252ull;
+        auto u = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((st >> 11) * (1.0 / 9007199254740992.0)); };
+        for (size_t i = 0; i < h.size(); i += 2) {
+            const float r = sqrtf(-2.0f * logf(u() + 1e-12f)) * 0.0221f, a = 6.2831853f * u();
+            h[i] = r * cosf(a); h[i + 1] = r * sinf(a);
+        }
+        hipMemcpy(db, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        // query pieces: bf16 pairs of gaussian values (piece 1, 2 scaled down as real residuals are)
+        std::vector<uint32_t> q((size_t)3 * QTT * NC * 256);
+        for (size_t i = 0; i < q.size(); ++i) {
+            const int piece = (int)(i / ((size_t)QTT * NC * 256));
+            const float sc = piece == 0 ? 1.0f : (piece == 1 ? 1.0f / 256 : 1.0f / 65536);
+            uint32_t a, b; float fa = h[2 * i] * sc, fb = h[2 * i + 1] * sc;
+            memcpy(&a, &fa, 4); memcpy(&b, &fb, 4);
+            q[i] = (a >> 16) | (b & 0xFFFF0000u);
+        }
+        hipMemcpy(qp, q.data(), q.size() * 4, hipMemcpyHostToDevice);
+    }
+    auto go = [&](auto kern, int QT_, int R_, int NST, int CW_) {
+        const size_t lds = (size_t)NST * (3 * QT_ + 2 * CW_ * R_) * 1024;
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int64_t blocks = (RT + CW_ * R_ - 1) / (CW_ * R_);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64 + 256), lds, 0, db, qp, out, n, KB, QTT, 0, NQ);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64 + 256), lds, 0, db, qp, out, n, KB, QTT, 0, NQ);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
+        return ms / 10;
+    };
+    for (int rep = 0; rep < 3; ++rep) {
+        printf("shapes  CW8 R2 NST3 %.4f | CW4 R4 NST3 %.4f | CW8 R1 NST4 %.4f | CW8 R1 NST5 %.4f | CW4 R2 NST4 %.4f | CW8 R2 NST2 %.4f | default-policy db CW8 R2 NST3 %.4f ms\n",
+               go(scores_split3_kernel<5, 2, 3, 8>, 5, 2, 3, 8), go(scores_split3_kernel<5, 4, 3, 4>, 5, 4, 3, 4),
+               go(scores_split3_kernel<5, 1, 4, 8>, 5, 1, 4, 8), go(scores_split3_kernel<5, 1, 5, 8>, 5, 1, 5, 8),
+               go(scores_split3_kernel<5, 2, 4, 4>, 5, 2, 4, 4), go(scores_split3_kernel<5, 2, 2, 8>, 5, 2, 2, 8),
+               go(scores_split3_kernel<5, 2, 3, 8, 0>, 5, 2, 3, 8));
+        printf("ablate  CW8 R2 NST3: full %.4f | no split %.4f | no MFMA %.4f | stream + barriers only %.4f ms\n",
+               go(scores_split3_kernel<5, 2, 3, 8>, 5, 2, 3, 8), go(scores_split3_kernel<5, 2, 3, 8, 2, 1>, 5, 2, 3, 8),
+               go(scores_split3_kernel<5, 2, 3, 8, 2, 2>, 5, 2, 3, 8), go(scores_split3_kernel<5, 2, 3, 8, 2, 3>, 5, 2, 3, 8));
+        fflush(stdout);
+    }
+    return 0;
+}

@@ -61,9 +61,11 @@ for k in sq:            # sustained clock and MFMA pipe occupancy of the similar
             clock = cyc / (sum(durs) / len(durs))                   # cycles per ns = GHz
             mfma_busy = sum(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024 / cyc
 sys.path.insert(0, root)
-from bench import scores_source_sha16          # ties the figures below to the kernel sources they were measured on
+from bench import rank_source_sha16, ranking_traffic, scores_source_sha16      # tie the figures below to the sources they were measured on
 out = {"note": "HBM bytes per launch; FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1; KiB -> bytes",
        "scores_kernel_source_sha16": scores_source_sha16(),
+       "rank_source_sha16": rank_source_sha16(),
+       "ranking_hbm_bytes_per_ranking": ranking_traffic({"per_kernel": traffic}),
        "per_kernel": traffic,
        "scores_kernel_hbm_bytes_per_launch": traffic[sk[0]]["total_bytes"] if sk else None,
        "scores_kernel_sustained_clock_ghz": round(clock, 3) if clock else None,
@@ -76,7 +78,7 @@ for line in open(os.path.join(src, "stats_bench.log")):
         bench = json.loads(line)
 with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
     f.write("# rocprofv3 summary, round %s\n\n" % tag)
-    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --extract-images 16` "
+    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --profile` (the headline loop alone) "
             "(N=1 004 993, Q=70, D=2048 fp32, 20 timed + 3 warm-up steps); PMC passes in separate runs "
             "(`tools/profile_round.sh`).\n\n")
     if bench:
@@ -84,6 +86,17 @@ with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
                 "(%.1f TFLOP/s = %.1f %% of 157.3).\n\n" % (bench["value"], bench["ms_per_step"],
                                                            bench["roofline"]["kernel_ms"], bench["roofline"]["achieved"],
                                                            100 * bench["roofline"]["frac"]))
+        # the sort kernels of ONE ranking (4 histograms, 4 scans, 4 scatters) against the bench's own HIP-event figure
+        per_rank = 0.0
+        for r in keep:
+            if "::sort_" in r["Name"]:
+                per_rank += float(r["AverageNs"]) / 1e3 * (4 if "sort_scan_kernel" in r["Name"] else 1)
+        sk_avg = [float(r["AverageNs"]) / 1e3 for r in keep if "::scores_lc_kernel" in r["Name"] and int(r["Calls"]) >= bench["steps"]]
+        if per_rank and bench.get("rank_ms_per_step"):
+            f.write("Ranking: the sort kernels' trace averages add up to %.1f us per ranking; bench `rank_ms_per_step` (HIP events around "
+                    "the 12 launches) = %.1f us (ratio %.3f).  Similarity kernel: trace average %.1f us, HIP events %.1f us.  "
+                    "Step: %.1f us by the wall clock.\n\n" % (per_rank, 1e3 * bench["rank_ms_per_step"], per_rank / (1e3 * bench["rank_ms_per_step"]),
+                                                               sk_avg[0] if sk_avg else float("nan"), 1e3 * bench["roofline"]["kernel_ms"], 1e3 * bench["ms_per_step"]))
     f.write("| kernel | calls | avg us | total ms | HBM read MB/launch | HBM write MB/launch |\n|---|---:|---:|---:|---:|---:|\n")
     for r in keep:
         k = short(r["Name"])
