@@ -16,6 +16,9 @@
 // uneven forms are grouped ncclSend / ncclRecv pairs -- one transfer per link, no ring.  The exchange calls make no HIP call of
 // their own (tests/fake_rccl.c stands in for RCCL on a CPU box and runs them with host buffers, several ranks as threads).
 #include <dlfcn.h>
+
+#include <mutex>
+
 #include <rccl/rccl.h>
 
 #include "mdx_common.h"
@@ -35,36 +38,45 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-// nullptr + message when RCCL cannot be found
+// nullptr + message when RCCL cannot be found.  Resolved ONCE per process under std::call_once: ranks-as-threads is an
+// advertised mode (tests/fake_rccl.c, C hosts), so two threads may make their first communicator call together -- neither
+// may see a half-filled table.  The failure text is kept and re-posted to every caller's thread-local error slot.
 static const Rccl *rccl()
 {
     static Rccl r;
-    static bool tried = false, ok = false;
-    if (tried) return ok ? &r : nullptr;
-    tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (const char *n : names)                     // the copy this process already has (PyTorch's), if any
-        if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-    for (const char *n : names)
-        if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.handle) {
-        set_error("mdx_comm: librccl.so.1 not found (%s)", dlerror());
-        return nullptr;
-    }
+    static std::once_flag once;
+    static bool ok = false;
+    static char why[256] = "";
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names)                     // the copy this process already has (PyTorch's), if any
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *n : names)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.handle) {
+            const char *e = dlerror();
+            snprintf(why, sizeof why, "mdx_comm: librccl.so.1 not found (%s)", e ? e : "?");
+            return;
+        }
 #define MDX_SYM(field, name)                                                    \
     *(void **)(&r.field) = dlsym(r.handle, name);                               \
-    if (!r.field) { set_error("mdx_comm: RCCL lacks %s", name); return nullptr; }
-    MDX_SYM(GetUniqueId, "ncclGetUniqueId")
-    MDX_SYM(CommInitRank, "ncclCommInitRank")
-    MDX_SYM(CommDestroy, "ncclCommDestroy")
-    MDX_SYM(AllGather, "ncclAllGather")
-    MDX_SYM(Send, "ncclSend")
-    MDX_SYM(Recv, "ncclRecv")
-    MDX_SYM(GroupStart, "ncclGroupStart")
-    MDX_SYM(GroupEnd, "ncclGroupEnd")
-    MDX_SYM(GetErrorString, "ncclGetErrorString")
+    if (!r.field) { snprintf(why, sizeof why, "mdx_comm: RCCL lacks %s", name); return; }
+        MDX_SYM(GetUniqueId, "ncclGetUniqueId")
+        MDX_SYM(CommInitRank, "ncclCommInitRank")
+        MDX_SYM(CommDestroy, "ncclCommDestroy")
+        MDX_SYM(AllGather, "ncclAllGather")
+        MDX_SYM(Send, "ncclSend")
+        MDX_SYM(Recv, "ncclRecv")
+        MDX_SYM(GroupStart, "ncclGroupStart")
+        MDX_SYM(GroupEnd, "ncclGroupEnd")
+        MDX_SYM(GetErrorString, "ncclGetErrorString")
 #undef MDX_SYM
-    ok = true;
+        ok = true;
+    });
+    if (!ok) {
+        set_error("%s", why);
+        return nullptr;
+    }
     return &r;
 }
 
@@ -126,7 +138,11 @@ int mdx_comm_destroy(mdx_comm *c)
 {
     if (!c) return MDX_OK;
     const Rccl *R = rccl();
-    ncclResult_t r = R ? R->CommDestroy(c->comm) : ncclSuccess;
+    if (!R) {                           // cannot happen after a successful mdx_comm_init in this process; never a silent leak
+        delete c;
+        return MDX_ERR_RUNTIME;
+    }
+    ncclResult_t r = R->CommDestroy(c->comm);
     delete c;
     if (r != ncclSuccess) {
         set_error("mdx_comm_destroy: ncclCommDestroy failed: %s", R->GetErrorString(r));
@@ -156,6 +172,11 @@ static int check_widths(const mdx_comm *c, const int64_t *widths, int64_t nq, co
 {
     MDX_CHECK_ARG(c && widths, "%s: NULL pointer", who);
     MDX_CHECK_ARG(nq >= 0, "%s: nq=%lld", who, (long long)nq);
+    if (c->device >= 0) {               // a communicator belongs to the device that was current at mdx_comm_init: work enqueued with
+        int cur = -1;                   // another device current would go to the wrong GPU's stream and fail obscurely or hang
+        if (hipGetDevice(&cur) == hipSuccess)
+            MDX_CHECK_ARG(cur == c->device, "%s: the communicator was created on device %d, device %d is current", who, c->device, cur);
+    }
     for (int g = 0; g < c->nranks; ++g) MDX_CHECK_ARG(widths[g] >= 0, "%s: widths[%d] negative", who, g);
     return MDX_OK;
 }

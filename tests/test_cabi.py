@@ -71,6 +71,19 @@ def test_round3_entry_points_check_their_arguments():
     assert h.mdx_exchange_scores(None, None, 1, None, None, None) == -1 and h.mdx_comm_destroy(None) == 0
 
 
+def test_round4_entry_points_check_their_arguments():
+    """mdx_scores_ex / mdx_scores_workspace_ex (MDX_F32_SPLIT3) refuse bad arguments before touching a device."""
+    import ctypes
+    from mdir_amd import _lib
+    h = _lib.lib()
+    assert h.mdx_scores_workspace_ex(70, 2048, _lib.MDX_F32_SPLIT3) == 80 * 2048 * 6           # three bf16 pieces per padded element
+    assert h.mdx_scores_workspace_ex(70, 2048, _lib.MDX_F32_CHAIN) == h.mdx_scores_workspace(70, 2048)
+    assert h.mdx_scores_workspace_ex(0, 2048, _lib.MDX_F32_SPLIT3) == 0
+    assert h.mdx_scores_ex(None, None, 1, 0, None, None, None, 0, _lib.MDX_F32_SPLIT3, None) == -1 and b"NULL" in h.mdx_last_error()
+    assert h.mdx_scores_ex(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 0, None, ctypes.c_void_p(16), None, 0, 7, None) == -1
+    assert b"compute mode" in h.mdx_last_error()
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from mdir_amd import ops

@@ -20,6 +20,23 @@ from mdir_amd import _lib
 lib = _lib.lib()
 i64 = ctypes.c_int64
 
+# the FIRST communicator calls of the process, from 8 threads at once (ranks-as-threads hosts): RCCL is resolved under
+# std::call_once, so every one of them finds the whole symbol table (a plain `static bool tried` let a second thread in
+# while the first was still filling it: NULL calls, or "not found" with no message)
+gate, first = threading.Barrier(8), []
+
+
+def first_call():
+    ident = (ctypes.c_char * 128)()
+    gate.wait()
+    first.append((lib.mdx_comm_unique_id(ident), bytes(ident)[:4]))
+
+
+ts = [threading.Thread(target=first_call) for _ in range(8)]
+[t.start() for t in ts]
+[t.join(60) for t in ts]
+assert first == [(0, b"ZZZZ")] * 8, first
+
 
 def run(G, nq, widths, call):
     rng = np.random.default_rng(G * 100 + nq)

@@ -156,3 +156,51 @@ def test_split3_edge_values_center_and_errors():
         half.scores(dev(qv), "ND", compute="split3")
     with pytest.raises(ValueError, match="compute"):
         ix.scores(dev(qv), "ND", compute="tf32")
+
+
+# ------------------------------------------------------------------------------------------------ two ranks, one GPU
+_TWO_RANK_SCRIPT = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from mdir_amd.sharded import ShardedIndex, shard_bounds, query_bounds
+from oracle import chain as OC
+from oracle import oracle as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+n, nq, d = 70001, 23, 256
+vecs, qvecs, _ = O.synth_ranking_problem(n, nq, d, seed=6)
+vecs[:, 11] = vecs[:, 5]; vecs[:, n - 2] = vecs[:, 5]            # exact ties inside a shard and across the two shards
+lo, hi = shard_bounds(n, world, rank)
+sh = ShardedIndex(torch.from_numpy(np.ascontiguousarray(vecs[:, lo:hi])).cuda(), "DN", n)
+rk, sc, (qlo, qhi) = sh.rank_queries(torch.from_numpy(qvecs).cuda(), "DN")
+assert (qlo, qhi) == query_bounds(nq, world, rank)
+want_sc = OC.scores_chain(vecs, qvecs)                            # [nq, n]: the whole problem on the host
+want_rk = OC.rank_full(want_sc)
+assert np.array_equal(sc.dense().cpu().numpy(), want_sc[qlo:qhi]), "exchanged scores"
+assert np.array_equal(rk.cpu().numpy(), want_rk[qlo:qhi]), "global ranking ids"
+ids, vals = sh.topk_queries(torch.from_numpy(qvecs).cuda(), 50, "DN")
+assert np.array_equal(ids.cpu().numpy(), want_rk[:, :50])
+dist.barrier()
+dist.destroy_process_group()
+print("TWO-RANK-OK", rank, flush=True)
+"""
+
+
+@pytest.mark.parametrize("chunks", ["1", "3"])
+def test_two_ranks_on_one_gpu_rank_ids_equal_the_oracle(chunks, tmp_path):
+    """The N > 1 data path with the REAL kernels (two rank processes sharing this GPU, collectives host-staged over gloo:
+    a functional dry run of configs[3]): every rank's rows of `ShardedIndex.rank_queries` -- shard similarity, exchange,
+    segment sort with global ids -- equal `OC.rank_full` of the whole problem to the last id, ties across shards included."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "two_rank.py"
+    script.write_text(_TWO_RANK_SCRIPT % {"root": ROOT})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", MDIR_AMD_EXCHANGE_CHUNKS=chunks)
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(script)], env=env, text=True, capture_output=True, timeout=900)
+    assert proc.returncode == 0 and proc.stdout.count("TWO-RANK-OK") == 2, (proc.stdout[-2000:], proc.stderr[-4000:])

@@ -1,12 +1,12 @@
 // Timing harness for the split-precision similarity kernel (mdx_scores_split_kernel.h): shapes of the workgroup and
 // timing-only ablations (ABL != 0: results wrong), all variants interleaved in one process on gaussian data of the real
 // magnitude (low-entropy data runs faster through DVFS and misleads).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdir_amd/csrc tools/split_ablate.hip -o tools/split_ablate_bin
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdir_amd/csrc -I tools/attic tools/split_ablate.hip -o tools/split_ablate_bin
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <vector>
-#include "mdx_scores_split_kernel.h"
+#include "scores_direct_kernel.h"       // tools/attic: the parked register-streaming form
 namespace mdx { void set_error(const char *, ...) {} }
 using namespace mdx;
 
@@ -37,6 +37,11 @@ int main(int argc, char **argv)
         }
         hipMemcpy(qp, q.data(), q.size() * 4, hipMemcpyHostToDevice);
     }
+    if (getenv("ZERO")) {           // all-zero operands: the same instruction stream at a fraction of the switching power (DVFS check)
+        hipMemset(db, 0, (size_t)RTp * KB * 1024);
+        hipMemset(qp, 0, (size_t)3 * QTT * NC * 1024);
+        printf("ZERO operands\n");
+    }
     auto go = [&](auto kern, int QT_, int R_, int NST, int CW_) {
         const size_t lds = (size_t)NST * (3 * QT_ + 2 * CW_ * R_) * 1024;
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -51,7 +56,32 @@ int main(int argc, char **argv)
         if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
         return ms / 10;
     };
+    auto direct = [&](auto kern, int lds, int R_, int CW_) {
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const int64_t blocks = (RT + CW_ * R_ - 1) / (CW_ * R_);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64), lds, 0, db, qp, out, n, KB, QTT, 0, NQ);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64), lds, 0, db, qp, out, n, KB, QTT, 0, NQ);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
+        return ms / 10;
+    };
     for (int rep = 0; rep < 3; ++rep) {
+        printf("direct  split3 CW8 R2 %.4f | CW8 R1 %.4f | CW4 R2 %.4f | CW8 R2 stream only %.4f | CW8 R2 no split %.4f || fp16 tiles (half the bytes) CW8 R2 %.4f | R4 %.4f ms\n",
+               direct(scores_direct_kernel<5, 2, 8, DirectSplit3>, direct_lds_bytes<5, 2, 8, DirectSplit3>(), 2, 8),
+               direct(scores_direct_kernel<5, 1, 8, DirectSplit3>, direct_lds_bytes<5, 1, 8, DirectSplit3>(), 1, 8),
+               direct(scores_direct_kernel<5, 2, 4, DirectSplit3>, direct_lds_bytes<5, 2, 4, DirectSplit3>(), 2, 4),
+               direct(scores_direct_kernel<5, 2, 8, DirectSplit3, 3>, direct_lds_bytes<5, 2, 8, DirectSplit3>(), 2, 8),
+               direct(scores_direct_kernel<5, 2, 8, DirectSplit3, 1>, direct_lds_bytes<5, 2, 8, DirectSplit3>(), 2, 8),
+               direct(scores_direct_kernel<5, 2, 8, DirectF16>, direct_lds_bytes<5, 2, 8, DirectF16>(), 2, 8), 0.0f);
+        printf("direct  stream only, no query staging, no barriers: split3 tiles CW8 R2 %.4f | R1 %.4f | CW4 R2 %.4f | fp16 tiles stream + barriers %.4f ms\n",
+               direct(scores_direct_kernel<5, 2, 8, DirectSplit3, 4>, direct_lds_bytes<5, 2, 8, DirectSplit3>(), 2, 8),
+               direct(scores_direct_kernel<5, 1, 8, DirectSplit3, 4>, direct_lds_bytes<5, 1, 8, DirectSplit3>(), 1, 8),
+               direct(scores_direct_kernel<5, 2, 4, DirectSplit3, 4>, direct_lds_bytes<5, 2, 4, DirectSplit3>(), 2, 4),
+               direct(scores_direct_kernel<5, 2, 8, DirectF16, 3>, direct_lds_bytes<5, 2, 8, DirectF16>(), 2, 8));
         printf("shapes  CW8 R2 NST3 %.4f | CW4 R4 NST3 %.4f | CW8 R1 NST4 %.4f | CW8 R1 NST5 %.4f | CW4 R2 NST4 %.4f | CW8 R2 NST2 %.4f | default-policy db CW8 R2 NST3 %.4f ms\n",
                go(scores_split3_kernel<5, 2, 3, 8>, 5, 2, 3, 8), go(scores_split3_kernel<5, 4, 3, 4>, 5, 4, 3, 4),
                go(scores_split3_kernel<5, 1, 4, 8>, 5, 1, 4, 8), go(scores_split3_kernel<5, 1, 5, 8>, 5, 1, 5, 8),
