@@ -261,7 +261,8 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
     ix->d_pad = round_up(d, 64);                                  // 4 fp32 or 2 fp16 k-blocks
     ix->KB = ix->d_pad / (storage == MDX_F16 ? 32 : TILE_K);
     ix->RT = ceil_div(n, TILE_ROWS);
-    ix->RT_pad = round_up(ix->RT, 16); // every wave of every workgroup has a tile to read (16 row tiles: the split-precision workgroup)
+    // every wave of every workgroup has a tile to read: 8 row tiles per workgroup, 16 for the split-precision kernel (fp32 shards)
+    ix->RT_pad = round_up(ix->RT, storage == MDX_F32 ? 16 : 8);
     ix->row_offset = row_offset;
     ix->bytes = ix->RT_pad * ix->KB * 1024;
     hipError_t e = hipMalloc((void **)&ix->tiles, (size_t)ix->bytes);
