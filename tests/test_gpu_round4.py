@@ -204,3 +204,111 @@ def test_two_ranks_on_one_gpu_rank_ids_equal_the_oracle(chunks, tmp_path):
     proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                            "--master-port", str(port), str(script)], env=env, text=True, capture_output=True, timeout=900)
     assert proc.returncode == 0 and proc.stdout.count("TWO-RANK-OK") == 2, (proc.stdout[-2000:], proc.stderr[-4000:])
+
+
+# ------------------------------------------------------------------------------------------------ the second caller
+def test_second_callers_sequence_cirtorch_examples_test_py(tmp_path, monkeypatch, capsys, golden):
+    """`cirtorch/examples/test.py:84-105,157-165,227-252`, statement by statement against the drop-in: an upstream-format
+    checkpoint (`meta` + `state_dict`, `meta['Lw'][set]['ms']`) -> `extract_vectors(net, images, imsize, transform,
+    ms=[1, 1/sqrt2, 1/2], msp=p)` for the database and (with bbxs) the queries -> dot / argsort / `compute_map_and_print`
+    -> `whitenapply(vecs, Lw['m'], Lw['P'])` on the whole [D,N] -> dot / argsort / mAP again.  Every stage against the
+    oracle (the trunk's features from torch on the CPU, everything after them from oracle/), the ranking stages also on
+    the goldens G5 / G7 through the same calls."""
+    from mdir_amd import ops
+    from mdir_amd.datasets import Compose, Normalize, ToTensor, configdataset, get_data_root
+    from mdir_amd.evaluate import compute_map_and_print
+    from mdir_amd.networks import extract_vectors, init_network
+    from mdir_amd.whiten import whitenapply
+    from test_host_api import _synthetic_dataset
+    import torch.nn.functional as F
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "3")
+    names, gnd = _synthetic_dataset(tmp_path, monkeypatch, n=14, nq=4)
+    rng = np.random.default_rng(8)
+    # --- an upstream checkpoint with a learned whitening inside (test.py:84-105, 157-165)
+    torch.manual_seed(4)
+    net0 = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False})
+    with torch.no_grad():
+        net0.pool.p.fill_(2.6)
+    D = 256
+    Lw = {"m": rng.normal(0, 0.01, (D, 1)), "P": np.linalg.qr(rng.standard_normal((D, D)))[0] * rng.uniform(0.5, 2.0, (D, 1))}
+    meta = {"architecture": "alexnet", "pooling": "gem", "whitening": False, "mean": net0.meta["mean"], "std": net0.meta["std"],
+            "outputdim": D, "local_whitening": False, "regional": False,
+            "Lw": {"retrieval-SfM-120k": {"ms": Lw, "ss": {"m": Lw["m"] * 0, "P": np.eye(D)}}}}
+    path = str(tmp_path / "upstream.pth")
+    torch.save({"meta": meta, "state_dict": net0.state_dict()}, path)
+    state = torch.load(path, weights_only=False)
+    net_params = {k: state["meta"].get(k, False) for k in ("architecture", "pooling", "local_whitening", "regional", "whitening")}
+    net_params.update(mean=state["meta"]["mean"], std=state["meta"]["std"], pretrained=False)
+    net = init_network(net_params)
+    net.load_state_dict(state["state_dict"])
+    net.meta["Lw"] = state["meta"]["Lw"]
+    ms = [1, 2 ** (-1 / 2), 1 / 2]
+    msp = net.pool.p.item()                                     # gem, not regional, no in-net whitening (test.py:139-143)
+    assert abs(msp - 2.6) < 1e-6
+    LwL = net.meta["Lw"]["retrieval-SfM-120k"]["ms"]            # `--whitening load:retrieval-SfM-120k`, len(ms) > 1
+    net.cuda().eval()
+    transform = Compose([ToTensor(), Normalize(net.meta["mean"], net.meta["std"])])
+    # --- test.py:227-237
+    cfg = configdataset("roxford5k", os.path.join(get_data_root(), "test"))
+    images = [cfg["im_fname"](cfg, i) for i in range(cfg["n"])]
+    qimages = [cfg["qim_fname"](cfg, i) for i in range(cfg["nq"])]
+    bbxs = [tuple(cfg["gnd"][i]["bbx"]) if cfg["gnd"][i]["bbx"] else None for i in range(cfg["nq"])]
+    with torch.no_grad():
+        vecs = extract_vectors(net, images, 224, transform, ms=ms, msp=msp)
+        qvecs = extract_vectors(net, qimages, 224, transform, bbxs=bbxs, ms=ms, msp=msp)
+    assert vecs.shape == (D, 14) and qvecs.shape == (D, 4) and not vecs.is_cuda and vecs.dtype == torch.float32
+    vecs, qvecs = vecs.numpy(), qvecs.numpy()
+
+    # the oracle's extraction: Pillow decode / crop / thumbnail, torch-CPU trunk, then oracle/ for everything behind it
+    cpu_net = init_network(net_params)
+    cpu_net.load_state_dict(state["state_dict"])
+    cpu_net.eval()
+
+    def oracle_vec(fn, box):
+        img = O.load_image(fn, 224, box)
+        x = ((np.asarray(img, np.float32) / 255.0 - np.array(net.meta["mean"], np.float32)) / np.array(net.meta["std"], np.float32))
+        x = torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))[None]
+        per_scale = []
+        for s in ms:
+            xs = x if s == 1 else F.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False)
+            with torch.no_grad():
+                per_scale.append(O.l2n(O.gem(cpu_net.features(xs).numpy(), msp))[0])
+        return O.ms_aggregate(np.stack(per_scale), msp)
+    want_vecs = np.stack([oracle_vec(f, None) for f in images], axis=1)
+    want_qvecs = np.stack([oracle_vec(f, b) for f, b in zip(qimages, bbxs)], axis=1)
+    np.testing.assert_allclose(vecs, want_vecs, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(qvecs, want_qvecs, rtol=0, atol=2e-5)
+
+    # --- test.py:239-242 through the C ABI: np.dot(vecs.T, qvecs), np.argsort(-scores, axis=0), compute_map_and_print
+    def search_rank_print(tag, v, q):
+        ix = ops.DescriptorIndex(dev(v), "DN")
+        sc = ix.scores(dev(q), "DN")
+        rk = ops.rank_full(sc)
+        np.testing.assert_array_equal(sc.cpu().numpy(), OC.scores_chain(v, q))                # the stated chain, bit for bit
+        np.testing.assert_allclose(sc.cpu().numpy().T, O.scores(v, q), rtol=0, atol=1e-5)      # the reference's BLAS statement
+        np.testing.assert_array_equal(rk.cpu().numpy(), OC.rank_full(OC.scores_chain(v, q)))
+        capsys.readouterr()
+        got = compute_map_and_print(tag, rk.t(), cfg["gnd"])
+        printed = capsys.readouterr().out
+        want = O.compute_map_and_print(tag, OC.rank_full(OC.scores_chain(v, q)).T, cfg["gnd"])
+        assert got[0] == want[0] and all(np.array_equal(got[1][k], want[1][k], equal_nan=True) for k in want[1])
+        assert ">> %s: mAP E:" % tag in printed
+        return got
+    first = search_rank_print("roxford5k", vecs, qvecs)
+    # --- test.py:244-252: whiten the whole matrices, search again
+    vecs_lw = whitenapply(vecs, LwL["m"], LwL["P"])
+    qvecs_lw = whitenapply(qvecs, LwL["m"], LwL["P"])
+    assert vecs_lw.shape == (D, 14) and vecs_lw.dtype == np.float64                            # float64 (m, P) in: numpy's result type
+    np.testing.assert_allclose(vecs_lw, O.whitenapply(vecs, LwL["m"], LwL["P"]), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(qvecs_lw, O.whitenapply(qvecs, LwL["m"], LwL["P"]), rtol=1e-5, atol=1e-6)
+    second = search_rank_print("roxford5k + whiten", vecs_lw.astype(np.float32), qvecs_lw.astype(np.float32))
+    assert set(first[0]) == set(second[0]) == {"map_easy", "map_medium", "map_hard"}
+    # --- the same calls on the reference's own outputs: G5 (whitenapply, fp32 and float64 P, dimensions) and G7 (dot + argsort)
+    g5 = golden("g5_whiten.npz")
+    np.testing.assert_allclose(whitenapply(g5["X"], g5["m"].astype(np.float32), g5["P"].astype(np.float32)), g5["whitenapply_f32_dimsNone"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(whitenapply(g5["X"], g5["m"], g5["P"], dimensions=48), g5["whitenapply_f64_dims48"], rtol=1e-5, atol=1e-6)
+    g7 = golden("g7_ranking.npz")
+    for tag in "abc":
+        sc = ops.DescriptorIndex(dev(g7[tag + "_vecs"]), "DN").scores(dev(g7[tag + "_qvecs"]), "DN")
+        np.testing.assert_allclose(sc.cpu().numpy().T, g7[tag + "_scores"], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(ops.rank_full(sc).cpu().numpy().T, g7[tag + "_ranks"])   # tie-free by construction
