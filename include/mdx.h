@@ -334,7 +334,8 @@ int mdx_rank_count(const float *scores, int64_t n, int64_t nq, int64_t id_offset
  * tiles on or above the diagonal are computed and each is stored twice: the result is exactly symmetric.  workspace:
  * mdx_gram_f64_workspace(d, n) bytes of device scratch -- the centred input transposed to [n, d] (both operands of the GEMM
  * are then read in 512-byte runs), then the partial results of up to 16 K ranges, which are added in range order: a fixed
- * summation order, whatever the schedule. */
+ * summation order, whatever the schedule.  That is 8 * (n_pad * d_pad + 16 * d_pad^2) bytes: ~0.87 GB at d = 2048,
+ * n = 20 000 (0.33 GB of transposed input + 0.54 GB of partials) -- size the scratch from the function, not by guess. */
 int64_t mdx_gram_f64_workspace(int64_t d, int64_t n);
 int mdx_gram_f64(const double *a, int64_t d, int64_t n, const double *center, double *out, void *workspace,
                  int64_t workspace_bytes, void *stream);

@@ -58,9 +58,14 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True):
             and conv.groups == 1 and conv.bias is None and _own_conv1x1(conv, residual)):
         from . import ops
         if ops.conv1x1_supported(conv.in_channels, conv.out_channels):
+            # the transposed copy of the weights is cached on the module, keyed by WHICH tensor the parameter is (storage
+            # pointer, shape) and by its in-place version: `load_state_dict(assign=True)`, `conv.weight = Parameter(...)`,
+            # `conv.weight.data = ...` and `.double().float()` replace the tensor without bumping `_version`
+            w = conv.weight
+            key = (w.data_ptr(), tuple(w.shape), w._version, x.device)
             wt = getattr(conv, "_mdx_wt", None)
-            if wt is None or wt[0] != conv.weight._version or wt[1].device != x.device:
-                wt = (conv.weight._version, ops.conv1x1_transpose_weights(conv.weight.detach().contiguous()))
+            if wt is None or wt[0] != key:
+                wt = (key, ops.conv1x1_transpose_weights(w.detach().contiguous()))
                 conv._mdx_wt = wt
             res = residual.contiguous() if residual is not None else None
             return ops.conv1x1_bn_act(x.contiguous(), wt[1], bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, res, relu)

@@ -36,6 +36,9 @@ def whitenapply(X, m, P, dimensions=None, device="cuda"):
 # ---------------------------------------------------------------------------
 
 def _as_f64(a, device):
+    """``device`` must be a ROCm device: the float64 products below run on libmdx's f64 matrix-core kernels and there is no
+    CPU route in this package (``ops.gram_f64`` / ``ops.project_f64`` raise on CPU tensors) -- an offline float64 step on
+    the host is the reference itself (``cirtorch/utils/whiten.py``)."""
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=torch.device(device))
 
 
