@@ -686,7 +686,7 @@ def main():
             u8 = torch.randint(0, 256, (4, 768, 1024, 3), generator=g5, device=device, dtype=torch.uint8)
             mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
             t_c, t_n = timed(lambda: ops.clahe_u8_to_chw(u8, 4, 8, mean, std)), timed(lambda: ops.u8_to_chw(u8, mean, std))
-            cb = 4 * 768 * 1024 * (3 + 1 + 3 + 1 + 1 + 12)          # rgb, L8 w/r, rgb again, L8', fp32 CHW out
+            cb = 4 * 768 * 1024 * (3 + 1 + 8 + 1 + 8 + 1 + 12)      # rgb in; L8 and chroma (a, b) written, then read; L8' and fp32 CHW out
             sec["clahe_preprocess"] = {
                 "workload": "4 x 1024x768 uint8 RGB -> CLAHE (clip 4, 8x8 tiles) on the Lab lightness -> normalised fp32 CHW "
                             "(parity unpinned: OpenCV's algorithm restated)",

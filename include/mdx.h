@@ -135,7 +135,9 @@ int mdx_u8_to_chw(const uint8_t *hwc, int64_t B, int64_t H, int64_t W, int C, co
  * is absent from the build image.  mean, std: HOST arrays of 3 floats.  workspace: device scratch of
  * mdx_clahe_workspace(B, H, W, tiles_x, tiles_y) bytes (the uint8 lightness plane [B,H,W], the per-tile look-up tables
  * [B, tiles_y, tiles_x, 256], the equalised lightness plane [B,H,W]; each region starts at a multiple of 256 bytes and is
- * readable by the caller afterwards). */
+ * readable by the caller afterwards; then the chroma (a, b) of RGB -> Lab as fp32 [B,H,W,2], so that the colour conversion's
+ * transcendental functions run once per pixel).  Two launches: one workgroup per (image, tile) -- Lab, LDS histogram, clip,
+ * spread, LUT -- then one thread per pixel. */
 int64_t mdx_clahe_workspace(int64_t B, int64_t H, int64_t W, int tiles_x, int tiles_y);
 int mdx_clahe_u8_to_chw(const uint8_t *rgb, int64_t B, int64_t H, int64_t W, int clip_limit, int tiles_x, int tiles_y,
                         const float *mean, const float *std, void *workspace, int64_t workspace_bytes, float *out, void *stream);
@@ -172,7 +174,7 @@ int mdx_resample_u8(const uint8_t *src, int64_t B, int H, int W, int C, int axis
  *                           refuses it (jdhuff.c), and a frame header that announces more picture than the file can hold
  *                           (size < width * height / 512 bytes: one bit per block) is "unsupported", so nobody sizes a
  *                           buffer from it.  These two functions run under ASan + UBSan over mutated and hand-made
- *                           hostile files in tests/test_fuzz_asan.py (`make -C mdir_amd/csrc asan`).
+ *                           hostile files in tests/test_fuzz_asan.py (`make -C mdir_amd/csrc -f Makefile.asan`).
  *   mdx_jpeg_coefficients   HOST (no device call; thread-safe, so loader threads run it in parallel).  Entropy decoding
  *                           of all scans (an error for a stream whose data runs out inside a scan: leave it to Pillow):
  *                           coef [nblocks][64] int16, quantised, natural order, component after component, every

@@ -1,7 +1,7 @@
 """Fuzz driver for the host-side JPEG parser / entropy decoder of libmdx (``mdx_jpeg_probe``, ``mdx_jpeg_coefficients``).
 
 Run by ``tests/test_fuzz_asan.py`` in a subprocess, with the AddressSanitizer + UBSan build of the library
-(``make -C mdir_amd/csrc asan`` -> ``mdir_amd/libmdx_asan.so``; host code only, never GPU ASan) and the sanitizer runtime
+(``make -C mdir_amd/csrc -f Makefile.asan`` -> ``mdir_amd/libmdx_asan.so``; host code only, never GPU ASan) and the sanitizer runtime
 preloaded: any out-of-bounds access, signed overflow or bad shift ends the process with a report and a non-zero status.
 No torch import and no device call: the two entry points are plain host code.
 

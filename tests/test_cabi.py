@@ -63,7 +63,7 @@ def test_round3_entry_points_check_their_arguments():
     mean = (ctypes.c_float * 3)(0, 0, 0)
     assert h.mdx_clahe_u8_to_chw(ctypes.c_void_p(16), 1, 8, 8, 4, 0, 8, mean, mean, ctypes.c_void_p(16), 1 << 20, ctypes.c_void_p(16), None) == -1
     assert h.mdx_clahe_u8_to_chw(ctypes.c_void_p(16), 1, 8, 8, 4, 8, 8, mean, mean, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), None) == -4
-    assert h.mdx_clahe_workspace(2, 10, 10, 8, 8) == 2 * 256 + 2 * 64 * 256
+    assert h.mdx_clahe_workspace(2, 10, 10, 8, 8) == 2 * 256 + 2 * 64 * 256 + 8 * 2 * 10 * 10      # L8, LUTs, equalised L8, chroma (a, b)
     lo, hi = ctypes.c_int64(), ctypes.c_int64()
     assert h.mdx_query_bounds(70, 8, 3, ctypes.byref(lo), ctypes.byref(hi)) == 0 and (lo.value, hi.value) == (27, 36)
     assert h.mdx_query_bounds(70, 8, 8, ctypes.byref(lo), ctypes.byref(hi)) == -1

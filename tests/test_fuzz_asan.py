@@ -1,7 +1,7 @@
 """Host-side native code under AddressSanitizer + UBSan (SURVEY section 5 "race detection / sanitizers"; VERDICT round 3,
 item 1).  The JPEG header parser and entropy decoder of libmdx walk untrusted file bytes on the DEFAULT loader route
 (``mdir_amd/datasets.py`` -> ``mdx_jpeg_probe`` / ``mdx_jpeg_coefficients``), in the evaluating process itself: a memory
-error there is a dead evaluation, not a dead worker.  ``make -C mdir_amd/csrc asan`` builds the library with the host code
+error there is a dead evaluation, not a dead worker.  ``make -C mdir_amd/csrc -f Makefile.asan`` builds the library with the host code
 instrumented (never the GPU code: GPU ASan is unavailable on this pool) and ``tests/fuzz_jpeg.py`` runs in a subprocess with
 the sanitizer runtime preloaded.  Done = zero reports over >= 60 000 mutated baseline / progressive files, the hand-made
 hostile headers and the 224-byte proof of concept of VERDICT round 3 -- and a planted overflow IS reported (the harness is live).
@@ -33,7 +33,7 @@ def asan_env():
     rt = _runtime()
     if rt is None:
         pytest.skip("hipcc ships no shared ASan runtime")
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "mdir_amd", "csrc"), "asan"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "mdir_amd", "csrc"), "-f", "Makefile.asan"], stdout=subprocess.DEVNULL)
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     return env
