@@ -705,6 +705,27 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(const uint8_t *__restrict
     o[2] = clamp8(lum + ((116130 * cb + 32768) >> 16));
 }
 
+// mdx_jpeg_pixels takes the geometry from its caller: only what mdx_jpeg_probe itself would have written is accepted (the
+// kernels index the coefficient and plane buffers by these fields)
+static bool info_consistent(const mdx_jpeg_info &in)
+{
+    if (!in.supported || (in.ncomp != 1 && in.ncomp != 3) || in.width <= 0 || in.height <= 0 || in.width > 65535 || in.height > 65535) return false;
+    const int h0 = in.hsamp[0], v0 = in.vsamp[0];
+    if (in.ncomp == 1) {
+        if (h0 != 1 || v0 != 1) return false;
+    } else {
+        if (!((h0 == 1 && v0 == 1) || (h0 == 2 && v0 == 1) || (h0 == 2 && v0 == 2))) return false;
+        if (in.hsamp[1] != 1 || in.vsamp[1] != 1 || in.hsamp[2] != 1 || in.vsamp[2] != 1) return false;
+    }
+    const int mcux = (in.width + 8 * h0 - 1) / (8 * h0), mcuy = (in.height + 8 * v0 - 1) / (8 * v0);
+    int64_t off = 0;
+    for (int c = 0; c < in.ncomp; ++c) {
+        if (in.blocks_w[c] != mcux * in.hsamp[c] || in.blocks_h[c] != mcuy * in.vsamp[c] || in.block_offset[c] != off) return false;
+        off += (int64_t)in.blocks_w[c] * in.blocks_h[c];
+    }
+    return in.nblocks == off;
+}
+
 static void geom_of(const mdx_jpeg_info &info, JpegGeom *g)
 {
     g->width = info.width;
@@ -774,6 +795,8 @@ int mdx_jpeg_pixels(const int16_t *coef, const uint16_t *quant, const mdx_jpeg_i
 {
     MDX_CHECK_ARG(coef && quant && info && planes && rgb, "mdx_jpeg_pixels: NULL pointer");
     MDX_CHECK_ARG(info->supported && info->nblocks > 0 && info->width > 0 && info->height > 0, "mdx_jpeg_pixels: unsupported image");
+    MDX_CHECK_ARG(info_consistent(*info), "mdx_jpeg_pixels: the geometry is not one mdx_jpeg_probe reports (sampling factors, block counts and "
+                                          "offsets must follow from width, height and the component count)");
     JpegGeom g;
     geom_of(*info, &g);
     hipStream_t s = (hipStream_t)stream;

@@ -84,6 +84,35 @@ def test_round4_entry_points_check_their_arguments():
     assert b"compute mode" in h.mdx_last_error()
 
 
+def test_jpeg_pixels_refuses_a_geometry_the_probe_would_not_report():
+    """mdx_jpeg_pixels indexes its buffers by the caller's mdx_jpeg_info: anything but the probe's own arithmetic is refused
+    before a kernel is launched."""
+    import ctypes
+    from mdir_amd import _lib
+    h = _lib.lib()
+    fake = ctypes.c_void_p(16)
+
+    def info(**kw):
+        i = _lib.JpegInfo()
+        i.width, i.height, i.ncomp, i.supported = 64, 48, 3, 1
+        i.hsamp[0], i.vsamp[0] = 2, 2
+        for c in (1, 2):
+            i.hsamp[c] = i.vsamp[c] = 1
+        i.blocks_w[0], i.blocks_h[0], i.blocks_w[1], i.blocks_h[1], i.blocks_w[2], i.blocks_h[2] = 8, 6, 4, 3, 4, 3
+        i.block_offset[0], i.block_offset[1], i.block_offset[2], i.nblocks = 0, 48, 60, 72
+        for k, v in kw.items():
+            if isinstance(v, tuple):
+                getattr(i, k)[v[0]] = v[1]
+            else:
+                setattr(i, k, v)
+        return i
+    for bad in (dict(nblocks=73), dict(blocks_w=(0, 9)), dict(blocks_h=(2, 4)), dict(block_offset=(1, 47)), dict(hsamp=(1, 2)), dict(vsamp=(0, 4)),
+                dict(ncomp=2), dict(width=70000), dict(height=-1), dict(width=65), dict(supported=0)):
+        i = info(**bad)
+        assert h.mdx_jpeg_pixels(fake, fake, ctypes.byref(i), fake, fake, None) == -1, bad
+    assert b"geometry" in h.mdx_last_error() or b"unsupported" in h.mdx_last_error()
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from mdir_amd import ops
