@@ -241,6 +241,17 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     // 64*R database rows leaves as one contiguous run (full cache lines instead of 64-B pieces).
     constexpr int ROWS = CW * R * TILE_ROWS;        // database rows per workgroup
     constexpr int LDW = ROWS + 4;                   // +4: the four 16-lane groups hit different banks
+#ifdef MDX_ABL_NO_EPILOGUE          // tools/scores_ablate.hip, timing only: what the epilogue costs (every accumulator stays alive in one sum)
+    {
+        f32x4 tot = accl;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < QT; ++q) tot += acc[r][q];
+        out[(int64_t)(lane % 64) * n + rt_wg * TILE_ROWS + wave] = tot[0] + tot[1] + tot[2] + tot[3];
+        return;
+    }
+#endif
     static_assert((QT * 16 + QR * 8) * LDW * 4 <= NSTAGE * STAGE_TILES * 1024, "output staging must fit in the ring");
     __builtin_amdgcn_s_barrier();
     float *stage = (float *)ring;

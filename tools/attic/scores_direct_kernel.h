@@ -73,8 +73,8 @@ constexpr int direct_lds_bytes()
 
 // db: the shard's tiles; KB = KiB tiles per row tile (the index's KB: 16-k blocks of an fp32 shard, 32-k blocks of an fp16 one);
 // qpieces: [piece][QT_total][NC] KiB tiles, NC = KB / TK chunks.  NC must be a multiple of DIRECT_PF and >= 2 * DIRECT_PF.
-template <int QT, int R, int CW, typename MM, int ABL = 0>
-__global__ __launch_bounds__(CW * 64, 1) void scores_direct_kernel(const f32x4 *__restrict__ db, const u32x4 *__restrict__ qpieces,
+template <int QT, int R, int CW, typename MM, int ABL = 0, int WGS = 1>
+__global__ __launch_bounds__(CW * 64, WGS) void scores_direct_kernel(const f32x4 *__restrict__ db, const u32x4 *__restrict__ qpieces,
                                                                    float *__restrict__ out, int64_t n, int KB, int QT_total,
                                                                    int qt_first, int nq_valid)
 {
@@ -131,14 +131,14 @@ __global__ __launch_bounds__(CW * 64, 1) void scores_direct_kernel(const f32x4 *
     };
     // The prologue issues in the loop's order (pinned): the compiler derives its counted waits from the issue order it
     // sees on BOTH ways into the loop, and a prologue it has reshuffled makes every wait in the loop over-wait by chunks
-    if constexpr (ABL != 4) load_queries(0);    // first, so that the wait for them leaves the shard loads below in flight
+    if constexpr (ABL != 4 && ABL != 5) load_queries(0);    // first, so that the wait for them leaves the shard loads below in flight
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
         fetch(j, j);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (ABL != 4) store_queries(0);
+    if constexpr (ABL != 4 && ABL != 5) store_queries(0);
     __builtin_amdgcn_sched_barrier(0);
     // Software pipeline inside the wave: while the MFMAs of chunk c run, the operands of chunk c+1 are prepared (the fp32
     // shard: 88 vector instructions of splitting per chunk, which otherwise sit in front of 60 MFMAs that wait for them --
@@ -154,12 +154,12 @@ __global__ __launch_bounds__(CW * 64, 1) void scores_direct_kernel(const f32x4 *
         constexpr int TAIL = decltype(tail)::value;
         // B_it: every wave has written its part of stage `it` (and waited for the writes), and every wave has left stage
         // it-1, whose slot this iteration's writes go to
-        if constexpr (ABL != 4) {
+        if constexpr (ABL != 4 && ABL != 5) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TAIL < 2 && ABL != 4) load_queries(it + 1);
+        if constexpr (TAIL < 2 && ABL != 4 && ABL != 5) load_queries(it + 1);
         __builtin_amdgcn_sched_barrier(0);      // the scheduler otherwise sinks every load of the iteration to its end
         const u32x4 *qs = (const u32x4 *)(ring + (it & 1) * (STAGE_TILES * 64)) + lane;
 #pragma unroll
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(CW * 64, 1) void scores_direct_kernel(const f32x4 *
                         dnext[r].m = __builtin_bit_cast(u32x4, raw[jn][r][TK - 1]);
                         dnext[r].l = dnext[r].h ^ dnext[r].m;
                     }
-                } else if constexpr (ABL == 3 || ABL == 4) {                // timing only: the stream and the barriers (4: not even those)
+                } else if constexpr (ABL == 3 || ABL == 4 || ABL == 5) {                // timing only: the stream and the barriers (4: not even those)
 #pragma unroll
                     for (int r = 0; r < R; ++r) acc[r][0] += raw[jn][r][0] + raw[jn][r][TK - 1];
                 } else {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(CW * 64, 1) void scores_direct_kernel(const f32x4 *
                     for (int r = 0; r < R; ++r) MM::prepare(raw[jn][r], dnext[r]);  // waits (counted vmcnt) for chunk c+1's loads only
                 }
             }
-            if constexpr (ABL != 3 && ABL != 4) {
+            if constexpr (ABL != 3 && ABL != 4 && ABL != 5) {
 #pragma unroll
                 for (int q = 0; q < QT; ++q) {
                     u32x4 qp[NQP];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(CW * 64, 1) void scores_direct_kernel(const f32x4 *
                 for (int r = 0; r < R; ++r) dcur[r] = dnext[r];
             }
         }
-        if constexpr (TAIL < 2 && ABL != 4) store_queries(it + 1);
+        if constexpr (TAIL < 2 && ABL != 4 && ABL != 5) store_queries(it + 1);
     };
     for (int it = 0; it + 2 < NIT; ++it) body(it, std::integral_constant<int, 0>{});
     body(NIT - 2, std::integral_constant<int, 1>{});
@@ -214,6 +214,10 @@ __global__ __launch_bounds__(CW * 64, 1) void scores_direct_kernel(const f32x4 *
     // rows leaves as one contiguous run
     constexpr int ROWS = CW * R * TILE_ROWS;
     constexpr int LDW = ROWS + 4;
+    if constexpr (ABL == 5) {                   // timing only: no epilogue either (one store per lane keeps the sums alive)
+        out[(int64_t)(tid % 70) * n + rt_wg * TILE_ROWS + tid / 70] = acc[0][0][0] + acc[R - 1][0][1];
+        return;
+    }
     __builtin_amdgcn_s_barrier();
     float *stage = (float *)ring;
     {

@@ -69,6 +69,52 @@ int main(int argc, char **argv)
         if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
         return ms / 10;
     };
+    // ---- the fp16 shard (configs[4]): half the bytes, one MFMA per tile pair.  KB = 64 tiles of 32 k per row tile.
+    auto direct16 = [&](auto kern, int lds, int R_, int CW_) {
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const int64_t blocks = (RT + CW_ * R_ - 1) / (CW_ * R_);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64), lds, 0, db, qp, out, n, KB / 2, QTT, 0, NQ);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64), lds, 0, db, qp, out, n, KB / 2, QTT, 0, NQ);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
+        return ms / 10;
+    };
+    auto ring16 = [&](auto kern, int R_, int KC_, int NST) {
+        const size_t lds = (size_t)NST * (5 + 4 * R_) * KC_ * 1024;
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int64_t blocks = (RT + 4 * R_ - 1) / (4 * R_);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, (const f32x4 *)qp, out, n, KB / 2, NQ, (unsigned long long *)nullptr);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, 0, db, (const f32x4 *)qp, out, n, KB / 2, NQ, (unsigned long long *)nullptr);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        return ms / 10;
+    };
+    if (getenv("F16")) {
+        for (int rep = 0; rep < 3; ++rep) {
+            printf("fp16 shard (4.4 GB)  ring (shipped) %.4f | direct CW8 R2 x1 %.4f | CW4 R2 x2 %.4f | CW4 R2 x3 %.4f | CW4 R4 x2 %.4f | CW8 R4 x1 %.4f ms\n",
+                   ring16(scores_lc_kernel<5, 2, 2, 3, 2, false, MmaF16>, 2, 2, 3),
+                   direct16(scores_direct_kernel<5, 2, 8, DirectF16>, direct_lds_bytes<5, 2, 8, DirectF16>(), 2, 8),
+                   direct16(scores_direct_kernel<5, 2, 4, DirectF16, 0, 2>, direct_lds_bytes<5, 2, 4, DirectF16>(), 2, 4),
+                   direct16(scores_direct_kernel<5, 2, 4, DirectF16, 0, 3>, direct_lds_bytes<5, 2, 4, DirectF16>(), 2, 4),
+                   direct16(scores_direct_kernel<5, 4, 4, DirectF16, 0, 2>, direct_lds_bytes<5, 4, 4, DirectF16>(), 4, 4),
+                   direct16(scores_direct_kernel<5, 4, 8, DirectF16>, direct_lds_bytes<5, 4, 8, DirectF16>(), 4, 8));
+            printf("fp16 stream only     with barriers CW8 R2 %.4f | no barriers %.4f | no barriers, no epilogue %.4f | CW4 R2 x3: barriers %.4f | none %.4f | none, no epilogue %.4f ms\n",
+                   direct16(scores_direct_kernel<5, 2, 8, DirectF16, 3>, direct_lds_bytes<5, 2, 8, DirectF16>(), 2, 8),
+                   direct16(scores_direct_kernel<5, 2, 8, DirectF16, 4>, direct_lds_bytes<5, 2, 8, DirectF16>(), 2, 8),
+                   direct16(scores_direct_kernel<5, 2, 8, DirectF16, 5>, direct_lds_bytes<5, 2, 8, DirectF16>(), 2, 8),
+                   direct16(scores_direct_kernel<5, 2, 4, DirectF16, 3, 3>, direct_lds_bytes<5, 2, 4, DirectF16>(), 2, 4),
+                   direct16(scores_direct_kernel<5, 2, 4, DirectF16, 4, 3>, direct_lds_bytes<5, 2, 4, DirectF16>(), 2, 4),
+                   direct16(scores_direct_kernel<5, 2, 4, DirectF16, 5, 3>, direct_lds_bytes<5, 2, 4, DirectF16>(), 2, 4));
+            fflush(stdout);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 3; ++rep) {
         printf("direct  split3 CW8 R2 %.4f | CW8 R1 %.4f | CW4 R2 %.4f | CW8 R2 stream only %.4f | CW8 R2 no split %.4f || fp16 tiles (half the bytes) CW8 R2 %.4f | R4 %.4f ms\n",
                direct(scores_direct_kernel<5, 2, 8, DirectSplit3>, direct_lds_bytes<5, 2, 8, DirectSplit3>(), 2, 8),

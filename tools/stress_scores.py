@@ -1,4 +1,4 @@
-"""Race screen for the loader/consumer similarity kernel: many random shapes, repeated launches,
+"""Race screen for the loader/consumer similarity kernels (exact chain, fp16 shard, and -- round 4 -- MDX_F32_SPLIT3 within 2e-6): many random shapes, repeated launches,
 every score compared bit for bit with the fmaf-chain oracle (a ring-protocol bug shows up as rare
 wrong tiles that come and go with shape and load)."""
 import os, sys, time
@@ -32,6 +32,11 @@ for it in range(iters):
             junk2 = junk @ junk if rep % 2 else None
         got = ix.scores(qd, "ND").cpu().numpy()
         ok = np.array_equal(got, want) if storage == "f32" else np.allclose(got, want, rtol=0, atol=2e-6)
+        if storage == "f32" and rep % 2 == 0:       # the labelled split-precision mode on the same index, between exact launches
+            got3 = ix.scores(qd, "ND", compute="split3").cpu().numpy()
+            if not (np.abs(got3 - want).max() <= 2e-6):
+                bad += 1
+                print("SPLIT3 MISMATCH it=%d rep=%d n=%d d=%d nq=%d: max diff %.3g" % (it, rep, n, d, nq, np.abs(got3 - want).max()))
         if not ok:
             bad += 1
             w = np.argwhere(got != want) if storage == "f32" else np.argwhere(np.abs(got - want) > 2e-6)
