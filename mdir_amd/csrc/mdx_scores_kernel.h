@@ -24,6 +24,30 @@ __host__ __device__ __forceinline__ int64_t shard_tile(int64_t rt, int64_t kb, i
 __host__ __device__ __forceinline__ int64_t shard_tile(int64_t rt, int64_t kb, int64_t KB) { return rt * KB + kb; }
 #endif
 
+// Workgroup -> row block.  Consecutive workgroup ids go to different XCDs (id mod 8), each with its own L2; a workgroup's
+// output is one run of 512-1 024 B per query row, 4 MB apart.  With block = id the runs that one L2 collects at about the
+// same time are 8 blocks apart; giving each XCD a CONTIGUOUS range of row blocks makes them neighbours, so that they leave the
+// L2 as longer runs (the same trick as the sort's tile order).  -DMDX_XCD_BLOCKS=0: the plain order (A/B in tools/).
+#ifndef MDX_XCD_BLOCKS
+#define MDX_XCD_BLOCKS 1
+#endif
+#ifdef MDX_XCD_BLOCKS_RUNTIME        // tools/split_ablate.hip: both orders in one process
+__device__ int mdx_xcd_blocks_flag = 1;
+#endif
+__device__ __forceinline__ int64_t row_block_of(unsigned id, unsigned nblocks)
+{
+#ifdef MDX_XCD_BLOCKS_RUNTIME
+    if (!mdx_xcd_blocks_flag) return id;
+#endif
+#if MDX_XCD_BLOCKS
+    const unsigned per = nblocks / 8, rem = nblocks % 8;          // XCD x takes `per` blocks, the first `rem` XCDs one more
+    const unsigned x = id % 8, k = id / 8;
+    return (int64_t)x * per + (x < rem ? x : rem) + k;
+#else
+    return id;
+#endif
+}
+
 // Element type of a shard.  A tile is always 64 lanes x 16 B; what the 16 bytes are and which
 // MFMA consumes them is the only difference between the fp32 (exact chain) and the fp16
 // (BASELINE.json configs[4]: "fp16 descriptors on CDNA4 fp16 MFMA") paths.
@@ -97,7 +121,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     unsigned long long t_entry = 0;
     if (STAMPS) t_entry = __builtin_amdgcn_s_memrealtime();
     const int nchunks = KB / KC;
-    const int64_t rt_wg = (int64_t)blockIdx.x * CW * R;            // first row tile of the workgroup
+    const int64_t rt_wg = row_block_of(blockIdx.x, gridDim.x) * CW * R;       // first row tile of the workgroup
     // blockIdx.y = query pass: several full groups of QT query tiles in one launch (many queries
     // against a small database: one pass alone would not fill the chip)
     qtiles += (int64_t)blockIdx.y * QT * KB * 64;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(CW * 64 + 256, 1) void scores_split3_kernel(const f
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NC = KB / 2;                                          // chunks of 32 k (KB is a multiple of 4)
-    const int64_t rt_wg = (int64_t)blockIdx.x * CW * R;            // first row tile of the workgroup
+    const int64_t rt_wg = row_block_of(blockIdx.x, gridDim.x) * CW * R;            // first row tile of the workgroup
     const int qt0 = qt_first + (int)blockIdx.y * QT;                // first query tile of this workgroup (grid.y = pass over groups of QT tiles)
     out += (int64_t)qt0 * TILE_ROWS * n;
 

@@ -312,3 +312,40 @@ def test_second_callers_sequence_cirtorch_examples_test_py(tmp_path, monkeypatch
         sc = ops.DescriptorIndex(dev(g7[tag + "_vecs"]), "DN").scores(dev(g7[tag + "_qvecs"]), "DN")
         np.testing.assert_allclose(sc.cpu().numpy().T, g7[tag + "_scores"], rtol=0, atol=1e-5)
         np.testing.assert_array_equal(ops.rank_full(sc).cpu().numpy().T, g7[tag + "_ranks"])   # tie-free by construction
+
+
+# ------------------------------------------------------------------------------------------------ fp16 shard: streaming kernel
+_F16_HASH_SCRIPT = r"""
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from mdir_amd import ops
+h = hashlib.sha256()
+for n, d, nq in ((70000, 2048, 70), (4993, 2048, 70), (33000, 512, 315), (1125, 512, 1125), (65600, 256, 1), (40000, 128, 129), (333, 100, 17), (5000, 64, 24)):
+    rng = np.random.default_rng(n + d + nq)
+    db = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    q = (rng.standard_normal((nq, d)) / np.sqrt(d)).astype(np.float32)
+    ix = ops.DescriptorIndex(torch.from_numpy(db).cuda(), "ND", storage="f16")
+    got = ix.scores(torch.from_numpy(q).cuda(), "ND").cpu().numpy()
+    want = q.astype(np.float16).astype(np.float64) @ db.astype(np.float16).astype(np.float64).T
+    assert np.abs(got - want).max() < 2e-6, (n, d, nq, np.abs(got - want).max())
+    h.update(got.tobytes())
+print("F16-HASH", h.hexdigest())
+"""
+
+
+def test_f16_stream_kernel_is_bit_identical_to_the_ring_kernel():
+    """The register-streaming kernel that fp16 shards take since round 4 (mdx_scores_stream_kernel.h) against the ring kernel
+    it replaces (MDX_F16_RING=1): the same bits on eight shapes -- full groups of query tiles in one launch, a query tail,
+    64-row and 128-row workgroups, d = 100 and 64 (not a whole number of four-chunk stages: those stay on the ring kernel) --
+    and both within fp32 accumulation of the float64 product of the fp16-rounded operands."""
+    import subprocess
+    out = {}
+    for ring in ("", "1"):
+        env = dict(os.environ)
+        env.pop("MDX_F16_RING", None)
+        if ring:
+            env["MDX_F16_RING"] = "1"
+        proc = subprocess.run([sys.executable, "-c", _F16_HASH_SCRIPT % {"root": ROOT}], env=env, text=True, capture_output=True, timeout=900)
+        assert proc.returncode == 0 and "F16-HASH" in proc.stdout, proc.stderr[-3000:]
+        out[ring] = proc.stdout.split("F16-HASH")[1].strip()
+    assert out[""] == out["1"]

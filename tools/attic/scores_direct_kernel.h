@@ -87,7 +87,7 @@ __global__ __launch_bounds__(CW * 64, WGS) void scores_direct_kernel(const f32x4
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NC = KB / TK, NIT = NC / PF;
-    const int64_t rt_wg = (int64_t)blockIdx.x * CW * R;
+    const int64_t rt_wg = row_block_of(blockIdx.x, gridDim.x) * CW * R;
     const int qt0 = qt_first + (int)blockIdx.y * QT;
     out += (int64_t)qt0 * TILE_ROWS * n;
 

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <vector>
 #include "scores_direct_kernel.h"       // tools/attic: the parked register-streaming form
+#include "mdx_scores_stream_kernel.h"
+#include "scores_stream_persistent_kernel.h"   // tools/attic
 namespace mdx { void set_error(const char *, ...) {} }
 using namespace mdx;
 
@@ -95,7 +97,64 @@ int main(int argc, char **argv)
         float ms; hipEventElapsedTime(&ms, a, b);
         return ms / 10;
     };
+    auto stream16 = [&](auto kern, int lds, int R_, int CW_, int wgs, bool check = false) {
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const int nblocks = (int)((RT + CW_ * R_ - 1) / (CW_ * R_));
+        const int grid = nblocks < 256 * wgs ? nblocks : 256 * wgs;
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(CW_ * 64), lds, 0, db, qp, out, n, KB / 2, QTT, 0, NQ, nblocks);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(CW_ * 64), lds, 0, db, qp, out, n, KB / 2, QTT, 0, NQ, nblocks);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
+        return ms / 10;
+    };
+    auto shipped16 = [&](auto kern, int lds, int R_) {
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const int64_t blocks = (RT + 4 * R_ - 1) / (4 * R_);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, db, (const f32x4 *)qp, out, n, KB / 2, NQ);
+        hipEventRecord(a);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, db, (const f32x4 *)qp, out, n, KB / 2, NQ);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
+        return ms / 10;
+    };
+    if (getenv("XCD")) {            // row-block order: plain (block = workgroup id) against XCD-contiguous, alternating in one process
+        for (int rep = 0; rep < 6; ++rep) {
+            const int flag = rep & 1;
+            hipMemcpyToSymbol(HIP_SYMBOL(mdx_xcd_blocks_flag), &flag, sizeof flag);
+            printf("%s  fp16: ring %.4f | SHIPPED stream x3 %.4f | x2 %.4f | x4 %.4f | direct CW4 R2 x3 %.4f | persistent CW4 R2 x3 %.4f | CW4 R4 x2 %.4f || split3 ring %.4f ms\n",
+                   flag ? "XCD-contiguous blocks" : "block = workgroup id ",
+                   ring16(scores_lc_kernel<5, 2, 2, 3, 2, false, MmaF16>, 2, 2, 3),
+                   shipped16(scores_f16_stream_kernel<5, 2, 3>, stream_lds_bytes<5, 2>(), 2),
+                   shipped16(scores_f16_stream_kernel<5, 2, 2>, stream_lds_bytes<5, 2>(), 2),
+                   shipped16(scores_f16_stream_kernel<5, 2, 4>, stream_lds_bytes<5, 2>(), 2),
+                   direct16(scores_direct_kernel<5, 2, 4, DirectF16, 0, 3>, direct_lds_bytes<5, 2, 4, DirectF16>(), 2, 4),
+                   stream16(scores_stream_persistent_kernel<5, 2, 4, StreamF16, 3>, stream_persistent_lds_bytes<5, 2, 4, StreamF16>(), 2, 4, 3),
+                   stream16(scores_stream_persistent_kernel<5, 4, 4, StreamF16, 2>, stream_persistent_lds_bytes<5, 4, 4, StreamF16>(), 4, 4, 2),
+                   go(scores_split3_kernel<5, 2, 3, 8>, 5, 2, 3, 8));
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (getenv("F16")) {
+        {   // bitwise: the persistent form against the ring kernel
+            std::vector<float> ha((size_t)70 * n), hb((size_t)70 * n);
+            hipMemset(out, 0xFF, (size_t)70 * n * 4);
+            ring16(scores_lc_kernel<5, 2, 2, 3, 2, false, MmaF16>, 2, 2, 3);
+            hipMemcpy(ha.data(), out, ha.size() * 4, hipMemcpyDeviceToHost);
+            hipMemset(out, 0xFF, (size_t)70 * n * 4);
+            stream16(scores_stream_persistent_kernel<5, 2, 4, StreamF16, 3>, stream_persistent_lds_bytes<5, 2, 4, StreamF16>(), 2, 4, 3);
+            hipMemcpy(hb.data(), out, hb.size() * 4, hipMemcpyDeviceToHost);
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < ha.size(); ++i) if (memcmp(&ha[i], &hb[i], 4)) { if (!bad) first = i; ++bad; }
+            printf("persistent stream kernel vs ring kernel: %zu of %zu scores differ (first at q=%zu row=%zu)\n", bad, ha.size(), first / n, first % n);
+        }
         for (int rep = 0; rep < 3; ++rep) {
             printf("fp16 shard (4.4 GB)  ring (shipped) %.4f | direct CW8 R2 x1 %.4f | CW4 R2 x2 %.4f | CW4 R2 x3 %.4f | CW4 R4 x2 %.4f | CW8 R4 x1 %.4f ms\n",
                    ring16(scores_lc_kernel<5, 2, 2, 3, 2, false, MmaF16>, 2, 2, 3),
@@ -104,6 +163,13 @@ int main(int argc, char **argv)
                    direct16(scores_direct_kernel<5, 2, 4, DirectF16, 0, 3>, direct_lds_bytes<5, 2, 4, DirectF16>(), 2, 4),
                    direct16(scores_direct_kernel<5, 4, 4, DirectF16, 0, 2>, direct_lds_bytes<5, 4, 4, DirectF16>(), 4, 4),
                    direct16(scores_direct_kernel<5, 4, 8, DirectF16>, direct_lds_bytes<5, 4, 8, DirectF16>(), 4, 8));
+            printf("fp16 PERSISTENT      CW4 R2 x3 %.4f | CW4 R2 x2 %.4f | CW4 R2 x4 %.4f | CW8 R2 x1 %.4f | CW8 R1 x2 %.4f | CW4 R4 x2 %.4f ms\n",
+                   stream16(scores_stream_persistent_kernel<5, 2, 4, StreamF16, 3>, stream_persistent_lds_bytes<5, 2, 4, StreamF16>(), 2, 4, 3),
+                   stream16(scores_stream_persistent_kernel<5, 2, 4, StreamF16, 2>, stream_persistent_lds_bytes<5, 2, 4, StreamF16>(), 2, 4, 2),
+                   stream16(scores_stream_persistent_kernel<5, 2, 4, StreamF16, 4>, stream_persistent_lds_bytes<5, 2, 4, StreamF16>(), 2, 4, 4),
+                   stream16(scores_stream_persistent_kernel<5, 2, 8, StreamF16, 1>, stream_persistent_lds_bytes<5, 2, 8, StreamF16>(), 2, 8, 1),
+                   stream16(scores_stream_persistent_kernel<5, 1, 8, StreamF16, 2>, stream_persistent_lds_bytes<5, 1, 8, StreamF16>(), 1, 8, 2),
+                   stream16(scores_stream_persistent_kernel<5, 4, 4, StreamF16, 2>, stream_persistent_lds_bytes<5, 4, 4, StreamF16>(), 4, 4, 2));
             printf("fp16 stream only     with barriers CW8 R2 %.4f | no barriers %.4f | no barriers, no epilogue %.4f | CW4 R2 x3: barriers %.4f | none %.4f | none, no epilogue %.4f ms\n",
                    direct16(scores_direct_kernel<5, 2, 8, DirectF16, 3>, direct_lds_bytes<5, 2, 8, DirectF16>(), 2, 8),
                    direct16(scores_direct_kernel<5, 2, 8, DirectF16, 4>, direct_lds_bytes<5, 2, 8, DirectF16>(), 2, 8),
