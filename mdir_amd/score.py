@@ -13,7 +13,9 @@ The default ``ranking="positions"`` feeds compute_map from ``mdx_rank_of`` (iden
 asserted in the tests and in bench.py -- without an N-long sort; the score object exposes
 nothing but the APs); ``ranking="full"`` runs the reference's dot + argsort + compute_map
 sequence literally.  ``storage="f16"`` (criterion key, not in the reference) keeps the database shard in
-fp16 for the fp16 MFMA -- BASELINE.json configs[4].
+fp16 for the fp16 MFMA -- BASELINE.json configs[4].  ``similarity="split3"`` (criterion key, not in the reference) takes
+the LABELLED split-precision form of the dot product on the same fp32 shard (three bf16 pieces per operand on the bf16
+MFMA: 0.75 of the exact kernel's time, scores within 2e-6 of it; default ``"exact"`` = the k-ordered fp32 chain).
 """
 import os.path
 
@@ -51,6 +53,11 @@ class CirDatasetAp:
         # scores within ~1e-3 relative: a looser, separately tested contract)
         self.storage = params.pop("storage", "f32")
         assert self.storage in {"f32", "f16"}, self.storage
+        # how an fp32 shard is multiplied: "exact" (default: the k-ordered fp32 fma chain, the parity contract) or "split3"
+        # (labelled second mode, include/mdx.h MDX_F32_SPLIT3)
+        self.similarity = params.pop("similarity", "exact")
+        assert self.similarity in {"exact", "split3"}, self.similarity
+        assert not (self.similarity == "split3" and self.storage != "f32"), "similarity: split3 multiplies an fp32 shard"
         if isinstance(self.dataset, dict):
             assert self.dataset.keys() == {"name", "queries", "db", "imgdir"}
             imgdir = self.dataset["imgdir"]
@@ -80,7 +87,8 @@ class CirDatasetAp:
             print(">> {}: database + query images, rank {} of {}...".format(self.dataset, *_rank_world()))
             averages, scores_per_query = sharded_retrieval_map(
                 network, self.images, self.qimages, self.bbxs, self.gnd, self.dataset, self.image_size,
-                self.transforms, device, lap=stopwatch.lap, storage=self.storage)
+                self.transforms, device, lap=stopwatch.lap, storage=self.storage,
+                compute="split3" if self.similarity == "split3" else "chain")
             self._log(logger, stopwatch, averages, scores_per_query)
             return
         print(">> {}: database images...".format(self.dataset))
@@ -98,7 +106,8 @@ class CirDatasetAp:
         with range_("%s/compute_score" % self.dataset):
             index = ops.DescriptorIndex(vecs, "ND", storage=self.storage)
             with range_("similarity"):
-                scores = index.scores(qvecs, "ND")                  # [Q,N] = (vecs.T @ qvecs).T
+                kw = {"compute": "split3"} if self.similarity == "split3" else {}
+                scores = index.scores(qvecs, "ND", **kw)            # [Q,N] = (vecs.T @ qvecs).T
             if self.ranking == "full":
                 with range_("ranking"):
                     ranks = ops.rank_full(scores)                   # [Q,N] = argsort(-scores, axis=0).T

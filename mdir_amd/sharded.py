@@ -127,10 +127,17 @@ def chunk_bounds(lo, hi, chunks):
 
 
 class ShardedIndex:
-    def __init__(self, local_vecs, layout, n_total, group=None, backend=None, storage="f32"):
-        """``storage``: "f32" (exact chain) or "f16" (fp16 shard on the fp16 MFMA, BASELINE.json configs[4])."""
+    def __init__(self, local_vecs, layout, n_total, group=None, backend=None, storage="f32", compute="chain"):
+        """``storage``: "f32" (exact chain) or "f16" (fp16 shard on the fp16 MFMA, BASELINE.json configs[4]).
+        ``compute``: "chain" (default) or "split3" -- the labelled split-precision similarity on an fp32 shard
+        (``DescriptorIndex.scores(compute=...)``, ``include/mdx.h`` ``MDX_F32_SPLIT3``)."""
         self.group = group
         self.storage = storage
+        if compute not in ("chain", "exact", "split3"):
+            raise ValueError("compute %r" % (compute,))
+        if compute == "split3" and storage != "f32":
+            raise ValueError("compute='split3' multiplies an fp32 shard")
+        self._score_kw = {"compute": "split3"} if compute == "split3" else {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_total = int(n_total)
@@ -210,8 +217,8 @@ class ShardedIndex:
     def local_scores(self, queries, qlayout="DN"):
         """``[Q, n_local]`` similarities against this rank's rows (no communication)."""
         if self.chunks == 1:
-            return self.index.scores(queries, qlayout)
-        return torch.cat([ix.scores(queries, qlayout) for _, _, ix in self.parts], dim=1)
+            return self.index.scores(queries, qlayout, **self._score_kw)
+        return torch.cat([ix.scores(queries, qlayout, **self._score_kw) for _, _, ix in self.parts], dim=1)
 
     # ----------------------------------------------------------- full ranking
     def _peer_widths(self, c):
@@ -321,7 +328,7 @@ class ShardedIndex:
         if ev:
             ev[0].record()
         for c, (_, _, ix) in enumerate(self.parts):
-            s_part = ix.scores(queries, qlayout)
+            s_part = ix.scores(queries, qlayout, **self._score_kw)
             nq = s_part.shape[0]
             widths = self._peer_widths(c)
             pending.append((self._start_exchange(s_part, widths, c), widths))
@@ -505,7 +512,7 @@ def _all_gather_uneven(pieces, mine, group):
 
 
 def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, transform, device,
-                          group=None, backend=None, lap=None, storage="f32", **kwargs):
+                          group=None, backend=None, lap=None, storage="f32", compute="chain", **kwargs):
     """Distributed form of ``CirDatasetAp.__call__`` (cirscore.py:49-71): every rank extracts its
     slice of the database (which stays resident as its shard) and its slice of the queries, query
     descriptors are all-gathered, similarities are computed against the local shard, and mAP comes
@@ -530,7 +537,7 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
     qvecs = gather_query_vectors(qlocal, len(qimages), group)
     if lap:
         lap("extract_descriptors")
-    index = ShardedIndex(vecs, "ND", len(images), group=group, backend=backend, storage=storage)
+    index = ShardedIndex(vecs, "ND", len(images), group=group, backend=backend, storage=storage, compute=compute)
     s_local = index.local_scores(qvecs.contiguous(), "ND")
 
     def one_map(g, kappas):

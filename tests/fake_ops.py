@@ -79,7 +79,7 @@ class DescriptorIndex:
         self.row_offset = row_offset
         self.device = vecs.device
 
-    def scores(self, queries, qlayout="DN", center=None, out=None):
+    def scores(self, queries, qlayout="DN", center=None, out=None, compute="chain"):
         q = queries.detach().numpy()
         q = np.ascontiguousarray(q.T if qlayout in ("DN", "dim_major") else q)
         if center is not None:

@@ -349,3 +349,65 @@ def test_f16_stream_kernel_is_bit_identical_to_the_ring_kernel():
         assert proc.returncode == 0 and "F16-HASH" in proc.stdout, proc.stderr[-3000:]
         out[ring] = proc.stdout.split("F16-HASH")[1].strip()
     assert out[""] == out["1"]
+
+
+def test_split3_from_the_scenario_surface_and_under_graph_capture(tmp_path):
+    """`criterion: {similarity: split3}` (scenarios/eval_split3.yml) through ./eval.py on the generated set-up: the printed
+    numbers equal the exact run's (the split scores are within 2e-6; none of the few dozen images is that close to another) --
+    in one process and as two rank processes on this GPU (ShardedIndex(compute="split3")).  And mdx_scores_ex + mdx_rank_full
+    recorded into a hipGraph replay to the eager result (the split mode makes no synchronising call)."""
+    import subprocess
+    from mdir_amd import ops
+    root = str(tmp_path / "synth")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_eval.py"), root])
+    env = dict(os.environ, CIRTORCH_ROOT=root, MDIR_AMD_WORKERS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    over = str(tmp_path / "split3.yml")
+    with open(over, "w") as f:
+        f.write("validation:\n  roxford5k: {criterion: {similarity: split3}}\n")
+
+    def printed(cmd):
+        proc = subprocess.run(cmd, env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert proc.returncode == 0, proc.stdout[-3000:]
+        got = {}
+        for line in proc.stdout.splitlines():
+            for label in ("roxford.5k medium", "247tokyo.1k"):
+                if line.strip().startswith(label):
+                    got[label] = float(line.split()[-1])
+        assert set(got) == {"roxford.5k medium", "247tokyo.1k"}, proc.stdout[-2000:]
+        return got
+    ev = [sys.executable, os.path.join(ROOT, "eval.py"), "eval.yml", os.path.join(root, "eval_synth.yml")]
+    exact = printed(ev)
+    assert printed(ev + [over]) == exact
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env["MDIR_AMD_DRYRUN_ONE_GPU"] = "1"
+    two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "eval.py"), "eval.yml", os.path.join(root, "eval_synth.yml"), over]
+    assert printed(two) == exact
+
+    # graph capture
+    rng = np.random.default_rng(12)
+    db, qv = _unit_rows(rng, 40000, 256), _unit_rows(rng, 37, 256)
+    ix = ops.DescriptorIndex(dev(db), "ND")
+    q = dev(qv)
+    sc = torch.empty((37, 40000), dtype=torch.float32, device=DEV)
+    rk = torch.empty((37, 40000), dtype=torch.int64, device=DEV)
+    ws = torch.empty(ops.rank_workspace_bytes(40000, 37), dtype=torch.uint8, device=DEV)
+    ix.scores(q, "ND", out=sc, compute="split3")                 # eager once: workspace allocated, LDS opt-in done
+    ops.rank_full(sc, out=rk, workspace=ws)
+    want_sc, want_rk = sc.clone(), rk.clone()
+    sc.zero_(), rk.zero_()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            ix.scores(q, "ND", out=sc, compute="split3")
+            ops.rank_full(sc, out=rk, workspace=ws)
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(sc, want_sc) and torch.equal(rk, want_rk)
+    assert float((sc - ix.scores(q, "ND")).abs().max()) <= 2e-6
