@@ -94,9 +94,8 @@ class ImagesFromList(data.Dataset):
                 if seen.format != "JPEG" or seen.mode not in ("RGB", "L"):
                     return None
                 seen_size = seen.size
-            if seen_size[0] * seen_size[1] > (Image.MAX_IMAGE_PIXELS or 89478485):
-                return None                                 # Pillow warns about such a picture: let it (the host route decodes it)
-            item = jpeg.entropy_decode(data, self.bbxs[index] if self.bbxs else None)
+            # beyond Pillow's MAX_IMAGE_PIXELS it warns about the picture: let it (entropy_decode declines, the host route decodes)
+            item = jpeg.entropy_decode(data, self.bbxs[index] if self.bbxs else None, max_pixels=Image.MAX_IMAGE_PIXELS or jpeg.MAX_PIXELS)
             if item is None or item.size != seen_size:
                 return None
         except Exception:

@@ -32,14 +32,21 @@ class JpegCoefficients:
         return self
 
 
-def entropy_decode(data, box=None):
+MAX_PIXELS = 89_478_485         # Pillow's Image.MAX_IMAGE_PIXELS: beyond it Pillow warns (and refuses at twice that)
+
+
+def entropy_decode(data, box=None, max_pixels=MAX_PIXELS):
     """``bytes`` of a JPEG file -> :class:`JpegCoefficients`, or ``None`` when the file is left to Pillow.  Host only
-    (``libmdx.so`` makes no device call here), thread-safe, releases the GIL."""
+    (``libmdx.so`` makes no device call here), thread-safe, releases the GIL.  The file is untrusted: the coefficient buffer
+    (128 B per 8x8 block) is sized from its frame header only after the probe has checked that a file of this length can
+    hold such a picture (``mdx_jpeg_probe``: one bit per block at least) and never for more than ``max_pixels``."""
     lib = _lib.lib()
     buf = np.frombuffer(data, dtype=np.uint8)
+    if buf.size == 0:
+        return None
     info = _lib.JpegInfo()
     ops.check(lib.mdx_jpeg_probe(buf.ctypes.data, buf.size, ctypes.byref(info)), "mdx_jpeg_probe")
-    if not info.supported:
+    if not info.supported or info.width * info.height > max_pixels:
         return None
     coef = torch.empty((info.nblocks, 64), dtype=torch.int16)
     quant = torch.empty((3, 64), dtype=torch.int16)            # uint16 bit patterns
