@@ -599,37 +599,42 @@ def main():
             kms = extra.get("roofline", {}).get("kernel_ms") or 0.0
             sec["configs2_top100"] = {"workload": "N=%d Q=%d: exact top-100 per query instead of the full ranking" % (n_total, NQ),
                                       "topk_ms": round(t_k, 4), "queries_per_s_with_the_fp32_similarity": round(NQ / ((kms + t_k) * 1e-3), 1) if kms else None}
-            # the LABELLED split-precision mode on the SAME fp32 shard (MDX_F32_SPLIT3: three bf16 pieces per operand, six products
-            # on the bf16 MFMA): not the headline, not the parity contract -- timed beside it with what it does to the result
+            # the LABELLED split-precision modes on the SAME fp32 shard (not the headline, not the parity contract -- timed beside it
+            # with what they do to the result): MDX_F32_SPLIT3 = three bf16 pieces per operand, six products on the bf16 MFMA;
+            # MDX_F32_SPLIT2 = block floating point, two fp16 pieces with a scaled residual, three products on the fp16 MFMA
             sc3 = torch.empty_like(sc)
-            t_3 = timed(lambda: sharded.index.scores(qvecs, "DN", out=sc3, compute="split3"), reps=10)
-            b3 = 4.0 * n_total * DIM + 4.0 * NQ * n_total + 6.0 * 80 * DIM
-            d3 = (sc3 - sc).abs()
-            ids3, _ = ops.topk(sc3, 100, workspace=ws)
-            with contextlib.redirect_stdout(sys.stderr):
-                avg3, _ = compute_map_and_print_from_scores("roxford5k", sc3, gnd)
-            diff3 = torch.nonzero(ids3 != rk[:, :100])
-            gap3 = 0.0
-            if len(diff3):          # where the two top-100 lists name other rows: how far apart are those rows' EXACT scores?
-                qq = diff3[:, 0]
-                gap3 = float((sc[qq, ids3[qq, diff3[:, 1]]] - sc[qq, rk[qq, diff3[:, 1]]]).abs().max())
-            assert float(d3.max()) <= SUM_ORDER_TOL and gap3 <= SUM_ORDER_TOL, (float(d3.max()), gap3)
-            sec["split3"] = {
-                "workload": "N=%d Q=%d D=%d, the SAME fp32 shard, MDX_F32_SPLIT3: x = h + m + l in bf16, products hh+hm+mh+hl+lh+mm on "
-                            "v_mfma_f32_16x16x32_bf16, fp32 accumulation (labelled second mode; the exact chain stays the headline)" % (n_total, NQ, DIM),
-                "scores_ms": round(t_3, 4), "exact_chain_scores_ms": kms or None,
-                "roofline": {"kernel": "mdx::scores_split3_kernel<QT=5,R=2,NSTAGE=3,CW=8> (8 MFMA waves splitting in registers + 4 LDS-DMA loader waves)",
-                             "bound": "hbm", "achieved": round(b3 / (t_3 * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": round(b3 / (t_3 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": b3, "traffic": None,
-                             "chain_equivalent_TFLOPs": round(2.0 * NQ * n_total * DIM / (t_3 * 1e-3) / 1e12, 1),
-                             "what": "power-bound with real operands (all-zero operands: the stream-only time of the same kernel), "
-                                     "profiles/r04_split3.md"},
-                "queries_per_s_with_the_fp32_ranking": round(NQ / ((t_3 + extra.get("rank_ms_per_step", 0.0)) * 1e-3), 1),
-                "max_abs_diff_vs_exact_chain": float(d3.max()), "mean_abs_diff_vs_exact_chain": float(d3.mean()), "asserted_bound": SUM_ORDER_TOL,
-                "map_medium_split3": avg3["map_medium"], "map_medium_exact": extra.get("map_medium"),
-                "top100_slot_agreement_with_exact": round(1.0 - len(diff3) / ids3.numel(), 6),
-                "top100_max_exact_score_gap_where_ids_differ": gap3,
-                "top1_agreement_with_exact": round(float((ids3[:, 0] == rk[:, 0]).float().mean()), 6)}
+            for mode, what, kern in (
+                    ("split3", "MDX_F32_SPLIT3: x = h + m + l in bf16, products hh+hm+mh+hl+lh+mm on v_mfma_f32_16x16x32_bf16, fp32 accumulation",
+                     "mdx::scores_split3_kernel<QT=5,R=2,NSTAGE=3,CW=8> (8 MFMA waves splitting in registers + 4 LDS-DMA loader waves)"),
+                    ("split2", "MDX_F32_SPLIT2: block floating point, X = h + m / 2^11 in fp16 (scaled residual), products hh + (hm+mh) / 2^11 on "
+                               "v_mfma_f32_16x16x32_f16, cross terms in their own accumulator",
+                     "mdx::scores_split2_kernel<QT=5,R=2,NSTAGE=3,CW=8> (same ring; half the matrix work of split3)")):
+                t_3 = timed(lambda: sharded.index.scores(qvecs, "DN", out=sc3, compute=mode), reps=10)
+                b3 = 4.0 * n_total * DIM + 4.0 * NQ * n_total + (6.0 if mode == "split3" else 4.0) * 80 * DIM
+                d3 = (sc3 - sc).abs()
+                ids3, _ = ops.topk(sc3, 100, workspace=ws)
+                with contextlib.redirect_stdout(sys.stderr):
+                    avg3, _ = compute_map_and_print_from_scores("roxford5k", sc3, gnd)
+                diff3 = torch.nonzero(ids3 != rk[:, :100])
+                gap3 = 0.0
+                if len(diff3):          # where the two top-100 lists name other rows: how far apart are those rows' EXACT scores?
+                    qq = diff3[:, 0]
+                    gap3 = float((sc[qq, ids3[qq, diff3[:, 1]]] - sc[qq, rk[qq, diff3[:, 1]]]).abs().max())
+                assert float(d3.max()) <= SUM_ORDER_TOL and gap3 <= SUM_ORDER_TOL, (mode, float(d3.max()), gap3)
+                sec[mode] = {
+                    "workload": "N=%d Q=%d D=%d, the SAME fp32 shard, %s (labelled second mode; the exact chain stays the headline)" % (n_total, NQ, DIM, what),
+                    "scores_ms": round(t_3, 4), "exact_chain_scores_ms": kms or None,
+                    "roofline": {"kernel": kern, "bound": "hbm", "achieved": round(b3 / (t_3 * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(b3 / (t_3 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": b3, "traffic": None,
+                                 "chain_equivalent_TFLOPs": round(2.0 * NQ * n_total * DIM / (t_3 * 1e-3) / 1e12, 1),
+                                 "what": ("power-bound with real operands (all-zero operands: the stream-only time of the same kernel)" if mode == "split3"
+                                          else "at the ring's stream-only time: half of split3's matrix work fits under the stream") + ", profiles/r04_split3.md"},
+                    "queries_per_s_with_the_fp32_ranking": round(NQ / ((t_3 + extra.get("rank_ms_per_step", 0.0)) * 1e-3), 1),
+                    "max_abs_diff_vs_exact_chain": float(d3.max()), "mean_abs_diff_vs_exact_chain": float(d3.mean()), "asserted_bound": SUM_ORDER_TOL,
+                    "map_medium_" + mode: avg3["map_medium"], "map_medium_exact": extra.get("map_medium"),
+                    "top100_slot_agreement_with_exact": round(1.0 - len(diff3) / ids3.numel(), 6),
+                    "top100_max_exact_score_gap_where_ids_differ": gap3,
+                    "top1_agreement_with_exact": round(float((ids3[:, 0] == rk[:, 0]).float().mean()), 6)}
             del sc3, d3
             half = ops.DescriptorIndex(rows, "ND", storage="f16")
             t_h = timed(lambda: half.scores(qvecs, "DN", out=sc), reps=10)

@@ -260,11 +260,21 @@ int mdx_scores(const mdx_index *index, const float *queries, int64_t nq, int qla
  *                   by the shard stream (HBM) instead of the matrix pipe.  NOT bit-equal to the chain: the accumulation
  *                   order differs (measured ~1e-7 on unit-norm descriptors; tests/test_gpu_round4.py bounds it by 2e-6,
  *                   the summation-order bound bench.py holds the reference's own BLAS path to).  fp32 range (bf16 has
- *                   fp32's exponent); an infinite operand gives NaN. */
-typedef enum mdx_compute { MDX_F32_CHAIN = 0, MDX_F32_SPLIT3 = 1 } mdx_compute;
+ *                   fp32's exponent); an infinite operand gives NaN.
+ *   MDX_F32_SPLIT2  a second labelled mode, for when the matrix' dynamic range is ordinary (L2-normalised descriptors: the path's
+ *                   own data).  Block floating point: each matrix is scaled by a power of two that brings its largest magnitude
+ *                   into fp16's range (the shard's maximum is read once at mdx_index_create, the queries' by a reduction on the
+ *                   device), every operand is two fp16 pieces X = h + m / 2^11 (round toward zero, residual exact and scaled:
+ *                   |X - h - m / 2^11| < 2^-20 |X|), a product is hh + (hm + mh) / 2^11 on v_mfma_f32_16x16x32_f16 -- THREE
+ *                   products instead of six, the cross terms in an accumulator of their own -- and the result is unscaled
+ *                   exactly.  Worst case for unit vectors 2^-20 sum |x_k q_k| <= 1e-6 on top of fp32 accumulation; elements
+ *                   more than 2^-27 below their matrix' largest lose relative precision (the bound is relative to
+ *                   max|x| max|q|, not to each element -- use MDX_F32_SPLIT3 for wide-range data).  Half the matrix work of
+ *                   SPLIT3: the kernel runs at its stream's speed (measured 1.65 ms against 1.97 and 2.62 for the exact chain). */
+typedef enum mdx_compute { MDX_F32_CHAIN = 0, MDX_F32_SPLIT3 = 1, MDX_F32_SPLIT2 = 2 } mdx_compute;
 
 /* mdx_scores with an explicit compute mode; workspace of at least mdx_scores_workspace_ex(nq, d, compute) bytes
- * (MDX_F32_SPLIT3: 6 bytes per padded query element).  MDX_F32_SPLIT3 needs an MDX_F32 shard. */
+ * (MDX_F32_SPLIT3: 6 bytes per padded query element; MDX_F32_SPLIT2: 4 + 256 bytes).  Both need an MDX_F32 shard. */
 int64_t mdx_scores_workspace_ex(int64_t nq, int64_t d, int compute);
 int mdx_scores_ex(const mdx_index *index, const float *queries, int64_t nq, int qlayout, const float *center,
                   float *scores, void *workspace, int64_t workspace_bytes, int compute, void *stream);

@@ -15,8 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 MDX_DIM_MAJOR, MDX_ROW_MAJOR = 0, 1
 MDX_POOL_GEM, MDX_POOL_MAC, MDX_POOL_SPOC = 0, 1, 2
 MDX_F32, MDX_F16 = 0, 1
-MDX_F32_CHAIN, MDX_F32_SPLIT3 = 0, 1
-COMPUTE = {"chain": MDX_F32_CHAIN, "exact": MDX_F32_CHAIN, "split3": MDX_F32_SPLIT3}
+MDX_F32_CHAIN, MDX_F32_SPLIT3, MDX_F32_SPLIT2 = 0, 1, 2
+COMPUTE = {"chain": MDX_F32_CHAIN, "exact": MDX_F32_CHAIN, "split3": MDX_F32_SPLIT3, "split2": MDX_F32_SPLIT2}
 STORAGE = {"f32": MDX_F32, "f16": MDX_F16}
 POOL_KINDS = {"gem": MDX_POOL_GEM, "mac": MDX_POOL_MAC, "spoc": MDX_POOL_SPOC}
 

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ s
                                                      int64_t ks, int64_t n, int64_t d,
                                                      const float *__restrict__ center,
                                                      f32x4 *__restrict__ tiles, int64_t RT,
-                                                     int64_t KB, int kb_fast)
+                                                     int64_t KB, int kb_fast, uint32_t *__restrict__ absmax)
 {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ s
     const int j = lane & 15, g = lane >> 4;
     const int64_t row = rt * TILE_ROWS + j;
     f32x4 v;
+    uint32_t best = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int64_t k = kb * TILE_K + 4 * t + g;
@@ -94,8 +95,18 @@ __global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ s
             if (center) x -= center[k];
         }
         v[t] = x;
+        const uint32_t u = __float_as_uint(x) & 0x7FFFFFFFu;
+        if (u < 0x7F800000u && u > best) best = u;
     }
     tiles[(rt * KB + kb) * 64 + lane] = v;
+    if (absmax) {               // the shard's largest finite magnitude (index build only): the scale of MDX_F32_SPLIT2
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64);
+            best = other > best ? other : best;
+        }
+        if (lane == 0 && best) atomicMax(absmax, best);
+    }
 }
 
 // Loader/consumer kernel (4 MFMA waves + 4 LDS-DMA loader waves), chunks of 2 tiles along k,
@@ -234,6 +245,34 @@ static int dispatch_split3(int qt, const f32x4 *db, const u32x4 *qp, float *out,
     }
 }
 
+template <int QT, int R>
+static int launch_split2(const f32x4 *db, const u32x4 *qp, float *out, int64_t n, int64_t RT, int KB, int QT_total, int qt_first,
+                         int nq_valid, float db_scale, const uint32_t *q_cell, hipStream_t s, int passes)
+{
+    auto kern = scores_split2_kernel<QT, R, SPLIT_NSTAGE, SPLIT_CW>;
+    constexpr int lds = SPLIT_NSTAGE * (2 * QT + 2 * SPLIT_CW * R) * 1024;
+    static bool opted[64];
+    int rc = lds_opt_in((const void *)kern, lds, opted);
+    if (rc != MDX_OK) return rc;
+    const int64_t blocks = ceil_div(RT, (int64_t)SPLIT_CW * R);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(SPLIT_CW * 64 + 256), lds, s, db, qp, out, n, KB, QT_total,
+                       qt_first, nq_valid, db_scale, q_cell);
+    return MDX_OK;
+}
+
+template <int R>
+static int dispatch_split2(int qt, const f32x4 *db, const u32x4 *qp, float *out, int64_t n, int64_t RT, int KB, int QT_total, int qt_first,
+                           int nq_valid, float db_scale, const uint32_t *q_cell, hipStream_t s, int passes)
+{
+    switch (qt) {
+        case 1: return launch_split2<1, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, db_scale, q_cell, s, passes);
+        case 2: return launch_split2<2, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, db_scale, q_cell, s, passes);
+        case 3: return launch_split2<3, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, db_scale, q_cell, s, passes);
+        case 4: return launch_split2<4, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, db_scale, q_cell, s, passes);
+        default: return launch_split2<5, R>(db, qp, out, n, RT, KB, QT_total, qt_first, nq_valid, db_scale, q_cell, s, passes);
+    }
+}
+
 }  // namespace mdx
 
 using namespace mdx;
@@ -243,6 +282,7 @@ struct mdx_index {
     int64_t n, d, d_pad, RT, RT_pad, KB, row_offset;
     int64_t bytes;
     int storage;        // MDX_F32 / MDX_F16
+    uint32_t max_bits;  // fp32 shards: bit pattern of the largest finite |x| (read back once at creation): the scale of MDX_F32_SPLIT2
 };
 
 extern "C" {
@@ -251,7 +291,7 @@ int mdx_abi_version(void) { return MDX_ABI_VERSION; }
 const char *mdx_last_error(void) { return mdx::g_err; }
 
 static int retile(const float *src, int64_t n, int64_t d, int layout, const float *center,
-                  f32x4 *tiles, int64_t RT, int64_t KB, hipStream_t s, int storage = MDX_F32)
+                  f32x4 *tiles, int64_t RT, int64_t KB, hipStream_t s, int storage = MDX_F32, uint32_t *absmax = nullptr)
 {
     const int64_t rs = layout == MDX_DIM_MAJOR ? 1 : d;
     const int64_t ks = layout == MDX_DIM_MAJOR ? n : 1;
@@ -262,7 +302,7 @@ static int retile(const float *src, int64_t n, int64_t d, int layout, const floa
                            center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1);
     else
         hipLaunchKernelGGL(retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, rs, ks, n, d,
-                           center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1);
+                           center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1, absmax);
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
@@ -293,7 +333,8 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
     ix->RT_pad = round_up(ix->RT, storage == MDX_F32 ? 16 : 8);
     ix->row_offset = row_offset;
     ix->bytes = ix->RT_pad * ix->KB * 1024;
-    hipError_t e = hipMalloc((void **)&ix->tiles, (size_t)ix->bytes);
+    ix->max_bits = 0;
+    hipError_t e = hipMalloc((void **)&ix->tiles, (size_t)ix->bytes + 256);     // + one word behind the tiles: the |x| maximum
     if (e != hipSuccess) {
         set_error("mdx_index_create: hipMalloc(%lld bytes) failed: %s", (long long)ix->bytes,
                   hipGetErrorString(e));
@@ -301,7 +342,16 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
         return MDX_ERR_NOMEM;
     }
     hipStream_t s = (hipStream_t)stream;
-    int rc = retile(src, n, d, layout, nullptr, ix->tiles, ix->RT_pad, ix->KB, s, storage);
+    uint32_t *cell = storage == MDX_F32 ? (uint32_t *)((char *)ix->tiles + ix->bytes) : nullptr;
+    if (cell && hipMemsetAsync(cell, 0, 4, s) != hipSuccess) cell = nullptr;
+    int rc = retile(src, n, d, layout, nullptr, ix->tiles, ix->RT_pad, ix->KB, s, storage, cell);
+    if (rc == MDX_OK && cell) {
+        // index creation is the call of this path that may synchronise: the maximum comes back with the build
+        if (hipMemcpyAsync(&ix->max_bits, cell, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            set_error("mdx_index_create: reading the shard's maximum failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = MDX_ERR_RUNTIME;
+        }
+    }
     if (rc != MDX_OK) {
         (void)hipStreamSynchronize(s);
         (void)hipFree(ix->tiles);
@@ -413,6 +463,7 @@ int64_t mdx_scores_workspace_ex(int64_t nq, int64_t d, int compute)
 {
     if (nq <= 0 || d <= 0) return 0;
     if (compute == MDX_F32_SPLIT3) return round_up(nq, TILE_ROWS) * round_up(d, 64) * 6;      // three bf16 pieces per element
+    if (compute == MDX_F32_SPLIT2) return round_up(nq, TILE_ROWS) * round_up(d, 64) * 4 + 256;    // two fp16 pieces + the queries' |q| maximum
     return mdx_scores_workspace(nq, d);
 }
 
@@ -420,9 +471,9 @@ int mdx_scores_ex(const mdx_index *ix, const float *queries, int64_t nq, int qla
                   void *workspace, int64_t workspace_bytes, int compute, void *stream)
 {
     if (compute == MDX_F32_CHAIN) return mdx_scores(ix, queries, nq, qlayout, center, scores, workspace, workspace_bytes, stream);
-    MDX_CHECK_ARG(compute == MDX_F32_SPLIT3, "mdx_scores_ex: compute mode %d", compute);
+    MDX_CHECK_ARG(compute == MDX_F32_SPLIT3 || compute == MDX_F32_SPLIT2, "mdx_scores_ex: compute mode %d", compute);
     MDX_CHECK_ARG(ix && queries && scores, "mdx_scores_ex: NULL pointer");
-    MDX_CHECK_ARG(ix->storage == MDX_F32, "mdx_scores_ex: MDX_F32_SPLIT3 multiplies an fp32 shard (this one is stored as fp16)");
+    MDX_CHECK_ARG(ix->storage == MDX_F32, "mdx_scores_ex: the split-precision modes multiply an fp32 shard (this one is stored as fp16)");
     MDX_CHECK_ARG(nq > 0 && nq < (1 << 20), "mdx_scores_ex: nq=%lld", (long long)nq);
     MDX_CHECK_ARG(qlayout == MDX_DIM_MAJOR || qlayout == MDX_ROW_MAJOR, "mdx_scores_ex: qlayout %d", qlayout);
     const int64_t need = mdx_scores_workspace_ex(nq, ix->d, compute);
@@ -434,20 +485,35 @@ int mdx_scores_ex(const mdx_index *ix, const float *queries, int64_t nq, int qla
     u32x4 *qp = (u32x4 *)workspace;
     const int64_t QT_total = ceil_div(nq, TILE_ROWS), NC = ix->KB / 2;
     const int64_t rs = qlayout == MDX_DIM_MAJOR ? 1 : ix->d, ks = qlayout == MDX_DIM_MAJOR ? nq : 1;
-    hipLaunchKernelGGL(retile_split3_kernel, dim3((unsigned)ceil_div(QT_total * NC, (int64_t)4)), dim3(256), 0, s, queries, rs, ks, nq, ix->d,
-                       center, qp, QT_total, NC);
+    const bool two = compute == MDX_F32_SPLIT2;
+    uint32_t *q_cell = two ? (uint32_t *)((char *)workspace + need - 256) : nullptr;
+    const float db_scale = two ? split2_scale(ix->max_bits) : 1.0f;
+    if (two) {
+        // the queries' largest |q - center| stays on the device: a reduction, then the re-tiling and the kernel's epilogue read it
+        MDX_HIP(hipMemsetAsync(q_cell, 0, 4, s));
+        const int64_t total = nq * ix->d;
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(ceil_div(total, (int64_t)1024) < 1024 ? ceil_div(total, (int64_t)1024) : 1024)), dim3(256), 0, s,
+                           queries, rs, ks, nq, ix->d, center, q_cell);
+        hipLaunchKernelGGL(retile_split2_kernel, dim3((unsigned)ceil_div(QT_total * NC, (int64_t)4)), dim3(256), 0, s, queries, rs, ks, nq, ix->d,
+                           center, (const uint32_t *)q_cell, qp, QT_total, NC);
+    } else {
+        hipLaunchKernelGGL(retile_split3_kernel, dim3((unsigned)ceil_div(QT_total * NC, (int64_t)4)), dim3(256), 0, s, queries, rs, ks, nq, ix->d,
+                           center, qp, QT_total, NC);
+    }
     MDX_LAUNCH_CHECK();
     const bool small = ix->RT < 4096;                 // < 65 536 rows: 128-row workgroups, so that the shard still spreads over the CUs
     const int64_t full = QT_total / SPLIT_QT, rem = QT_total % SPLIT_QT;
+    auto go = [&](int qt, int64_t qt_first, int passes) -> int {
+        if (two)
+            return small ? dispatch_split2<1>(qt, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)qt_first, (int)nq, db_scale, q_cell, s, passes)
+                         : dispatch_split2<2>(qt, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)qt_first, (int)nq, db_scale, q_cell, s, passes);
+        return small ? dispatch_split3<1>(qt, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)qt_first, (int)nq, s, passes)
+                     : dispatch_split3<2>(qt, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)qt_first, (int)nq, s, passes);
+    };
     int rc = MDX_OK;
-    for (int64_t g0 = 0; g0 < full && rc == MDX_OK; g0 += 32768) {      // grid.y < 65 536
-        const int passes = (int)((full - g0) < 32768 ? (full - g0) : 32768);
-        rc = small ? dispatch_split3<1>(SPLIT_QT, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)(g0 * SPLIT_QT), (int)nq, s, passes)
-                   : dispatch_split3<2>(SPLIT_QT, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)(g0 * SPLIT_QT), (int)nq, s, passes);
-    }
-    if (rc == MDX_OK && rem)
-        rc = small ? dispatch_split3<1>((int)rem, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)(full * SPLIT_QT), (int)nq, s, 1)
-                   : dispatch_split3<2>((int)rem, ix->tiles, qp, scores, ix->n, ix->RT, (int)ix->KB, (int)QT_total, (int)(full * SPLIT_QT), (int)nq, s, 1);
+    for (int64_t g0 = 0; g0 < full && rc == MDX_OK; g0 += 32768)        // grid.y < 65 536
+        rc = go(SPLIT_QT, g0 * SPLIT_QT, (int)((full - g0) < 32768 ? (full - g0) : 32768));
+    if (rc == MDX_OK && rem) rc = go((int)rem, full * SPLIT_QT, 1);
     if (rc != MDX_OK) return rc;
     MDX_LAUNCH_CHECK();
     return MDX_OK;

@@ -15,7 +15,9 @@ nothing but the APs); ``ranking="full"`` runs the reference's dot + argsort + co
 sequence literally.  ``storage="f16"`` (criterion key, not in the reference) keeps the database shard in
 fp16 for the fp16 MFMA -- BASELINE.json configs[4].  ``similarity="split3"`` (criterion key, not in the reference) takes
 the LABELLED split-precision form of the dot product on the same fp32 shard (three bf16 pieces per operand on the bf16
-MFMA: 0.75 of the exact kernel's time, scores within 2e-6 of it; default ``"exact"`` = the k-ordered fp32 chain).
+MFMA: 0.75 of the exact kernel's time, scores within 2e-6 of it; ``"split2"``: two fp16 pieces with a scaled residual,
+block floating point, 0.63 of the exact kernel's time, same bound for data of ordinary dynamic range; default ``"exact"`` =
+the k-ordered fp32 chain).
 """
 import os.path
 
@@ -56,8 +58,8 @@ class CirDatasetAp:
         # how an fp32 shard is multiplied: "exact" (default: the k-ordered fp32 fma chain, the parity contract) or "split3"
         # (labelled second mode, include/mdx.h MDX_F32_SPLIT3)
         self.similarity = params.pop("similarity", "exact")
-        assert self.similarity in {"exact", "split3"}, self.similarity
-        assert not (self.similarity == "split3" and self.storage != "f32"), "similarity: split3 multiplies an fp32 shard"
+        assert self.similarity in {"exact", "split3", "split2"}, self.similarity
+        assert not (self.similarity != "exact" and self.storage != "f32"), "similarity: split3 / split2 multiply an fp32 shard"
         if isinstance(self.dataset, dict):
             assert self.dataset.keys() == {"name", "queries", "db", "imgdir"}
             imgdir = self.dataset["imgdir"]
@@ -88,7 +90,7 @@ class CirDatasetAp:
             averages, scores_per_query = sharded_retrieval_map(
                 network, self.images, self.qimages, self.bbxs, self.gnd, self.dataset, self.image_size,
                 self.transforms, device, lap=stopwatch.lap, storage=self.storage,
-                compute="split3" if self.similarity == "split3" else "chain")
+                compute="chain" if self.similarity == "exact" else self.similarity)
             self._log(logger, stopwatch, averages, scores_per_query)
             return
         print(">> {}: database images...".format(self.dataset))
@@ -106,7 +108,7 @@ class CirDatasetAp:
         with range_("%s/compute_score" % self.dataset):
             index = ops.DescriptorIndex(vecs, "ND", storage=self.storage)
             with range_("similarity"):
-                kw = {"compute": "split3"} if self.similarity == "split3" else {}
+                kw = {} if self.similarity == "exact" else {"compute": self.similarity}
                 scores = index.scores(qvecs, "ND", **kw)            # [Q,N] = (vecs.T @ qvecs).T
             if self.ranking == "full":
                 with range_("ranking"):

@@ -129,15 +129,15 @@ def chunk_bounds(lo, hi, chunks):
 class ShardedIndex:
     def __init__(self, local_vecs, layout, n_total, group=None, backend=None, storage="f32", compute="chain"):
         """``storage``: "f32" (exact chain) or "f16" (fp16 shard on the fp16 MFMA, BASELINE.json configs[4]).
-        ``compute``: "chain" (default) or "split3" -- the labelled split-precision similarity on an fp32 shard
+        ``compute``: "chain" (default), "split3" or "split2" -- the labelled split-precision similarities on an fp32 shard
         (``DescriptorIndex.scores(compute=...)``, ``include/mdx.h`` ``MDX_F32_SPLIT3``)."""
         self.group = group
         self.storage = storage
-        if compute not in ("chain", "exact", "split3"):
+        if compute not in ("chain", "exact", "split3", "split2"):
             raise ValueError("compute %r" % (compute,))
-        if compute == "split3" and storage != "f32":
-            raise ValueError("compute='split3' multiplies an fp32 shard")
-        self._score_kw = {"compute": "split3"} if compute == "split3" else {}
+        if compute in ("split3", "split2") and storage != "f32":
+            raise ValueError("compute=%r multiplies an fp32 shard" % (compute,))
+        self._score_kw = {"compute": compute} if compute in ("split3", "split2") else {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_total = int(n_total)

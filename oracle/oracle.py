@@ -203,6 +203,44 @@ def scores_split3(vecs, qvecs):
     return s.astype(F32)
 
 
+def _fp16_toward_zero(x):
+    """float64 -> the fp16 value of no larger magnitude (what ``v_cvt_pkrtz_f16_f32`` gives a finite in-range value),
+    as float64: normals keep 11 significant bits, values under 2^-14 sit on the 2^-24 grid."""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.abs(x)
+    e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    q = np.exp2(np.maximum(e, -14.0) - 10.0)
+    return np.sign(x) * np.floor(a / q) * q
+
+
+def split2_scale(a):
+    """The power of two that brings the matrix' largest finite magnitude into [2^13, 2^14) (1 for an all-zero matrix):
+    the block exponent of ``MDX_F32_SPLIT2`` (mdir_amd/csrc/mdx_scores_split_kernel.h ``split2_scale``)."""
+    m = np.abs(np.asarray(a, dtype=F32))
+    m = m[np.isfinite(m)]
+    top = float(m.max()) if m.size else 0.0
+    if top == 0.0 or top < np.finfo(np.float32).tiny:
+        return 1.0
+    return float(np.exp2(np.clip(13 - np.floor(np.log2(top)), -126, 126)))
+
+
+def scores_split2(vecs, qvecs):
+    """The two-piece block-floating form of ``np.dot(vecs.T, qvecs)`` (cirscore.py:69) as the library computes it
+    (``MDX_F32_SPLIT2``), up to the order of the fp32 accumulation: each matrix scaled by its ``split2_scale``, every operand
+    ``X = h + m / 2^11`` in fp16 (round toward zero, residual exact), products ``hh + (hm + mh) / 2^11`` summed in float64,
+    unscaled.  ``[D,N]``, ``[D,Q]`` -> fp32 ``[N,Q]``.  Test infrastructure."""
+    sd, sq = split2_scale(vecs), split2_scale(qvecs)
+
+    def pieces(a, s):
+        X = np.asarray(a, dtype=F32).astype(np.float64) * s
+        h = _fp16_toward_zero(X)
+        return h, _fp16_toward_zero((X - h) * 2048.0)
+    dh, dm = pieces(vecs, sd)
+    qh, qm = pieces(qvecs, sq)
+    s = dh.T @ qh + (dh.T @ qm + dm.T @ qh) / 2048.0
+    return (s / (sd * sq)).astype(F32)
+
+
 def ranks(sc):
     """Per-query descending ranking ``[N,Q] -> int64 [N,Q]``.
 

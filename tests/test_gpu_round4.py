@@ -132,6 +132,61 @@ def test_split3_scores_within_summation_order_of_the_chain(n, d, nq):
     np.testing.assert_array_equal(ix.scores(dev(qvecs), "DN").cpu().numpy(), chain)      # the exact mode of the same index
 
 
+@pytest.mark.parametrize("n,d,nq", SPLIT_SHAPES)
+def test_split2_scores_within_summation_order_of_the_chain(n, d, nq):
+    """MDX_F32_SPLIT2 (block floating point: two fp16 pieces with a scaled residual, three products) on the same 21 shapes:
+    |score - chain| <= 2e-6, against float64 no worse than twice the chain's own error (or 3e-7), equal to the numpy
+    restatement within fp32 accumulation, both layouts the same bits, and scaling the database by 1e3 and the queries by
+    1e-4 (other block exponents) scales the scores exactly by 0.1-ish: the same values times the exact power-of-two part."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(n + d + nq)
+    db, qv = _unit_rows(rng, n, d), _unit_rows(rng, nq, d)
+    vecs, qvecs = np.ascontiguousarray(db.T), np.ascontiguousarray(qv.T)
+    chain = OC.scores_chain(vecs, qvecs)
+    ix = ops.DescriptorIndex(dev(vecs), "DN")
+    got = ix.scores(dev(qvecs), "DN", compute="split2").cpu().numpy()
+    assert got.shape == chain.shape and np.isfinite(got).all()
+    assert np.abs(got - chain).max() <= SUM_ORDER_TOL
+    exact = (qv.astype(np.float64) @ db.astype(np.float64).T)
+    err2, err_chain = np.abs(got - exact).max(), np.abs(chain - exact).max()
+    assert err2 <= max(2.0 * err_chain, 3e-7), (err2, err_chain)
+    if n * nq <= 2_000_000:
+        np.testing.assert_allclose(got.T, O.scores_split2(vecs, qvecs), rtol=0, atol=1e-6)
+    got2 = ops.DescriptorIndex(dev(db), "ND").scores(dev(qv), "ND", compute="split2").cpu().numpy()
+    np.testing.assert_array_equal(got2, got)
+    # other block exponents: powers of two move the block exponent only -> bit-identical results up to that power
+    big = ops.DescriptorIndex(dev(db * np.float32(1024.0)), "ND").scores(dev(qv * np.float32(2.0 ** -13)), "ND", compute="split2").cpu().numpy()
+    np.testing.assert_array_equal(big, got * np.float32(2.0 ** -3))
+    np.testing.assert_array_equal(ix.scores(dev(qvecs), "DN").cpu().numpy(), chain)      # the exact mode of the same index
+
+
+def test_split2_range_center_zero_rows_and_errors():
+    from mdir_amd import ops
+    rng = np.random.default_rng(10)
+    n, d, nq = 900, 200, 21
+    db = rng.standard_normal((n, d)).astype(np.float32) * np.float32(37.0)          # not unit norm: the block exponent takes it
+    db[3] = 0
+    db[5] *= np.float32(1e-3)                                                       # a weak row: still 2^-20 of the BLOCK scale
+    qv = rng.standard_normal((nq, d)).astype(np.float32) * np.float32(1e-6)
+    qv[2] = 0
+    m = (rng.standard_normal(d) * 1e-6).astype(np.float32)
+    ix = ops.DescriptorIndex(dev(db), "ND")
+    got = ix.scores(dev(qv), "ND", center=dev(m), compute="split2").cpu().numpy()
+    want = (qv - m).astype(np.float64) @ db.astype(np.float64).T
+    assert np.isfinite(got).all() and (got[:, 3] == 0).all()
+    # bound of the mode: 2^-20 sum_k |q_k| |x_k| with every element counted at (at least) 2^-10 of its matrix' maximum, + fp32 accumulation
+    qa, xa = np.abs((qv - m).astype(np.float64)), np.abs(db.astype(np.float64))
+    floor_q, floor_x = qa.max() * 2.0 ** -10, xa.max() * 2.0 ** -10
+    bound = 2.0 ** -19 * (np.maximum(qa, floor_q) @ np.maximum(xa, floor_x).T) + 2.0 ** -22 * (qa @ xa.T)
+    assert (np.abs(got - want) <= bound).all(), float((np.abs(got - want) / bound).max())
+    zero = ops.DescriptorIndex(dev(np.zeros((64, d), np.float32)), "ND")             # an all-zero shard: scale 1, scores 0
+    assert (zero.scores(dev(qv), "ND", compute="split2").cpu().numpy() == 0).all()
+    assert (ix.scores(dev(np.zeros((3, d), np.float32)), "ND", compute="split2").cpu().numpy() == 0).all()
+    half = ops.DescriptorIndex(dev(db[:64] * np.float32(1e-3)), "ND", storage="f16")
+    with pytest.raises(ValueError, match="fp32 shard"):
+        half.scores(dev(qv), "ND", compute="split2")
+
+
 def test_split3_edge_values_center_and_errors():
     from mdir_amd import ops
     rng = np.random.default_rng(9)

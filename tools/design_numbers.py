@@ -55,6 +55,10 @@ rows = [
         f(g(sec, "split3", "roofline", "frac")), f(g(sec, "split3", "max_abs_diff_vs_exact_chain"), "%.1e"),
         f(g(sec, "split3", "top100_slot_agreement_with_exact"), "%.4f"), f(g(sec, "split3", "queries_per_s_with_the_fp32_ranking"), "%.0f")),
      "`secondary_configs.split3`, `profiles/%s_split3.md`" % tag),
+    ("LABELLED block-floating mode `MDX_F32_SPLIT2` (two fp16 pieces, three products)", "%s ms = %s GB/s of algorithmic bytes = %s of 8 TB/s; max abs(diff) %s; top-100 slot agreement %s; with the fp32 ranking %s queries/s"
+     % (f(g(sec, "split2", "scores_ms")), f(g(sec, "split2", "roofline", "achieved"), "%.0f"), f(g(sec, "split2", "roofline", "frac")),
+        f(g(sec, "split2", "max_abs_diff_vs_exact_chain"), "%.1e"), f(g(sec, "split2", "top100_slot_agreement_with_exact"), "%.4f"),
+        f(g(sec, "split2", "queries_per_s_with_the_fp32_ranking"), "%.0f")), "`secondary_configs.split2`"),
     ("configs[4]: fp16 shard (HBM-bound)", "%s ms = %s GB/s = %s of 8 TB/s; top-100 agreement with fp32 %s"
      % (f(g(sec, "configs4_fp16_shard", "scores_ms")), f(g(sec, "configs4_fp16_shard", "roofline", "achieved"), "%.0f"),
         f(g(sec, "configs4_fp16_shard", "roofline", "frac")), f(g(sec, "configs4_fp16_shard", "top100_slot_agreement_with_fp32"), "%.4f")),

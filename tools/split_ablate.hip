@@ -1,7 +1,7 @@
 // Timing harness for the split-precision similarity kernel (mdx_scores_split_kernel.h): shapes of the workgroup and
 // timing-only ablations (ABL != 0: results wrong), all variants interleaved in one process on gaussian data of the real
 // magnitude (low-entropy data runs faster through DVFS and misleads).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mdir_amd/csrc -I tools/attic tools/split_ablate.hip -o tools/split_ablate_bin
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMDX_XCD_BLOCKS_RUNTIME -I mdir_amd/csrc -I tools/attic tools/split_ablate.hip -o tools/split_ablate_bin
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -199,8 +199,8 @@ int main(int argc, char **argv)
                go(scores_split3_kernel<5, 1, 4, 8>, 5, 1, 4, 8), go(scores_split3_kernel<5, 1, 5, 8>, 5, 1, 5, 8),
                go(scores_split3_kernel<5, 2, 4, 4>, 5, 2, 4, 4), go(scores_split3_kernel<5, 2, 2, 8>, 5, 2, 2, 8),
                go(scores_split3_kernel<5, 2, 3, 8, 0>, 5, 2, 3, 8));
-        printf("ablate  CW8 R2 NST3: full %.4f | no split %.4f | no MFMA %.4f | stream + barriers only %.4f ms\n",
-               go(scores_split3_kernel<5, 2, 3, 8>, 5, 2, 3, 8), go(scores_split3_kernel<5, 2, 3, 8, 2, 1>, 5, 2, 3, 8),
+        printf("ablate  CW8 R2 NST3: full %.4f | two-piece cost model (3 products) %.4f | no split %.4f | no MFMA %.4f | stream + barriers only %.4f ms\n",
+               go(scores_split3_kernel<5, 2, 3, 8>, 5, 2, 3, 8), go(scores_split3_kernel<5, 2, 3, 8, 2, 4>, 5, 2, 3, 8), go(scores_split3_kernel<5, 2, 3, 8, 2, 1>, 5, 2, 3, 8),
                go(scores_split3_kernel<5, 2, 3, 8, 2, 2>, 5, 2, 3, 8), go(scores_split3_kernel<5, 2, 3, 8, 2, 3>, 5, 2, 3, 8));
         fflush(stdout);
     }

@@ -18,7 +18,7 @@ rows = bench.gen_rows(0, n, dev)
 qvecs, qid = bench.gen_queries(n, dev)
 ix = ops.DescriptorIndex(rows, "ND")
 del rows
-sc = {m: torch.empty((bench.NQ, n), dtype=torch.float32, device=dev) for m in ("chain", "split3")}
+sc = {m: torch.empty((bench.NQ, n), dtype=torch.float32, device=dev) for m in ("chain", "split3", "split2")}
 
 
 def timed(mode):
@@ -36,9 +36,10 @@ for mode in sc:
 torch.cuda.synchronize()
 for rnd in range(3):
     print("round %d: " % rnd + "  ".join("%s %.4f ms" % (m, timed(m)) for m in sc), flush=True)
-diff = (sc["chain"] - sc["split3"]).abs()
-print("max |split3 - chain| = %.3g, mean %.3g; top-1 equal %s" % (float(diff.max()), float(diff.mean()),
-      bool((sc["chain"].argmax(1) == sc["split3"].argmax(1)).all())))
+for m in ("split3", "split2"):
+    diff = (sc["chain"] - sc[m]).abs()
+    print("max |%s - chain| = %.3g, mean %.3g; top-1 equal %s" % (m, float(diff.max()), float(diff.mean()),
+          bool((sc["chain"].argmax(1) == sc[m].argmax(1)).all())))
 t = timed("split3")
 algo = 4.0 * n * bench.DIM + 4.0 * bench.NQ * n
 print("split3: %.4f ms = %.2f TB/s of algorithmic bytes (%.3f of 8 TB/s); chain-equivalent %.1f TFLOP/s" % (

@@ -33,10 +33,11 @@ for it in range(iters):
         got = ix.scores(qd, "ND").cpu().numpy()
         ok = np.array_equal(got, want) if storage == "f32" else np.allclose(got, want, rtol=0, atol=2e-6)
         if storage == "f32" and rep % 2 == 0:       # the labelled split-precision mode on the same index, between exact launches
-            got3 = ix.scores(qd, "ND", compute="split3").cpu().numpy()
-            if not (np.abs(got3 - want).max() <= 2e-6):
-                bad += 1
-                print("SPLIT3 MISMATCH it=%d rep=%d n=%d d=%d nq=%d: max diff %.3g" % (it, rep, n, d, nq, np.abs(got3 - want).max()))
+            for mode in ("split3", "split2"):
+                got3 = ix.scores(qd, "ND", compute=mode).cpu().numpy()
+                if not (np.abs(got3 - want).max() <= 2e-6):
+                    bad += 1
+                    print("%s MISMATCH it=%d rep=%d n=%d d=%d nq=%d: max diff %.3g" % (mode, it, rep, n, d, nq, np.abs(got3 - want).max()))
         if not ok:
             bad += 1
             w = np.argwhere(got != want) if storage == "f32" else np.argwhere(np.abs(got - want) > 2e-6)
