@@ -178,14 +178,15 @@ def test_full_size_scores_bit_exact_on_samples(big):
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)        # vs the reference's BLAS: north-star tolerance
 
 
-def test_full_size_split3_mode_on_the_same_shard(big):
-    """MDX_F32_SPLIT3 at BASELINE's full size, on the index the exact tests use (no second copy): every score within the
+@pytest.mark.parametrize("mode", ["split3", "split2"])
+def test_full_size_split_modes_on_the_same_shard(big, mode):
+    """MDX_F32_SPLIT3 / MDX_F32_SPLIT2 at BASELINE's full size, on the index the exact tests use (no second copy): every score within the
     summation-order bound 2e-6 of the exact chain (all 70 M of them, on the device), sampled rows as close to the float64 dot
     product as the chain is, exact zeros stay zeros, duplicated rows still tie exactly, and the ranking of the split scores
     differs from the exact ranking only between rows whose EXACT scores are closer than the bound."""
     from mdir_amd import ops
     sc, rk, n, nq = big["sc"], big["rk"], big["n"], big["nq"]
-    s3 = big["ix"].scores(big["q"].contiguous(), "ND", compute="split3")
+    s3 = big["ix"].scores(big["q"].contiguous(), "ND", compute=mode)
     assert float((s3 - sc).abs().max()) <= 2e-6
     assert bool((s3[:, 5] == 0).all()) and bool((s3[:, 123] == s3[:, 77]).all()) and bool((s3[:, 900_000] == s3[:, 77]).all())
     rng = np.random.default_rng(3)
@@ -194,7 +195,7 @@ def test_full_size_split3_mode_on_the_same_shard(big):
     exact = big["q"].cpu().numpy().astype(np.float64) @ sub.T
     err3 = np.abs(s3[:, torch.from_numpy(ids).to(DEV)].cpu().numpy() - exact).max()
     errc = np.abs(sc[:, torch.from_numpy(ids).to(DEV)].cpu().numpy() - exact).max()
-    assert err3 <= max(2.0 * errc, 2e-7), (err3, errc)
+    assert err3 <= max(2.0 * errc, 3e-7), (err3, errc)
     k = 1000
     ids3, _ = ops.topk(s3, k)
     differ = torch.nonzero(ids3 != rk[:, :k])

@@ -433,6 +433,10 @@ def test_split3_from_the_scenario_surface_and_under_graph_capture(tmp_path):
     ev = [sys.executable, os.path.join(ROOT, "eval.py"), "eval.yml", os.path.join(root, "eval_synth.yml")]
     exact = printed(ev)
     assert printed(ev + [over]) == exact
+    over2 = str(tmp_path / "split2.yml")
+    with open(over2, "w") as f:
+        f.write("validation:\n  roxford5k: {criterion: {similarity: split2}}\n")
+    assert printed(ev + [over2]) == exact
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -18,10 +18,10 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BU
   timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "mdx::" --output-format csv -d $W/pmc_$n -- python3 $R/bench.py --steps 3 --warmup 1 --profile ${PMC_ARGS:-} > $OUT/pmc_$n.log 2>&1
   cp $W/pmc_$n/*/*_counter_collection.csv $OUT/pmc_$n.csv
 done
-# the labelled split-precision mode (MDX_F32_SPLIT3) on the same shard: its own counter passes over tools/split_bench.py
+# the labelled split-precision modes (MDX_F32_SPLIT3, MDX_F32_SPLIT2) on the same shard: their own counter passes over tools/split_bench.py
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAVES"; do
   n=$(echo $c | cut -d' ' -f1)
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "scores_split3" --output-format csv -d $W/pmc3_$n -- python3 $R/tools/split_bench.py 1004993 3 > $OUT/pmc_split3_$n.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "scores_split" --output-format csv -d $W/pmc3_$n -- python3 $R/tools/split_bench.py 1004993 3 > $OUT/pmc_split3_$n.log 2>&1
   cp $W/pmc3_$n/*/*_counter_collection.csv $OUT/pmc_split3_$n.csv
 done
 timeout 200 python3 $R/tools/split_bench.py > $OUT/split_bench.log 2>&1

@@ -73,17 +73,18 @@ out = {"note": "HBM bytes per launch; FETCH_SIZE x2 (gfx950 correction), WRITE_S
 # the split-precision kernel's own passes (tools/profile_round.sh: tools/split_bench.py under --pmc)
 f3, w3, s3 = pmc("pmc_split3_FETCH_SIZE.csv"), pmc("pmc_split3_WRITE_SIZE.csv"), pmc("pmc_split3_SQ_VALU_MFMA_BUSY_CYCLES.csv")
 for k in f3:
-    if "scores_split3" in k:
+    if "scores_split3" in k or "scores_split2" in k:
+        key = "split3_kernel" if "scores_split3" in k else "split2_kernel"
         rd = 2.0 * 1024 * sum(f3[k]["FETCH_SIZE"]) / len(f3[k]["FETCH_SIZE"])
         wr = 1024 * sum(w3[k]["WRITE_SIZE"]) / len(w3[k]["WRITE_SIZE"]) if w3.get(k, {}).get("WRITE_SIZE") else 0.0
-        out["split3_kernel"] = {"name": k, "read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
+        out[key] = {"name": k, "read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
         if s3.get(k, {}).get("GRBM_GUI_ACTIVE"):
             cyc = sum(s3[k]["GRBM_GUI_ACTIVE"]) / len(s3[k]["GRBM_GUI_ACTIVE"]) / 8.0
             durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                     for r in csv.DictReader(open(os.path.join(src, "pmc_split3_SQ_VALU_MFMA_BUSY_CYCLES.csv")))
                     if short(r["Kernel_Name"]) == k and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
             if durs:
-                out["split3_kernel"].update(sustained_clock_ghz=round(cyc / (sum(durs) / len(durs)), 3),
+                out[key].update(sustained_clock_ghz=round(cyc / (sum(durs) / len(durs)), 3),
                                             ms_in_the_counter_pass=round(sum(durs) / len(durs) / 1e6, 4),
                                             mfma_pipe_busy=round(sum(s3[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(s3[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024 / cyc, 4),
                                             counters={n: sum(v) / len(v) for n, v in s3[k].items()})
