@@ -36,6 +36,7 @@
 namespace mdx {
 
 struct DirectSplit3 {                   // fp32 shard, three bf16 pieces per operand, six products (mdx_scores_split_kernel.h)
+    static constexpr bool TWO_ACC = false;
     static constexpr int TK = 2;        // KiB of shard per row tile and chunk of 32 k: the fp32 tiles (rt, 2c), (rt, 2c+1)
     static constexpr int NQP = 3;       // query piece arrays
     struct Db { u32x4 h, m, l; };
@@ -51,7 +52,18 @@ struct DirectSplit3 {                   // fp32 shard, three bf16 pieces per ope
     }
 };
 
+struct DirectSplit2 {                   // fp32 shard, MDX_F32_SPLIT2: two fp16 pieces (scale 2^17 for unit-norm rows: timing harness), three products
+    static constexpr int TK = 2;
+    static constexpr int NQP = 2;
+    static constexpr bool TWO_ACC = true;
+    struct Db { u32x4 h, m; };
+    static __device__ __forceinline__ void prepare(const f32x4 (&raw)[TK], Db &d) { split2(raw[0], raw[1], 131072.0f, d.h, d.m); }
+    static __device__ __forceinline__ f32x4 mma(const u32x4 (&q)[NQP], const Db &d, f32x4 a) { return mfma_f16(q[0], d.h, a); }
+    static __device__ __forceinline__ f32x4 mmx(const u32x4 (&q)[NQP], const Db &d, f32x4 a) { return mfma_f16(q[0], d.m, mfma_f16(q[1], d.h, a)); }
+};
+
 struct DirectF16 {                      // fp16 shard (MDX_F16): one v_mfma_f32_16x16x32_f16 per tile pair
+    static constexpr bool TWO_ACC = false;
     static constexpr int TK = 1;
     static constexpr int NQP = 1;
     struct Db { f32x4 v; };
@@ -113,11 +125,15 @@ __global__ __launch_bounds__(CW * 64, WGS) void scores_direct_kernel(const f32x4
     };
 
     // ----------------------------------------------------------------- consumer
-    f32x4 acc[R][QT];
+    constexpr bool TWO = MM::TWO_ACC;
+    f32x4 acc[R][QT], acx[TWO ? R : 1][TWO ? QT : 1];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int q = 0; q < QT; ++q) acc[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < QT; ++q) {
+            acc[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (TWO) acx[r][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
     const f32x4 *dbp[R];
 #pragma unroll
@@ -193,7 +209,10 @@ __global__ __launch_bounds__(CW * 64, WGS) void scores_direct_kernel(const f32x4
 #pragma unroll
                     for (int p = 0; p < NQP; ++p) qp[p] = qs[((j * NQP + p) * QT + q) * 64];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r][q] = MM::mma(qp, dcur[r], acc[r][q]);
+                    for (int r = 0; r < R; ++r) {
+                        acc[r][q] = MM::mma(qp, dcur[r], acc[r][q]);
+                        if constexpr (TWO) acx[r][q] = MM::mmx(qp, dcur[r], acx[r][q]);      // split2: 1.54 ms against 1.55 for the ring kernel: parked too
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(CW * 64, WGS) void scores_direct_kernel(const f32x4
             for (int q = 0; q < QT; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    stage[(q * 16 + qrow + i) * LDW + (wave * R + r) * TILE_ROWS + col] = acc[r][q][i];
+                    stage[(q * 16 + qrow + i) * LDW + (wave * R + r) * TILE_ROWS + col] = TWO ? acc[r][q][i] + acx[r][q][i] * (1.0f / 2048.0f) : acc[r][q][i];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -124,6 +124,31 @@ int main(int argc, char **argv)
         if (e != hipSuccess) printf("launch error: %s\n", hipGetErrorString(e));
         return ms / 10;
     };
+    if (getenv("SPLIT2")) {         // the two-piece mode: ring (shipped) against the register-streaming form
+        uint32_t *cell; hipMalloc(&cell, 256);
+        { float one = 0.02f; uint32_t bits; memcpy(&bits, &one, 4); hipMemcpy(cell, &bits, 4, hipMemcpyHostToDevice); }
+        auto ring2 = [&](auto kern, int R_, int CW_) {
+            const size_t lds = (size_t)3 * (2 * 5 + 2 * CW_ * R_) * 1024;
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const int64_t blocks = (RT + CW_ * R_ - 1) / (CW_ * R_);
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64 + 256), lds, 0, db, qp, out, n, KB, QTT, 0, NQ, 131072.0f, (const uint32_t *)cell);
+            hipEventRecord(a);
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(CW_ * 64 + 256), lds, 0, db, qp, out, n, KB, QTT, 0, NQ, 131072.0f, (const uint32_t *)cell);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            return ms / 10;
+        };
+        for (int rep = 0; rep < 3; ++rep) {
+            printf("split2  ring CW8 R2 NST3 (shipped) %.4f | direct CW8 R2 x1 %.4f | direct CW4 R2 x2 %.4f | direct CW8 R1 x1 %.4f ms\n",
+                   ring2(scores_split2_kernel<5, 2, 3, 8>, 2, 8),
+                   direct(scores_direct_kernel<5, 2, 8, DirectSplit2>, direct_lds_bytes<5, 2, 8, DirectSplit2>(), 2, 8),
+                   direct(scores_direct_kernel<5, 2, 4, DirectSplit2, 0, 2>, direct_lds_bytes<5, 2, 4, DirectSplit2>(), 2, 4),
+                   direct(scores_direct_kernel<5, 1, 8, DirectSplit2>, direct_lds_bytes<5, 1, 8, DirectSplit2>(), 1, 8));
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (getenv("XCD")) {            // row-block order: plain (block = workgroup id) against XCD-contiguous, alternating in one process
         for (int rep = 0; rep < 6; ++rep) {
             const int flag = rep & 1;
