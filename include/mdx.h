@@ -13,7 +13,8 @@
  *    nothing persistent except inside an mdx_index (explicit create/destroy).
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
  *    only enqueue work and do not synchronise the device, with two exceptions:
- *    mdx_index_create / _ex / _destroy allocate / free, and creation also waits for a
+ *    mdx_index_create / _ex / _destroy allocate / free (creating an fp32 shard also waits
+ *    for its build: see there), and creation also waits for a
  *    one-off probe kernel (a few hundred microseconds per device and process) that
  *    settles how the sort ranks inside a wave; a process that ranks WITHOUT ever
  *    creating an index runs that probe in its first mdx_rank_* / mdx_topk call instead
@@ -219,8 +220,10 @@ typedef struct mdx_index mdx_index;
 /* Build a shard from n descriptors of dimension d.  `src` is a DEVICE pointer in
  * the given layout.  `row_offset` is the global id of the shard's first row
  * (added to ids by nothing here -- kept for the caller, see mdx_index_info).
- * Allocates n_pad*d_pad*4 bytes of device memory.  Synchronises `stream` only
- * if the build fails. */
+ * Allocates n_pad*d_pad*4 bytes of device memory.  An fp32 shard's creation waits for
+ * the build on `stream` (the shard's largest magnitude -- the block exponent of
+ * MDX_F32_SPLIT2 -- is reduced inside the re-tiling pass and read back here, once);
+ * an fp16 shard's only if the build fails. */
 int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
                      int64_t row_offset, void *stream);
 /* Same with an explicit storage type (mdx_storage).  `src` is fp32 in both cases. */
