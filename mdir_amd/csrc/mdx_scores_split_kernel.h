@@ -63,7 +63,10 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &a, const u32x4 &b, const
 // 2^-20 |X|.  A product is hh + (hm + mh) / 2^11 -- three MFMAs instead of six; the cross terms go to an accumulator of their
 // own, which is scaled once at the end; the dropped mm / 2^22 is <= 2^-20 of the product.  What this costs against the
 // three-piece form: elements more than 2^-27 below the matrix' largest lose relative precision (they are subnormal in
-// fp16 after scaling) -- the error bound is relative to max|x| max|q|, not to each element.
+// fp16 after scaling) -- the error bound is relative to max|x| max|q|, not to each element.  Truncation (not rounding to
+// nearest: v_cvt_pkrtz_f16_f32 packs two values in one instruction) leaves every operand short by up to 2^-20 of itself, so a
+// score comes out short by up to 2^-19 of ITSELF: a bias proportional to the score, neutral for a ranking; the random part
+// is an order of magnitude smaller.
 typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split2(const f32x4 &x0, const f32x4 &x1, float scale, u32x4 &h, u32x4 &m)

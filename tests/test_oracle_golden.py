@@ -476,3 +476,47 @@ def test_clahe_restatement_properties():
     assert len(np.unique(O.clahe_apply(const, lc, tc))) == 1                       # every tile has the same LUT
     out, _ = O.apply_clahe_rgb(rng.integers(0, 256, (37, 53, 3), dtype=np.uint8))
     assert out.dtype == np.float32 and out.min() >= 0 and out.max() <= 1
+
+
+def test_split_precision_restatements():
+    """The oracle's restatements of the two labelled split-precision modes (MDX_F32_SPLIT3: three bf16 pieces; MDX_F32_SPLIT2:
+    block floating point, two fp16 pieces) -- what the GPU tests compare the kernels with: the pieces are representable in
+    their formats, reconstruct the operand to the stated bounds, and the scores sit inside the modes' error bounds against
+    the float64 product."""
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal(20000) * np.exp(rng.uniform(-30, 30, 20000))).astype(np.float32)
+    x[:3] = [0.0, -0.0, np.float32(1.17549435e-38)]
+    h, m, l = O.split3_bf16(x)
+    for piece in (h, m, l):                                     # a bf16 value: the low 16 bits of the fp32 pattern are zero
+        assert (piece.view(np.uint32) & 0xFFFF == 0).all()
+    rec = h.astype(np.float64) + m + l
+    ok = np.abs(x) > 1e-30                                      # (pieces of denormal-sized residuals flush; not the path's data)
+    assert (np.abs(x[ok] - rec[ok]) <= np.abs(x[ok]) * 2.0 ** -24).all()
+    # bf16 rounding is to nearest even: against the definition on a few hand cases
+    hand = np.array([1.0, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -7, 1.0 + 3 * 2.0 ** -8, -3.1415927], np.float32)
+    np.testing.assert_array_equal(O.bf16_round(hand), np.array([1.0, 1.0, 1.0 + 2.0 ** -7, 1.0 + 2.0 ** -6, -3.140625], np.float32))
+
+    # fp16 toward zero: equal to numpy's float16 wherever that conversion is exact or rounds down in magnitude
+    v = np.concatenate([rng.standard_normal(5000) * 100, rng.standard_normal(5000) * 1e-5, [0.0, 65504.0, 6.1035e-05, 5.96e-08]])
+    t = O._fp16_toward_zero(v)
+    assert (np.abs(t) <= np.abs(v)).all() and (np.sign(t) * np.sign(v) >= 0).all()
+    assert (t.astype(np.float16).astype(np.float64) == t).all()             # representable in fp16
+    ulp = np.where(np.abs(v) >= 2.0 ** -14, np.exp2(np.floor(np.log2(np.maximum(np.abs(v), 1e-300))) - 10), 2.0 ** -24)
+    assert (np.abs(v - t) < ulp).all()
+    for a in (np.array([0.02, -0.7]), np.array([1e-20, 3e-21]), np.array([5e20]), np.zeros(4)):
+        s = O.split2_scale(a.astype(np.float32))
+        top = np.abs(a).max()
+        assert s == 1.0 if top == 0 else (np.log2(s) == np.round(np.log2(s)) and 2.0 ** 13 <= top * s < 2.0 ** 14)
+
+    vecs, qvecs, _ = O.synth_ranking_problem(3000, 40, 512, seed=5)
+    exact = vecs.astype(np.float64).T @ qvecs.astype(np.float64)
+    assert np.abs(O.scores_split3(vecs, qvecs) - exact).max() < 6e-8        # 2^-23 of the products + the final fp32 rounding
+    # split2 truncates toward zero twice per operand: every piece sum falls short of its operand by up to 2^-20 of it, so a
+    # score falls short by up to 2^-19 of itself -- a bias proportional to the score (it shrinks all scores alike: neutral
+    # for a ranking) -- plus a far smaller random part
+    s2 = O.scores_split2(vecs, qvecs)
+    assert (np.abs(s2 - exact) <= 2.0 ** -19 * np.abs(exact) + 5e-8).all()
+    assert np.abs(s2 - exact).max() < 1e-6
+    # block exponents are exact: other powers of two in, the same scores times that power out
+    np.testing.assert_array_equal(O.scores_split2(vecs * np.float32(2.0 ** 9), qvecs * np.float32(2.0 ** -20)),
+                                  O.scores_split2(vecs, qvecs) * np.float32(2.0 ** -11))
