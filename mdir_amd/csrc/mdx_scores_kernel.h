@@ -48,6 +48,18 @@ __device__ __forceinline__ int64_t row_block_of(unsigned id, unsigned nblocks)
 #endif
 }
 
+// A score leaves the kernel once and is next read by another kernel (the ranking).  NT: a non-temporal store, which does
+// not allocate in the caches on its way out.  Measured (tools/split_ablate.hip, -DMDX_EPI_NT=0/1, several processes each): the
+// HBM-bound split-precision ring kernel 1.60-1.64 -> 1.39-1.46 ms with it -- its query pieces are re-read from the L2 by every
+// workgroup, and 281 MB of output passing through the same caches pushes them out; the power-bound three-piece form, the exact
+// chain (MFMA-bound) and the fp16 kernels: no change or 1 % worse.  So only the split kernels ask for it.
+template <bool NT>
+__device__ __forceinline__ void store_score(float *p, float v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // Element type of a shard.  A tile is always 64 lanes x 16 B; what the 16 bytes are and which
 // MFMA consumes them is the only difference between the fp32 (exact chain) and the fp16
 // (BASELINE.json configs[4]: "fp16 descriptors on CDNA4 fp16 MFMA") paths.
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     const int nq_here = (nq_valid - (int)blockIdx.y * QT * TILE_ROWS) < QCAP ? (nq_valid - (int)blockIdx.y * QT * TILE_ROWS) : QCAP;
     for (int e = tid; e < nq_here * ROWS; e += CW * 64) {
         const int qi = e / ROWS, rr = e % ROWS;
-        if (rr < rows_valid) out[(int64_t)qi * n + row0 + rr] = stage[qi * LDW + rr];
+        if (rr < rows_valid) store_score<false>(out + (int64_t)qi * n + row0 + rr, stage[qi * LDW + rr]);
     }
     if (STAMPS && dbg && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

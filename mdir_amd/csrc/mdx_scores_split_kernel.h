@@ -361,7 +361,7 @@ __device__ __forceinline__ void split_kernel_body(f32x4 *ring, const f32x4 *__re
     const int nq_here = left < QT * TILE_ROWS ? left : QT * TILE_ROWS;
     for (int e = tid; e < nq_here * ROWS; e += CW * 64) {
         const int qi = e / ROWS, rr = e % ROWS;
-        if (rr < rows_valid) out[(int64_t)qi * n + row0 + rr] = stage[qi * LDW + rr];
+        if (rr < rows_valid) store_score<true>(out + (int64_t)qi * n + row0 + rr, stage[qi * LDW + rr]);      // non-temporal: see store_score
     }
 }
 

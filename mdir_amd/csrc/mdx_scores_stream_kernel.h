@@ -152,7 +152,7 @@ __global__ __launch_bounds__(STREAM_CW * 64, WGS) void scores_f16_stream_kernel(
     const int nq_here = left < QT * TILE_ROWS ? left : QT * TILE_ROWS;
     for (int e = tid; e < nq_here * ROWS; e += CW * 64) {
         const int qi = e / ROWS, rr = e % ROWS;
-        if (rr < rows_valid) out[(int64_t)qi * n + row0 + rr] = stage[qi * LDW + rr];
+        if (rr < rows_valid) store_score<false>(out + (int64_t)qi * n + row0 + rr, stage[qi * LDW + rr]);
     }
 }
 
