@@ -273,7 +273,7 @@ int mdx_scores(const mdx_index *index, const float *queries, int64_t nq, int qla
  *                   exactly.  Worst case for unit vectors 2^-20 sum |x_k q_k| <= 1e-6 on top of fp32 accumulation; elements
  *                   more than 2^-27 below their matrix' largest lose relative precision (the bound is relative to
  *                   max|x| max|q|, not to each element -- use MDX_F32_SPLIT3 for wide-range data).  Half the matrix work of
- *                   SPLIT3: the kernel runs at its stream's speed (measured 1.65 ms against 1.97 and 2.62 for the exact chain). */
+ *                   SPLIT3: the kernel runs at its stream's speed (measured 1.4-1.55 ms against 1.92-2.1 and 2.6 for the exact chain). */
 typedef enum mdx_compute { MDX_F32_CHAIN = 0, MDX_F32_SPLIT3 = 1, MDX_F32_SPLIT2 = 2 } mdx_compute;
 
 /* mdx_scores with an explicit compute mode; workspace of at least mdx_scores_workspace_ex(nq, d, compute) bytes
