@@ -12,6 +12,10 @@
 
 #include "mdx_common.h"
 
+#ifndef MDX_SORT_NT
+#define MDX_SORT_NT 1     // the final ranking is stored non-temporally (0.859 -> 0.846 ms at 70 x 1 M; -DMDX_SORT_NT=0: plain)
+#endif
+
 namespace mdx {
 
 #ifndef MDX_SORT_ITEMS
@@ -433,8 +437,13 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
             const int64_t dst = (int64_t)dst32;
             if (dst < klimit) {
                 if (ranks) {
-                    if (OFF32) *(int64_t *)((char *)(ranks + q * klimit) + (dst32 << 3)) = (int64_t)v + id_offset;
-                    else ranks[q * klimit + dst] = (int64_t)v + id_offset;
+                    // the ranking leaves the sort here and is not read by it again: a non-temporal store (MDX_SORT_NT)
+                    int64_t *dstp = OFF32 ? (int64_t *)((char *)(ranks + q * klimit) + (dst32 << 3)) : ranks + q * klimit + dst;
+#if MDX_SORT_NT
+                    __builtin_nontemporal_store((int64_t)v + id_offset, dstp);
+#else
+                    *dstp = (int64_t)v + id_offset;
+#endif
                 }
                 if (top_scores) top_scores[q * klimit + dst] = scores[base + v];
             }
@@ -442,6 +451,8 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
             w_out[row + (int64_t)dst32] = k;
             ((uint32_t *)h_out)[row + (int64_t)dst32] = v;
         } else {
+            // (plain stores: the intermediates are written as partial lines that neighbouring tiles complete in the L2;
+            // non-temporal stores here cost 2.2x -- 1.88 ms against 0.85)
             *(uint32_t *)(wrow + (dst32 << 2)) = (k & 0xFF000000u) | v;
             if (OUT == FMT_A) *(uint16_t *)(hrow + (dst32 << 1)) = (uint16_t)(k >> 8);
             if (OUT == FMT_B) *(uint8_t *)(hrow + dst32) = (uint8_t)(k >> 16);
