@@ -261,8 +261,10 @@ int mdx_scores(const mdx_index *index, const float *queries, int64_t nq, int qla
  *                   hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- dropped terms
  *                   <= 2^-23 of a product, below fp32's own rounding.  6/16 of the fp32 MFMA time: the kernel is bound
  *                   by the shard stream (HBM) instead of the matrix pipe.  NOT bit-equal to the chain: the accumulation
- *                   order differs (measured ~1e-7 on unit-norm descriptors; tests/test_gpu_round4.py bounds it by 2e-6,
- *                   the summation-order bound bench.py holds the reference's own BLAS path to).  fp32 range (bf16 has
+ *                   order differs (measured 8e-7 at most over the 70 M scores of the headline workload; tests/test_gpu_round4.py
+ *                   bounds it by 2e-6 -- the summation-order bound bench.py holds the reference's own BLAS path to -- for
+ *                   scores up to ~0.5 and by 1e-6 + 4e-6 |s| in general: at a self-match, s = 1, ANY fp32 evaluation of a
+ *                   2048-term dot product is ~2e-6 from the exact value, the chain included).  fp32 range (bf16 has
  *                   fp32's exponent); an infinite operand gives NaN.
  *   MDX_F32_SPLIT2  a second labelled mode, for when the matrix' dynamic range is ordinary (L2-normalised descriptors: the path's
  *                   own data).  Block floating point: each matrix is scaled by a power of two that brings its largest magnitude

@@ -470,3 +470,30 @@ def test_split3_from_the_scenario_surface_and_under_graph_capture(tmp_path):
     torch.cuda.synchronize()
     assert torch.equal(sc, want_sc) and torch.equal(rk, want_rk)
     assert float((sc - ix.scores(q, "ND")).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("d", [512, 2048])
+def test_split_modes_on_self_matches_and_non_negative_descriptors(d):
+    """query == database (the 247tokyo1k shape; cirscore.py:56-57) puts scores of exactly 1 on the diagonal -- where every fp32
+    evaluation of a d-term dot product is at its worst: the k-ordered chain itself is ~sqrt(d) 2^-24 |s| = 1-2.4e-6 from the
+    float64 product there.  Stated and held here: |split - chain| <= 1e-6 + 4e-6 |s| (2e-6 for everything but near-duplicates);
+    against float64 split2 is not worse than the chain (its long accumulation runs over 64 chunk sums, not 2048 terms), split3
+    within twice the chain's error; non-negative descriptors (GeM outputs before whitening: no sign cancellation) included."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(d)
+    db = rng.standard_normal((1125, d)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    pos = np.abs(db)
+    pos = (pos / np.linalg.norm(pos, axis=1, keepdims=True)).astype(np.float32)
+    for m in (db, pos):
+        ix = ops.DescriptorIndex(dev(m), "ND")
+        q = m[:200].copy()
+        chain = OC.scores_chain(np.ascontiguousarray(m.T), np.ascontiguousarray(q.T))
+        exact = q.astype(np.float64) @ m.astype(np.float64).T
+        err_chain = np.abs(chain - exact).max()
+        for mode, slack in (("split3", 2.0), ("split2", 1.0)):
+            got = ix.scores(dev(q), "ND", compute=mode).cpu().numpy()
+            assert (np.abs(got - chain) <= 1e-6 + 4e-6 * np.abs(exact)).all(), (mode, float((np.abs(got - chain) - 4e-6 * np.abs(exact)).max()))
+            assert np.abs(got - exact).max() <= slack * err_chain + 2e-7, (mode, np.abs(got - exact).max(), err_chain)
+            # every row still retrieves itself first (a self-match is 1 up to ~2e-6, everything else is far below)
+            assert (got[:, :].argmax(axis=1) == np.arange(200)).all()
