@@ -350,9 +350,9 @@ int mdx_rank_count(const float *scores, int64_t n, int64_t nq, int64_t id_offset
  * = `np.dot(Xc, Xc.T)` with `Xc = X - m` (whiten.py:21-22), `np.dot(df, df.T)` (whiten.py:42 and :46).  Only the
  * tiles on or above the diagonal are computed and each is stored twice: the result is exactly symmetric.  workspace:
  * mdx_gram_f64_workspace(d, n) bytes of device scratch -- the centred input transposed to [n, d] (both operands of the GEMM
- * are then read in 512-byte runs), then the partial results of up to 16 K ranges, which are added in range order: a fixed
- * summation order, whatever the schedule.  That is 8 * (n_pad * d_pad + 16 * d_pad^2) bytes: ~0.87 GB at d = 2048,
- * n = 20 000 (0.33 GB of transposed input + 0.54 GB of partials) -- size the scratch from the function, not by guess. */
+ * are then read in 1-KiB runs), then the partial results of up to 16 K ranges, which are added in range order: a fixed
+ * summation order, whatever the schedule.  That is at most 8 * (n_pad * d_pad + 16 * d^2) bytes: 0.84 GB at d = 2048,
+ * n = 20 000 (0.33 GB of transposed input + 0.50 GB for 15 ranges) -- size the scratch from the function, not by guess. */
 int64_t mdx_gram_f64_workspace(int64_t d, int64_t n);
 int mdx_gram_f64(const double *a, int64_t d, int64_t n, const double *center, double *out, void *workspace,
                  int64_t workspace_bytes, void *stream);
@@ -360,7 +360,8 @@ int mdx_gram_f64(const double *a, int64_t d, int64_t n, const double *center, do
 /* Projection of centred descriptors:
  *   p [dout, d] row-major, x [d, n] row-major, center [d] or NULL  ->  out [dout, n] = p . (x - center)
  * = `df = np.dot(P, X-m)` (whiten.py:45).  workspace: mdx_project_f64_workspace(dout, d) bytes of device scratch (p
- * transposed, so that both operands are read in 512-byte runs). */
+ * transposed, so that both operands are read in 1-KiB runs).  An odd n costs one more short launch (the large-tile kernel
+ * moves column pairs). */
 int64_t mdx_project_f64_workspace(int64_t dout, int64_t d);
 int mdx_project_f64(const double *p, int64_t dout, int64_t d, const double *x, int64_t n, const double *center,
                     double *out, void *workspace, int64_t workspace_bytes, void *stream);

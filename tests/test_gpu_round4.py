@@ -497,3 +497,38 @@ def test_split_modes_on_self_matches_and_non_negative_descriptors(d):
             assert np.abs(got - exact).max() <= slack * err_chain + 2e-7, (mode, np.abs(got - exact).max(), err_chain)
             # every row still retrieves itself first (a self-match is 1 up to ~2e-6, everything else is far below)
             assert (got[:, :].argmax(axis=1) == np.arange(200)).all()
+
+
+# ---------------------------------------------------------------- f3: the loader/consumer f64 GEMM (128 x 128 tiles of large problems)
+
+@pytest.mark.parametrize("d,n", [(1024, 4096), (1100, 3001), (2048, 5000), (1030, 17), (2048, 20000)])
+def test_gram_f64_large_tiles_vs_numpy(d, n):
+    """mdx_gram_f64 where it takes the loader/consumer kernel (d >= 1024): tile edges (d not a multiple of 128), a K range
+    that is not a multiple of the 16-k stage (zero rows of the transposed copy), K ranges + the ordered reduction, fewer k
+    than one ring of stages; np.dot(Xc, Xc.T) of whiten.py:22 with the centring fused."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(d + n)
+    A = rng.standard_normal((d, n))
+    m = A.mean(axis=1)
+    Ac = A - m[:, None]
+    scale = np.sqrt(np.outer((A * A).sum(1), (A * A).sum(1)))
+    got = ops.gram_f64(dev(A)).cpu().numpy()
+    assert np.max(np.abs(got - A @ A.T) / scale) < 1e-13
+    np.testing.assert_array_equal(got, got.T)
+    got_c = ops.gram_f64(dev(A), dev(m)).cpu().numpy()
+    assert np.max(np.abs(got_c - Ac @ Ac.T) / (np.sqrt(np.outer((Ac * Ac).sum(1), (Ac * Ac).sum(1))) + 1e-300)) < 1e-13
+
+
+@pytest.mark.parametrize("dout,d,n", [(1024, 1024, 1024), (1100, 1030, 1025), (1024, 2048, 4097), (2048, 16, 1500), (2048, 2048, 20000)])
+def test_project_f64_large_tiles_vs_numpy(dout, d, n):
+    """mdx_project_f64 where it takes the loader/consumer kernel (dout, n >= 1024): an odd n (rows of X at 8-byte alignment
+    only, a last column tile of one column), dout and d off the tile and stage sizes, one stage of k; with and without the
+    centring of whiten.py:45 (applied by the consumer waves on the operand)."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(dout + d + n)
+    P, X, m = rng.standard_normal((dout, d)), rng.standard_normal((d, n)), rng.standard_normal(d)
+    got = ops.project_f64(dev(P), dev(X), dev(m)).cpu().numpy()
+    bound = np.sqrt((P * P).sum(1))[:, None] * np.sqrt(((X - m[:, None]) ** 2).sum(0))[None, :]
+    assert np.max(np.abs(got - P @ (X - m[:, None])) / bound) < 1e-13
+    got0 = ops.project_f64(dev(P), dev(X)).cpu().numpy()
+    assert np.max(np.abs(got0 - P @ X) / (np.sqrt((P * P).sum(1))[:, None] * np.sqrt((X * X).sum(0))[None, :])) < 1e-13
