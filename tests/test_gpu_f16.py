@@ -56,12 +56,14 @@ def test_f16_whitening_projection():
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
 
 
-def test_configs4_end_to_end_vgg16_multiscale_whitening_fp16(tmp_path):
+@pytest.mark.parametrize("n_images", [90, 1125])
+def test_configs4_end_to_end_vgg16_multiscale_whitening_fp16(tmp_path, n_images):
     """BASELINE.json configs[4] through the product's scenario surface: VGG16-GeM (random init), 3 scales + learned
     whitening (learned here from the set's descriptors; the cirwhiten / cirmultiscale wrapper chain), a 247tokyo1k-shaped set (query == database, the image
     itself in `junk`: cirscore.py:56-57), descriptors kept as fp16 (`criterion: {storage: f16}`, scenarios/eval_fp16.yml)
     against the fp32 shard.  Stated bounds: |mAP(fp16) - mAP(fp32)| <= 0.005; the two top-10 lists name the same ids in
-    >= 97 % of the slots; every fp16 score within 2e-3 of the fp32 one."""
+    >= 97 % of the slots; every fp16 score within 2e-3 of the fp32 one.  n_images = 1125: the real set's size (N = Q = 1125,
+    D = 512: the shape of the bench line's `configs4_247tokyo1k_shape` leg, here with extracted descriptors)."""
     import json
     import os
     import subprocess
@@ -74,7 +76,7 @@ def test_configs4_end_to_end_vgg16_multiscale_whitening_fp16(tmp_path):
     from mdir_amd.networks import extract_vectors_device
     from mdir_amd.scenario import dict_deep_overlay
     root = str(tmp_path / "synth")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_eval.py"), root, "vgg16", "90"])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_eval.py"), root, "vgg16", str(n_images)])
     os.environ["CIRTORCH_ROOT"] = root
     os.environ["MDIR_AMD_WORKERS"] = "2"
 
@@ -111,7 +113,7 @@ def test_configs4_end_to_end_vgg16_multiscale_whitening_fp16(tmp_path):
     net = load_network(sc["network"], torch.device(DEV)).eval()
     with torch.no_grad():
         vecs = extract_vectors_device(net, images, 320, tr, device=torch.device(DEV))       # [N, 512]
-    assert vecs.shape == (90, 512)
+    assert vecs.shape == (n_images, 512)
     s32 = ops.DescriptorIndex(vecs, "ND").scores(vecs, "ND")
     s16 = ops.DescriptorIndex(vecs, "ND", storage="f16").scores(vecs, "ND")
     worst = float((s32 - s16).abs().max())
@@ -121,7 +123,7 @@ def test_configs4_end_to_end_vgg16_multiscale_whitening_fp16(tmp_path):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         json.dump({"map_fp32": map32, "map_fp16": map16, "max_abs_score_diff": worst, "top10_slot_agreement": agree},
-                  open(os.path.join(out, "configs4_measured.json"), "w"))
+                  open(os.path.join(out, "configs4_measured_%d.json" % n_images), "w"))
     assert 0.05 < map32 < 0.999, map32                                   # a non-trivial retrieval problem
     assert abs(map16 - map32) <= 0.005, (map16, map32)
     assert worst <= 2e-3, worst
