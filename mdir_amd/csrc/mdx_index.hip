@@ -20,8 +20,6 @@
 
 namespace mdx {
 
-constexpr int WAVES = 4;        // waves (= tiles) per workgroup of the re-tiling kernels
-
 static thread_local char g_err[512] = "";
 
 void set_error(const char *fmt, ...)
@@ -32,80 +30,107 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-// fp16 variant of the re-tiling: tile = 16 rows x 32 k, lane (g,j) holds (row j, k 32kb+8g+e), e = 0..7,
-// converted from the fp32 source with round-to-nearest-even.
-__global__ __launch_bounds__(256) void retile_f16_kernel(const float *__restrict__ src, int64_t rs,
-                                                         int64_t ks, int64_t n, int64_t d,
-                                                         const float *__restrict__ center,
-                                                         f32x4 *__restrict__ tiles, int64_t RT,
-                                                         int64_t KB, int kb_fast)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-    if (tile >= RT * KB) return;
-    int64_t rt, kb;
-    if (kb_fast) { rt = tile / KB; kb = tile % KB; }
-    else         { kb = tile / RT; rt = tile % RT; }
-    const int j = lane & 15, g = lane >> 4;
-    const int64_t row = rt * TILE_ROWS + j;
-    f16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int64_t k = kb * 32 + 8 * g + e;
-        float x = 0.0f;
-        if (row < n && k < d) {
-            x = src[row * rs + k * ks];
-            if (center) x -= center[k];
-        }
-        v[e] = (_Float16)x;
-    }
-    tiles[(rt * KB + kb) * 64 + lane] = __builtin_bit_cast(f32x4, v);
-}
+// ---------------------------------------------------------------------------
+// Re-tiling: an fp32 matrix [rows, k] in either layout of the API -> fragment-order tiles (the index build, the queries
+// of every call, the whitening matrix).  Rows >= n and k >= d read 0; `center[k]` (or nothing) is subtracted on the way.
+//   fp32 tile = 16 rows x 16 k: lane (g, j), element t = (row j, k 16 kb + 4 t + g)
+//   fp16 tile = 16 rows x 32 k: lane (g, j), element e = (row j, k 32 kb + 8 g + e), round-to-nearest-even
+// Round 1-3 let every lane fetch its own elements from the source: a wave-load was 16 pieces of 16 B (row-major sources)
+// or 4 pieces of 64 B (dimension-major) -- the build of the 8.2 GB shard ran at 0.86 TB/s read + write (19 ms; rocprofv3,
+// profiles/r04_summary.md).  Here a workgroup reads a block of the source in whole 1-KiB runs (64 lanes x 16 B along the
+// contiguous direction), parks it in LDS and every wave assembles tiles from there; the row stride of the LDS block makes the
+// 64 lanes of an assembling read hit 64 different banks.  The tiles leave as before, one coalesced KiB per wave-store.
+//   ROWMAJOR  (element (row, k) at src[row * d + k]):  block = 16 rows x 256 k
+//   otherwise (element (row, k) at src[k * n + row]):  block = 16 (fp16: 32) k x 256 rows
+// ---------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // a 16-byte load at dword alignment (any n, d)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// ---------------------------------------------------------------------------
-// re-tiling: any strided [rows, k] fp32 matrix -> fragment-order tiles
-//   element (row, k) is read from src[row*rs + k*ks]; rows >= n and k >= d read 0.
-//   kb_fast != 0 : consecutive waves take consecutive kb of one row tile
-//                  (row-major sources: 256 contiguous bytes per row and workgroup)
-//   kb_fast == 0 : consecutive waves take consecutive row tiles of one kb
-//                  (dimension-major sources: 256 contiguous bytes per k)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void retile_kernel(const float *__restrict__ src, int64_t rs,
-                                                     int64_t ks, int64_t n, int64_t d,
-                                                     const float *__restrict__ center,
-                                                     f32x4 *__restrict__ tiles, int64_t RT,
-                                                     int64_t KB, int kb_fast, uint32_t *__restrict__ absmax)
+template <bool F16, bool ROWMAJOR>
+__global__ __launch_bounds__(256) void retile_block_kernel(const float *__restrict__ src, int64_t n, int64_t d, const float *__restrict__ center,
+                                                           f32x4 *__restrict__ tiles, int64_t RT, int64_t KB, uint32_t *__restrict__ absmax,
+                                                           unsigned inner)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-    if (tile >= RT * KB) return;
-    int64_t rt, kb;
-    if (kb_fast) { rt = tile / KB; kb = tile % KB; }
-    else         { kb = tile / RT; rt = tile % RT; }
+    // block id -> (bx, by) = (row tile, k span) or (row span, k block); the index that walks ALONG the source's contiguous
+    // direction is the fast one: consecutive blocks read adjacent KiB of the same lines
+    const unsigned bx = ROWMAJOR ? blockIdx.x / inner : blockIdx.x % inner, by = ROWMAJOR ? blockIdx.x % inner : blockIdx.x / inner;
+    constexpr int TK = F16 ? 32 : 16;                       // k per tile
+    constexpr int LINES = ROWMAJOR ? 16 : TK;               // 1-KiB runs of the source per block: rows, or k rows
+    constexpr int LD = ROWMAJOR ? 260 : (F16 ? 258 : 272);  // floats per line in LDS (bank spread of the assembling reads)
+    __shared__ __attribute__((aligned(16))) float blk[LINES * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int64_t row = rt * TILE_ROWS + j;
-    f32x4 v;
     uint32_t best = 0;
+    // ---- the block, in runs of 1 KiB: line `l`, floats 4 * lane .. 4 * lane + 3
+    const int64_t line0 = ROWMAJOR ? (int64_t)bx * 16 : (int64_t)by * TK;      // first row / first k
+    const int64_t col0 = (ROWMAJOR ? (int64_t)by : (int64_t)bx) * 256 + 4 * lane;   // first k / first row of this lane
+    const int64_t nlines = ROWMAJOR ? n : d, ncols = ROWMAJOR ? d : n;
+    const int64_t ld_src = ncols;
+    float cen[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ROWMAJOR && center) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int64_t k = kb * TILE_K + 4 * t + g;
-        float x = 0.0f;
-        if (row < n && k < d) {
-            x = src[row * rs + k * ks];
-            if (center) x -= center[k];
-        }
-        v[t] = x;
-        const uint32_t u = __float_as_uint(x) & 0x7FFFFFFFu;
-        if (u < 0x7F800000u && u > best) best = u;
+        for (int e = 0; e < 4; ++e) cen[e] = col0 + e < d ? center[col0 + e] : 0.f;
     }
-    tiles[(rt * KB + kb) * 64 + lane] = v;
+#pragma unroll
+    for (int i = 0; i < LINES / 4; ++i) {
+        const int l = wave * (LINES / 4) + i;
+        const int64_t line = line0 + l;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (line < nlines) {
+            const float *p = src + line * ld_src + col0;
+            if (col0 + 3 < ncols) {
+                const f32x4u v = *(const f32x4u *)p;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = col0 + e < ncols ? p[e] : 0.f;
+            }
+            if (center) {
+                const float ck = ROWMAJOR ? 0.f : center[line];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col0 + e < ncols) x[e] -= ROWMAJOR ? cen[e] : ck;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t u = __float_as_uint(x[e]) & 0x7FFFFFFFu;
+            if (u < 0x7F800000u && u > best) best = u;
+        }
+        *(f32x2 *)&blk[l * LD + 4 * lane] = (f32x2){x[0], x[1]};
+        *(f32x2 *)&blk[l * LD + 4 * lane + 2] = (f32x2){x[2], x[3]};
+    }
+    __syncthreads();
+    // ---- tiles: 16 (fp16: 8) of them per block, 4 (2) per wave
+    constexpr int TILES = ROWMAJOR ? 256 / TK : 16;
+#pragma unroll
+    for (int i = 0; i < TILES / 4; ++i) {
+        const int tl = wave * (TILES / 4) + i;                          // tile of the block: along k (ROWMAJOR) or along rows
+        const int64_t rt = ROWMAJOR ? (int64_t)bx : (int64_t)bx * 16 + tl;
+        const int64_t kb = ROWMAJOR ? (int64_t)by * TILES + tl : (int64_t)by;
+        if (rt >= RT || kb >= KB) continue;
+        f32x4 out;
+        if constexpr (F16) {
+            f16x8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)(ROWMAJOR ? blk[j * LD + tl * 32 + 8 * g + e] : blk[(8 * g + e) * LD + tl * 16 + j]);
+            out = __builtin_bit_cast(f32x4, h);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) out[t] = ROWMAJOR ? blk[j * LD + tl * 16 + 4 * t + g] : blk[(4 * t + g) * LD + tl * 16 + j];
+        }
+        tiles[(rt * KB + kb) * 64 + lane] = out;
+    }
     if (absmax) {               // the shard's largest finite magnitude (index build only): the scale of MDX_F32_SPLIT2
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64);
             best = other > best ? other : best;
         }
-        if (lane == 0 && best) atomicMax(absmax, best);
+        // one device-wide atomic per wave would be 2 M of them on ONE address for a 1 M x 2048 shard (~10 ns each: 20 of the
+        // build's 23 ms); a wave first looks at the cell -- a stale, smaller value only costs an atomic that changes nothing
+        if (lane == 0 && best > *(volatile uint32_t *)absmax) atomicMax(absmax, best);
     }
 }
 
@@ -293,16 +318,17 @@ const char *mdx_last_error(void) { return mdx::g_err; }
 static int retile(const float *src, int64_t n, int64_t d, int layout, const float *center,
                   f32x4 *tiles, int64_t RT, int64_t KB, hipStream_t s, int storage = MDX_F32, uint32_t *absmax = nullptr)
 {
-    const int64_t rs = layout == MDX_DIM_MAJOR ? 1 : d;
-    const int64_t ks = layout == MDX_DIM_MAJOR ? n : 1;
-    const int64_t blocks = ceil_div(RT * KB, (int64_t)WAVES);
-    MDX_CHECK_ARG(blocks < (1ll << 31), "matrix too large to re-tile in one launch");
-    if (storage == MDX_F16)
-        hipLaunchKernelGGL(retile_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, rs, ks, n, d,
-                           center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1);
-    else
-        hipLaunchKernelGGL(retile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, rs, ks, n, d,
-                           center, tiles, RT, KB, layout == MDX_DIM_MAJOR ? 0 : 1, absmax);
+    const bool rowmajor = layout != MDX_DIM_MAJOR, f16 = storage == MDX_F16;
+    // blocks: 16 rows x 256 k (row-major) or one k block x 256 rows (dimension-major); the second grid dimension is the short one
+    const int64_t gx = rowmajor ? RT : ceil_div(RT, (int64_t)16);
+    const int64_t gy = rowmajor ? ceil_div(KB * (f16 ? 32 : 16), (int64_t)256) : KB;
+    MDX_CHECK_ARG(gx * gy < (1ll << 31), "matrix too large to re-tile in one launch");
+    const dim3 grid((unsigned)(gx * gy)), block(256);
+    const unsigned inner = (unsigned)(rowmajor ? gy : gx);
+    if (f16 && rowmajor)       hipLaunchKernelGGL((retile_block_kernel<true, true>), grid, block, 0, s, src, n, d, center, tiles, RT, KB, absmax, inner);
+    else if (f16)              hipLaunchKernelGGL((retile_block_kernel<true, false>), grid, block, 0, s, src, n, d, center, tiles, RT, KB, absmax, inner);
+    else if (rowmajor)         hipLaunchKernelGGL((retile_block_kernel<false, true>), grid, block, 0, s, src, n, d, center, tiles, RT, KB, absmax, inner);
+    else                       hipLaunchKernelGGL((retile_block_kernel<false, false>), grid, block, 0, s, src, n, d, center, tiles, RT, KB, absmax, inner);
     MDX_LAUNCH_CHECK();
     return MDX_OK;
 }
