@@ -326,6 +326,14 @@ int mdx_rank_of(const float *scores, int64_t n, int64_t nq, const int64_t *ids,
                 const int64_t *offsets, int64_t total, float *id_scores, int64_t *pos,
                 void *stream);
 
+/* Positions of labelled ids inside a GIVEN ranking (the literal form of evaluate.py:80-81,
+ * `np.arange(N)[np.in1d(ranks[:, q], ids)]`, for every query in one pass):
+ *   pos[t] = p with ranks[q * ld + p] == ids[t], or -1 when the id does not occur among the n entries of row q,
+ * t in [offsets[q], offsets[q+1]).  ranks int64, one row of n ids per query at a stride of ld >= n elements (the
+ * [Q, N] matrix mdx_rank_full writes, or its first columns); ids int64 [total] >= 0, unique within a query. */
+int mdx_rank_positions(const int64_t *ranks, int64_t n, int64_t nq, int64_t ld, const int64_t *ids,
+                       const int64_t *offsets, int64_t total, int64_t *pos, void *stream);
+
 /* Scores of given ids: out[t] = scores[q, ids[t]] for t in the CSR range of q. */
 int mdx_gather_scores(const float *scores, int64_t n, int64_t nq, const int64_t *ids,
                       const int64_t *offsets, int64_t total, float *out, void *stream);

@@ -1484,6 +1484,76 @@ static int topk_sampled(const float *scores, int64_t n, int64_t nq, int64_t k, i
 
 using namespace mdx;
 
+namespace mdx {
+
+// ---------------------------------------------------------------------------
+// Positions of labelled ids INSIDE a given ranking: pos[t] = p with ranks[q][p] == ids[t] (or -1) -- what
+// `np.arange(N)[np.in1d(ranks[:, q], ids)]` (evaluate.py:80-81) yields, for all queries in one pass over the ranking.
+// The host-side form of this (one torch.isin + nonzero + copy per query, protocol level and list) took 72 ms for
+// 70 x 1 M -- twenty times the similarity + ranking kernels it follows (tools/eval_path_bench.py).
+// A workgroup hashes its query's ids (a chunk of up to RP_CHUNK of them) into LDS -- open addressing, the table twice as
+// large as the chunk -- and streams a slice of the ranking row through it with 16-byte loads: HBM-bound, 8 B per element.
+// Ids are non-negative (an entry < 0 is never looked up); of an id listed twice, either entry receives the position
+// and the other stays -1 (the callers pass unique lists).
+// ---------------------------------------------------------------------------
+constexpr int RP_CHUNK = 2048, RP_TABLE = 4096, RP_ROWS_PER_BLOCK = 16384;
+
+__global__ __launch_bounds__(256) void rank_positions_kernel(const int64_t *__restrict__ ranks, int64_t ld, int64_t n,
+                                                             const int64_t *__restrict__ ids, const int64_t *__restrict__ offsets,
+                                                             int64_t *__restrict__ pos)
+{
+    __shared__ int64_t key[RP_TABLE];
+    __shared__ int32_t slot[RP_TABLE];
+    const int q = blockIdx.y;
+    const int64_t lo = offsets[q], hi = offsets[q + 1];
+    const int64_t p0 = (int64_t)blockIdx.x * RP_ROWS_PER_BLOCK, p1 = (p0 + RP_ROWS_PER_BLOCK) < n ? (p0 + RP_ROWS_PER_BLOCK) : n;
+    const int64_t *row = ranks + (int64_t)q * ld;
+    for (int64_t c0 = lo; c0 < hi; c0 += RP_CHUNK) {
+        const int cnt = (int)((hi - c0) < RP_CHUNK ? (hi - c0) : RP_CHUNK);
+        for (int i = threadIdx.x; i < RP_TABLE; i += 256) key[i] = -1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const int64_t id = ids[c0 + i];
+            if (id < 0) continue;
+            uint32_t h = (uint32_t)(((uint64_t)id * 0x9E3779B97F4A7C15ull) >> 52) & (RP_TABLE - 1);
+            while (true) {
+                const unsigned long long old = atomicCAS((unsigned long long *)&key[h], ~0ull, (unsigned long long)id);
+                if (old == ~0ull) { slot[h] = i; break; }
+                if ((int64_t)old == id) break;                                  // listed twice: the first entry keeps the slot
+                h = (h + 1) & (RP_TABLE - 1);
+            }
+        }
+        __syncthreads();
+        auto look = [&](int64_t id, int64_t p) {
+            if (id < 0) return;
+            uint32_t h = (uint32_t)(((uint64_t)id * 0x9E3779B97F4A7C15ull) >> 52) & (RP_TABLE - 1);
+            while (true) {
+                const int64_t k = key[h];
+                if (k == id) { pos[c0 + slot[h]] = p; return; }
+                if (k == -1) return;
+                h = (h + 1) & (RP_TABLE - 1);
+            }
+        };
+        int64_t p = p0 + 2 * threadIdx.x;
+        if ((((uintptr_t)row) & 15) == 0) {                                     // p0 is even: pairs are 16-byte aligned with the row
+            for (; p + 1 < p1; p += 512) {
+                const longlong2 v = *(const longlong2 *)(row + p);
+                look(v.x, p);
+                look(v.y, p + 1);
+            }
+            if (p < p1) look(row[p], p);
+        } else {
+            for (; p < p1; p += 512) {
+                look(row[p], p);
+                if (p + 1 < p1) look(row[p + 1], p + 1);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mdx
+
 extern "C" {
 
 int64_t mdx_rank_workspace(int64_t n, int64_t nq)
@@ -1584,6 +1654,22 @@ int mdx_rank_of(const float *scores, int64_t n, int64_t nq, const int64_t *ids,
     if (rc != MDX_OK) return rc;
     MDX_HIP(hipMemsetAsync(pos, 0, (size_t)total * sizeof(int64_t), (hipStream_t)stream));
     return mdx_rank_count(scores, n, nq, 0, id_scores, ids, offsets, total, pos, stream);
+}
+
+
+int mdx_rank_positions(const int64_t *ranks, int64_t n, int64_t nq, int64_t ld, const int64_t *ids, const int64_t *offsets,
+                       int64_t total, int64_t *pos, void *stream)
+{
+    MDX_CHECK_ARG(ranks && ids && offsets && pos, "mdx_rank_positions: NULL pointer");
+    MDX_CHECK_ARG(n > 0 && nq > 0 && nq < 65536 && ld >= n && total >= 0, "mdx_rank_positions: n=%lld nq=%lld ld=%lld total=%lld", (long long)n,
+                  (long long)nq, (long long)ld, (long long)total);
+    if (total == 0) return MDX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MDX_HIP(hipMemsetAsync(pos, 0xFF, (size_t)total * sizeof(int64_t), s));        // -1: not in the ranking
+    hipLaunchKernelGGL(mdx::rank_positions_kernel, dim3((unsigned)ceil_div(n, (int64_t)mdx::RP_ROWS_PER_BLOCK), (unsigned)nq), dim3(256), 0, s, ranks, ld, n, ids,
+                       offsets, pos);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
 }
 
 }  // extern "C"

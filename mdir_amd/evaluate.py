@@ -82,16 +82,62 @@ def map_from_positions(pos_lists, junk_lists, nok, kappas=()):
     return total / (nq - nempty), aps, pr / (nq - nempty), prs
 
 
-def compute_map(ranks, gnd, kappas=[]):
+class _Positions:
+    """Rank positions of every labelled id of every query, fetched ONCE (one kernel pass + one copy to the host) and then
+    looked up per protocol level and list.  ``fetch(id_lists)`` -> one int64 array per query aligned with the sorted unique
+    non-negative ids it was given; -1 = the id has no position (not a database row / not in the ranking)."""
+
+    def __init__(self, gnd, fetch):
+        self.ids = []
+        for g in gnd:
+            parts = [np.asarray(g[k], dtype=np.int64).reshape(-1) for k in ("ok", "easy", "hard", "junk") if k in g]
+            ids = np.unique(np.concatenate(parts)) if parts else np.empty(0, dtype=np.int64)
+            self.ids.append(ids[ids >= 0])
+        self.pos = fetch(self.ids)
+
+    def of(self, q, ids):
+        """Ascending positions of the SET ``ids`` in query q (what ``np.arange(N)[np.in1d(ranks[:, q], ids)]`` yields)."""
+        ids = np.unique(np.asarray(ids, dtype=np.int64).reshape(-1))
+        have = self.ids[q]
+        if len(ids) == 0 or len(have) == 0:
+            return np.empty(0, dtype=np.int64)
+        at = np.minimum(np.searchsorted(have, ids), len(have) - 1)
+        found = self.pos[q][at[have[at] == ids]]
+        return np.sort(found[found >= 0])
+
+
+def _is_device_tensor(x):
+    return torch is not None and isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def positions_in_ranking(ranks, id_lists):
+    """Positions of ids inside a DEVICE ranking ``[N,Q]`` (column q = query q; the transposed view of the ``[Q,N]`` matrix
+    mdx_rank_full writes costs nothing) through ``mdx_rank_positions``: one pass over the ranking for all queries and
+    lists.  One int64 array per query aligned with ``id_lists[q]`` (non-negative, unique), -1 where absent."""
+    from . import ops
+    rows = ranks.t()
+    if rows.stride(1) != 1:
+        rows = rows.contiguous()
+    pos, off = ops.rank_positions(rows, id_lists)
+    pos = pos.cpu().numpy()
+    return [pos[off[q]:off[q + 1]] for q in range(len(id_lists))]
+
+
+def compute_map(ranks, gnd, kappas=[], _positions=None):
     """mAP of a ranking (evaluate.py:39-111).
 
     ``ranks``: ``[N,Q]`` ids best-to-worst per column -- numpy array or torch tensor
     (CPU or GPU; a transposed view of the ``[Q,N]`` matrix mdx_rank_full writes is
     fine).  ``gnd[q]``: ``ok`` ids, optional ``junk`` ids.  Queries with no
-    positives are NaN and excluded from the mean.
+    positives are NaN and excluded from the mean.  A ranking on the GPU is searched by
+    ``mdx_rank_positions`` (all queries and lists in one pass; each id is taken to occur once per
+    column, as in any ranking), a host ranking with ``np.isin`` column by column.
     Returns ``(map, aps, pr, prs)``.
     """
     nq = len(gnd)
+    if _positions is None and _is_device_tensor(ranks):
+        _positions = _Positions(gnd, lambda lists: positions_in_ranking(ranks, lists))
+    where = (lambda q, ids: _positions.of(q, ids)) if _positions is not None else (lambda q, ids: _column_positions(ranks, q, ids))
     pos_lists, junk_lists, nok = [], [], []
     for q in range(nq):
         ok = np.asarray(gnd[q]["ok"])
@@ -101,8 +147,8 @@ def compute_map(ranks, gnd, kappas=[]):
             junk_lists.append(np.empty(0, dtype=np.int64))
             continue
         junk = np.asarray(gnd[q]["junk"]) if "junk" in gnd[q] else np.empty(0)
-        pos_lists.append(_column_positions(ranks, q, ok))
-        junk_lists.append(_column_positions(ranks, q, junk))
+        pos_lists.append(where(q, ok))
+        junk_lists.append(where(q, junk))
     return map_from_positions(pos_lists, junk_lists, nok, kappas)
 
 
@@ -114,6 +160,23 @@ def positions_from_scores(scores, id_lists):
     pos, _, off = ops.rank_of(scores, id_lists)
     pos = pos.cpu().numpy()
     return [pos[off[q]:off[q + 1]] for q in range(len(id_lists))]
+
+
+def _score_positions(scores, gnd):
+    """:class:`_Positions` from device scores: ids outside ``[0, n)`` are not database rows and have no position
+    (``np.in1d`` finds nothing for them, evaluate.py:80-81)."""
+    n = scores.shape[1]
+
+    def fetch(lists):
+        inside = [ids[ids < n] for ids in lists]
+        got = positions_from_scores(scores, inside)
+        out = []
+        for ids, sub, p in zip(lists, inside, got):
+            full = np.full(len(ids), -1, dtype=np.int64)
+            full[:len(sub)] = p                      # ids are sorted: those < n come first
+            out.append(full)
+        return out
+    return _Positions(gnd, fetch)
 
 
 def labelled_lists(gnd, n):
@@ -132,12 +195,13 @@ def labelled_lists(gnd, n):
     return oks, junks, nok
 
 
-def compute_map_from_scores(scores, gnd, kappas=[]):
+def compute_map_from_scores(scores, gnd, kappas=[], _positions=None):
     """:func:`compute_map` on scores ``[Q,N]`` (device) instead of a ranking."""
     oks, junks, nok = labelled_lists(gnd, scores.shape[1])
-    both = positions_from_scores(scores, [np.concatenate([o, j]) for o, j in zip(oks, junks)])
-    pos_lists = [b[:len(o)] for b, o in zip(both, oks)]
-    junk_lists = [b[len(o):] for b, o in zip(both, oks)]
+    if _positions is None:
+        _positions = _score_positions(scores, gnd)
+    pos_lists = [_positions.of(q, o) for q, o in enumerate(oks)]
+    junk_lists = [_positions.of(q, j) for q, j in enumerate(junks)]
     return map_from_positions(pos_lists, junk_lists, nok, kappas)
 
 
@@ -172,10 +236,13 @@ def _evaluate(dataset, gnd, kappas, one_map):
 
 
 def compute_map_and_print(dataset, ranks, gnd, kappas=[1, 5, 10]):
-    """``(averages, per_query)`` dicts with the reference's keys (evaluate.py:114-152)."""
-    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map(ranks, g, k))
+    """``(averages, per_query)`` dicts with the reference's keys (evaluate.py:114-152).  A ranking on the GPU is searched
+    once for every labelled id (all protocol levels share the positions)."""
+    positions = _Positions(gnd, lambda lists: positions_in_ranking(ranks, lists)) if _is_device_tensor(ranks) else None
+    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map(ranks, g, k, _positions=positions))
 
 
 def compute_map_and_print_from_scores(dataset, scores, gnd, kappas=[1, 5, 10]):
-    """Same as :func:`compute_map_and_print`, from device scores ``[Q,N]``."""
-    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map_from_scores(scores, g, k))
+    """Same as :func:`compute_map_and_print`, from device scores ``[Q,N]`` (one counting pass for all protocol levels)."""
+    positions = _score_positions(scores, gnd)
+    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map_from_scores(scores, g, k, _positions=positions))

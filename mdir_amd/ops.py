@@ -6,6 +6,7 @@ torch.distributed.  Every function here hands raw device pointers to the C ABI
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -483,14 +484,13 @@ def topk(scores, k, id_offset=0, workspace=None):
 
 
 def _csr(id_lists, device):
-    offsets = [0]
-    flat = []
-    for ids in id_lists:
-        flat.extend(int(i) for i in ids)
-        offsets.append(len(flat))
-    ids_t = torch.tensor(flat, dtype=torch.int64, device=device)
-    off_t = torch.tensor(offsets, dtype=torch.int64, device=device)
-    return ids_t, off_t, offsets
+    arrays = [np.asarray(ids, dtype=np.int64).reshape(-1) for ids in id_lists]
+    offsets = np.zeros(len(arrays) + 1, dtype=np.int64)
+    if arrays:
+        np.cumsum([len(a) for a in arrays], out=offsets[1:])
+    flat = np.concatenate(arrays) if arrays else np.empty(0, dtype=np.int64)
+    both = torch.from_numpy(np.concatenate([flat, offsets])).to(device)      # one copy
+    return both[:len(flat)], both[len(flat):], [int(o) for o in offsets]
 
 
 def rank_of(scores, id_lists):
@@ -507,12 +507,35 @@ def rank_of(scores, id_lists):
     pos = torch.zeros(total, dtype=torch.int64, device=scores.device)
     sc = torch.empty(total, dtype=torch.float32, device=scores.device)
     if total:
-        if int(ids_t.min()) < 0 or int(ids_t.max()) >= n:
+        flat = np.concatenate([np.asarray(ids, dtype=np.int64).reshape(-1) for ids in id_lists])
+        if int(flat.min()) < 0 or int(flat.max()) >= n:
             raise IndexError("labelled id out of range [0,%d)" % n)
         with torch.cuda.device(scores.device):
             check(_lib.lib().mdx_rank_of(sp, n, nq, _vp(ids_t.data_ptr()), _vp(off_t.data_ptr()), total,
                                          _vp(sc.data_ptr()), _vp(pos.data_ptr()), _stream()), "mdx_rank_of")
     return pos, sc, offsets
+
+
+def rank_positions(ranks, id_lists):
+    """Positions of the given ids inside a ranking: ``ranks`` int64 ``[Q, N]`` on the device (rows contiguous; a row stride
+    larger than N, e.g. the first columns of a wider matrix, is fine), ``id_lists[q]`` = non-negative ids, unique within a
+    query.  Returns ``(pos, offsets)``: flat int64 device tensor aligned with the concatenated lists (-1 where the id does not
+    occur in row q) and the CSR offsets.  ``np.arange(N)[np.in1d(ranks[:, q], ids)]`` of evaluate.py:80-81 in one pass."""
+    if not (isinstance(ranks, torch.Tensor) and ranks.is_cuda and ranks.dtype == torch.int64 and ranks.dim() == 2):
+        raise ValueError("ranks: a 2-d int64 CUDA tensor [Q, N]")
+    if ranks.stride(1) != 1:
+        raise ValueError("ranks: every query's row must be contiguous (pass the [Q, N] matrix, not a copy of its transpose)")
+    nq, n = ranks.shape
+    if len(id_lists) != nq:
+        raise ValueError("need one id list per query")
+    ids_t, off_t, offsets = _csr(id_lists, ranks.device)
+    total = ids_t.numel()
+    pos = torch.empty(total, dtype=torch.int64, device=ranks.device)
+    if total:
+        with torch.cuda.device(ranks.device):
+            check(_lib.lib().mdx_rank_positions(_vp(ranks.data_ptr()), n, nq, ranks.stride(0) if nq > 1 else n, _vp(ids_t.data_ptr()),
+                                                _vp(off_t.data_ptr()), total, _vp(pos.data_ptr()), _stream()), "mdx_rank_positions")
+    return pos, offsets
 
 
 def gather_scores(scores, ids_t, off_t):

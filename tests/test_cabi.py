@@ -17,7 +17,7 @@ def _declared():
 def test_header_declares_the_path():
     names = _declared()
     for must in ("mdx_pool_l2n", "mdx_ms_aggregate", "mdx_index_create", "mdx_scores", "mdx_rank_full",
-                 "mdx_topk", "mdx_rank_of", "mdx_rank_count", "mdx_l2n_rows"):
+                 "mdx_topk", "mdx_rank_of", "mdx_rank_positions", "mdx_rank_count", "mdx_l2n_rows"):
         assert must in names
 
 

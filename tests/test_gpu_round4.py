@@ -532,3 +532,70 @@ def test_project_f64_large_tiles_vs_numpy(dout, d, n):
     assert np.max(np.abs(got - P @ (X - m[:, None])) / bound) < 1e-13
     got0 = ops.project_f64(dev(P), dev(X)).cpu().numpy()
     assert np.max(np.abs(got0 - P @ X) / (np.sqrt((P * P).sum(1))[:, None] * np.sqrt((X * X).sum(0))[None, :])) < 1e-13
+
+
+# ---------------------------------------------------------------- a13: positions of labelled ids inside a device ranking
+
+def test_rank_positions_vs_numpy_isin():
+    """mdx_rank_positions = `np.arange(N)[np.in1d(ranks[:, q], ids)]` (evaluate.py:80-81) for all queries in one pass: ids
+    that do not occur (-1), an empty list, a list longer than one LDS chunk (2 048), a partial ranking (the first columns of
+    a wider matrix: row stride > n), rows at 8-byte alignment only, n smaller than one block."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(12)
+    for n, nq, width in ((100_003, 5, 100_003), (40_000, 3, 50_001), (777, 4, 777)):
+        full = np.stack([rng.permutation(width) for _ in range(nq)]).astype(np.int64)      # [Q, width]
+        rk = dev(full)[:, :n]                                                                # first n columns
+        lists = [np.unique(rng.integers(0, width + 50, size=s)) for s in ((3000, 0, 17, 1, 250)[:nq] if nq <= 5 else ())]
+        pos, off = ops.rank_positions(rk, lists)
+        pos = pos.cpu().numpy()
+        for q in range(nq):
+            got = pos[off[q]:off[q + 1]]
+            col = full[q, :n]
+            want = np.full(len(lists[q]), -1, dtype=np.int64)
+            where = {int(v): i for i, v in enumerate(col)}
+            for t, v in enumerate(lists[q]):
+                want[t] = where.get(int(v), -1)
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(np.sort(got[got >= 0]), np.nonzero(np.isin(col, lists[q]))[0])
+    with pytest.raises(ValueError):
+        ops.rank_positions(dev(full).t(), lists)                                             # rows must be contiguous
+
+
+def test_map_from_a_device_ranking_equals_the_host_path_and_the_positions_route(golden):
+    """compute_map / compute_map_and_print on a GPU ranking (mdx_rank_positions, one pass for all protocol levels) give the
+    numbers of the same functions on the host copy (np.isin column by column: the reference's statement) and of the
+    sort-free route -- incl. ids listed in two lists, duplicated ids, ids that are not database rows, queries without
+    positives."""
+    from mdir_amd import ops
+    from mdir_amd.evaluate import compute_map, compute_map_and_print, compute_map_and_print_from_scores
+    rng = np.random.default_rng(5)
+    n, nq = 30_011, 9
+    sc = rng.standard_normal((nq, n)).astype(np.float32)
+    sc[:, ::7] = sc[:, 3:4]                                            # ties
+    scd = dev(sc)
+    rk = ops.rank_full(scd)                                            # [Q, N]
+    rk_host = rk.t().cpu().numpy()                                     # [N, Q]
+    gnd = []
+    for q in range(nq):
+        easy = rng.choice(n, 12, replace=False)
+        hard = rng.choice(n, 9, replace=False)
+        junk = np.concatenate([rng.choice(n, 6, replace=False), easy[:2], [n + 5, n + 6]])     # in two lists; not database rows
+        if q == 4:
+            easy, hard = np.empty(0, dtype=np.int64), np.empty(0, dtype=np.int64)
+        if q == 6:
+            hard = np.concatenate([hard, hard[:3]])                                           # listed twice
+        gnd.append({"easy": easy, "hard": hard, "junk": junk})
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        a_dev, p_dev = compute_map_and_print("roxford5k", rk.t(), gnd)
+        a_host, p_host = compute_map_and_print("roxford5k", rk_host, gnd)
+        a_pos, p_pos = compute_map_and_print_from_scores("roxford5k", scd, gnd)
+    assert a_dev == a_host == a_pos
+    for k in p_host:
+        np.testing.assert_array_equal(p_dev[k], p_host[k])
+        np.testing.assert_array_equal(p_pos[k], p_host[k])
+    old = [{"ok": np.concatenate([g["easy"], g["hard"]]), "junk": g["junk"]} for g in gnd]
+    m_dev = compute_map(rk.t(), old, [1, 5, 10])
+    m_host = compute_map(rk_host, old, [1, 5, 10])
+    for x, y in zip(m_dev, m_host):
+        np.testing.assert_array_equal(x, y)
