@@ -1510,28 +1510,31 @@ __global__ __launch_bounds__(256) void rank_positions_kernel(const int64_t *__re
     const int64_t *row = ranks + (int64_t)q * ld;
     for (int64_t c0 = lo; c0 < hi; c0 += RP_CHUNK) {
         const int cnt = (int)((hi - c0) < RP_CHUNK ? (hi - c0) : RP_CHUNK);
-        for (int i = threadIdx.x; i < RP_TABLE; i += 256) key[i] = -1;
+        int tsize = 64;                                                         // at least twice the chunk: short probe chains; a few
+        while (tsize < 2 * cnt) tsize <<= 1;                                    // dozen ids (rOxford) leave almost nothing to clear
+        const uint32_t mask = (uint32_t)tsize - 1;
+        for (int i = threadIdx.x; i < tsize; i += 256) key[i] = -1;
         __syncthreads();
         for (int i = threadIdx.x; i < cnt; i += 256) {
             const int64_t id = ids[c0 + i];
             if (id < 0) continue;
-            uint32_t h = (uint32_t)(((uint64_t)id * 0x9E3779B97F4A7C15ull) >> 52) & (RP_TABLE - 1);
+            uint32_t h = (uint32_t)(((uint64_t)id * 0x9E3779B97F4A7C15ull) >> 40) & mask;
             while (true) {
                 const unsigned long long old = atomicCAS((unsigned long long *)&key[h], ~0ull, (unsigned long long)id);
                 if (old == ~0ull) { slot[h] = i; break; }
                 if ((int64_t)old == id) break;                                  // listed twice: the first entry keeps the slot
-                h = (h + 1) & (RP_TABLE - 1);
+                h = (h + 1) & mask;
             }
         }
         __syncthreads();
         auto look = [&](int64_t id, int64_t p) {
             if (id < 0) return;
-            uint32_t h = (uint32_t)(((uint64_t)id * 0x9E3779B97F4A7C15ull) >> 52) & (RP_TABLE - 1);
+            uint32_t h = (uint32_t)(((uint64_t)id * 0x9E3779B97F4A7C15ull) >> 40) & mask;
             while (true) {
                 const int64_t k = key[h];
                 if (k == id) { pos[c0 + slot[h]] = p; return; }
                 if (k == -1) return;
-                h = (h + 1) & (RP_TABLE - 1);
+                h = (h + 1) & mask;
             }
         };
         int64_t p = p0 + 2 * threadIdx.x;
