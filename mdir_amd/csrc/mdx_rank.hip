@@ -1491,12 +1491,12 @@ namespace mdx {
 // `np.arange(N)[np.in1d(ranks[:, q], ids)]` (evaluate.py:80-81) yields, for all queries in one pass over the ranking.
 // The host-side form of this (one torch.isin + nonzero + copy per query, protocol level and list) took 72 ms for
 // 70 x 1 M -- twenty times the similarity + ranking kernels it follows (tools/eval_path_bench.py).
-// A workgroup hashes its query's ids (a chunk of up to RP_CHUNK of them) into LDS -- open addressing, the table twice as
-// large as the chunk -- and streams a slice of the ranking row through it with 16-byte loads: HBM-bound, 8 B per element.
+// A workgroup hashes its query's ids (a chunk of up to RP_CHUNK of them; longer lists take another sweep of the slice)
+// into LDS -- open addressing, the table at least twice as large as the chunk -- and streams a slice of the ranking row through it with 16-byte loads: HBM-bound, 8 B per element.
 // Ids are non-negative (an entry < 0 is never looked up); of an id listed twice, either entry receives the position
 // and the other stays -1 (the callers pass unique lists).
 // ---------------------------------------------------------------------------
-constexpr int RP_CHUNK = 2048, RP_TABLE = 4096, RP_ROWS_PER_BLOCK = 16384;
+constexpr int RP_CHUNK = 512, RP_TABLE = 1024, RP_ROWS_PER_BLOCK = 16384;      // 12 KiB of LDS: a dozen workgroups per CU
 
 __global__ __launch_bounds__(256) void rank_positions_kernel(const int64_t *__restrict__ ranks, int64_t ld, int64_t n,
                                                              const int64_t *__restrict__ ids, const int64_t *__restrict__ offsets,
@@ -1539,6 +1539,17 @@ __global__ __launch_bounds__(256) void rank_positions_kernel(const int64_t *__re
         };
         int64_t p = p0 + 2 * threadIdx.x;
         if ((((uintptr_t)row) & 15) == 0) {                                     // p0 is even: pairs are 16-byte aligned with the row
+            for (; p + 3 * 512 + 1 < p1; p += 4 * 512) {                       // four loads in flight per lane
+                typedef long long i64x2 __attribute__((ext_vector_type(2)));
+                i64x2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load((const i64x2 *)(row + p + u * 512));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    look(v[u].x, p + u * 512);
+                    look(v[u].y, p + u * 512 + 1);
+                }
+            }
             for (; p + 1 < p1; p += 512) {
                 const longlong2 v = *(const longlong2 *)(row + p);
                 look(v.x, p);

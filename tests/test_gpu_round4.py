@@ -538,7 +538,7 @@ def test_project_f64_large_tiles_vs_numpy(dout, d, n):
 
 def test_rank_positions_vs_numpy_isin():
     """mdx_rank_positions = `np.arange(N)[np.in1d(ranks[:, q], ids)]` (evaluate.py:80-81) for all queries in one pass: ids
-    that do not occur (-1), an empty list, a list longer than one LDS chunk (2 048), a partial ranking (the first columns of
+    that do not occur (-1), an empty list, a list longer than one LDS chunk (512), a partial ranking (the first columns of
     a wider matrix: row stride > n), rows at 8-byte alignment only, n smaller than one block."""
     from mdir_amd import ops
     rng = np.random.default_rng(12)
