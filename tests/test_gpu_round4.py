@@ -599,3 +599,26 @@ def test_map_from_a_device_ranking_equals_the_host_path_and_the_positions_route(
     m_host = compute_map(rk_host, old, [1, 5, 10])
     for x, y in zip(m_dev, m_host):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("n,d,nq", [(1001, 101, 7), (37, 3, 5), (4099, 259, 33), (263, 1027, 18)])
+def test_retile_odd_shapes_both_layouts_and_storages(n, d, nq):
+    """The LDS-staged re-tiling (index build + queries) on shapes whose rows start at 4-byte alignment only and end inside a
+    16-byte run (d, n not multiples of 4), with and without the centre, fp32 (bit-exact vs the chain) and fp16 shards
+    (vs the same inputs rounded to fp16, float64 accumulation)."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(n * d + nq)
+    db = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    qv = (rng.standard_normal((nq, d)) / np.sqrt(d)).astype(np.float32)
+    m = rng.normal(0, 0.05, d).astype(np.float32)
+    vecs, qvecs = np.ascontiguousarray(db.T), np.ascontiguousarray(qv.T)
+    want = OC.scores_chain(vecs, qvecs)
+    want_c = OC.scores_chain(vecs, np.ascontiguousarray((qv - m).T))
+    for lay, src, q in (("DN", vecs, qvecs), ("ND", db, qv)):
+        ix = ops.DescriptorIndex(dev(src), lay)
+        np.testing.assert_array_equal(ix.scores(dev(q), lay).cpu().numpy(), want)
+        np.testing.assert_array_equal(ix.scores(dev(q), lay, center=dev(m)).cpu().numpy(), want_c)
+        ix16 = ops.DescriptorIndex(dev(src), lay, storage="f16")
+        got16 = ix16.scores(dev(q), lay, center=dev(m)).cpu().numpy()
+        ref16 = (qv - m).astype(np.float16).astype(np.float64) @ db.astype(np.float16).astype(np.float64).T
+        np.testing.assert_allclose(got16, ref16, rtol=0, atol=3e-5)
