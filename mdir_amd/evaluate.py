@@ -105,6 +105,90 @@ class _Positions:
         found = self.pos[q][at[have[at] == ids]]
         return np.sort(found[found >= 0])
 
+    def _flat(self):
+        """All queries' (id, position) pairs as flat arrays, ordered by (query, position) -- built on first use."""
+        if getattr(self, "_f", None) is None:
+            nq = len(self.ids)
+            lens = np.array([len(x) for x in self.ids], dtype=np.int64)
+            ids = np.concatenate(self.ids) if nq else np.empty(0, dtype=np.int64)
+            pos = np.concatenate(self.pos) if nq else np.empty(0, dtype=np.int64)
+            qq = np.repeat(np.arange(nq, dtype=np.int64), lens)
+            m = int(ids.max()) + 1 if len(ids) else 1
+            key = qq * m + ids                              # ascending: queries ascending, ids sorted inside a query
+            order = np.lexsort((pos, qq))
+            q_s = qq[order]
+            starts = np.searchsorted(q_s, np.arange(nq + 1))
+            self._f = (m, key, order, q_s, pos[order], pos[order] >= 0, starts)
+        return self._f
+
+    def _mark(self, lists):
+        """Boolean membership of the flat pairs in the per-query id SETS ``lists`` (ids that were never fetched mark nothing)."""
+        m, key = self._flat()[:2]
+        lens = np.array([len(x) for x in lists], dtype=np.int64)
+        flat = np.concatenate(lists) if len(lists) else np.empty(0, dtype=np.int64)
+        qq = np.repeat(np.arange(len(lists), dtype=np.int64), lens)
+        keep = (flat >= 0) & (flat < m)
+        want = qq[keep] * m + flat[keep]
+        mask = np.zeros(len(key), dtype=bool)
+        if len(key) and len(want):
+            at = np.minimum(np.searchsorted(key, want), len(key) - 1)
+            mask[at[key[at] == want]] = True
+        return mask
+
+    def map(self, gnd, kappas=()):
+        """:func:`map_from_positions` for ``gnd`` (``ok`` / optional ``junk`` per query) on the fetched positions, with the
+        set lookups, the junk shift and the AP terms computed for all queries at once.  Every float64 operation of
+        ``compute_ap`` / ``compute_map`` (evaluate.py:3-37, :85-106) is kept, in its order: the terms are the same
+        expressions elementwise, each query's AP is the left-to-right sum of its terms (``np.cumsum``), the means add up
+        in query order -- bit-identical to the per-query statement (tests/test_evaluate.py)."""
+        nq = len(gnd)
+        empty = np.empty(0, dtype=np.int64)
+        oks = [np.asarray(g["ok"], dtype=np.int64).reshape(-1) for g in gnd]
+        nok = [len(o) for o in oks]
+        junks = [np.asarray(g["junk"], dtype=np.int64).reshape(-1) if ("junk" in g and n) else empty for g, n in zip(gnd, nok)]
+        _, _, order, q_s, pos_s, valid_s, starts = self._flat()
+        ok_s = self._mark(oks)[order] & valid_s
+        junk_s = self._mark(junks)[order] & valid_s
+        jcum = np.cumsum(junk_s)
+        before = jcum - junk_s                                                  # junk strictly earlier in the whole array
+        base = np.where(starts[:-1] > 0, jcum[np.maximum(starts[:-1], 1) - 1], 0) if len(jcum) else np.zeros(nq, dtype=np.int64)
+        sel = np.nonzero(ok_s)[0]
+        q_o = q_s[sel]
+        adj = pos_s[sel] - (before[sel] - base[q_o])                            # positives move up by the junk ranked before them
+        counts = np.bincount(q_o, minlength=nq) if len(q_o) else np.zeros(nq, dtype=np.int64)
+        first = np.concatenate([[0], np.cumsum(counts)])
+        j = np.arange(len(sel), dtype=np.int64) - first[q_o]
+        jf, af = j.astype(np.float64), adj.astype(np.float64)
+        p0 = np.ones(len(sel))
+        nz = adj != 0
+        p0[nz] = jf[nz] / af[nz]
+        p1 = (jf + 1.0) / (af + 1.0)
+        with np.errstate(divide="ignore"):
+            step = 1.0 / np.asarray(nok, dtype=np.float64)
+        terms = (p0 + p1) * step[q_o] / 2.0
+        aps = np.zeros(nq)
+        pr = np.zeros(len(kappas))
+        prs = np.zeros((nq, len(kappas)))
+        total, nempty = 0.0, 0
+        for q in range(nq):
+            if nok[q] == 0:
+                aps[q] = float("nan")
+                prs[q, :] = float("nan")
+                nempty += 1
+                continue
+            a, b = first[q], first[q + 1]
+            ap = float(np.cumsum(terms[a:b])[-1]) if b > a else 0.0
+            if len(kappas):
+                pos1 = adj[a:b] + 1
+                top = int(pos1.max())
+                for i, kappa in enumerate(kappas):
+                    kq = min(top, kappa)
+                    prs[q, i] = (pos1 <= kq).sum() / kq
+            aps[q] = ap
+            total += ap
+            pr = pr + prs[q, :]
+        return total / (nq - nempty), aps, pr / (nq - nempty), prs
+
 
 def _is_device_tensor(x):
     return torch is not None and isinstance(x, torch.Tensor) and x.is_cuda
@@ -137,7 +221,8 @@ def compute_map(ranks, gnd, kappas=[], _positions=None):
     nq = len(gnd)
     if _positions is None and _is_device_tensor(ranks):
         _positions = _Positions(gnd, lambda lists: positions_in_ranking(ranks, lists))
-    where = (lambda q, ids: _positions.of(q, ids)) if _positions is not None else (lambda q, ids: _column_positions(ranks, q, ids))
+    if _positions is not None:
+        return _positions.map(gnd, kappas)
     pos_lists, junk_lists, nok = [], [], []
     for q in range(nq):
         ok = np.asarray(gnd[q]["ok"])
@@ -147,8 +232,8 @@ def compute_map(ranks, gnd, kappas=[], _positions=None):
             junk_lists.append(np.empty(0, dtype=np.int64))
             continue
         junk = np.asarray(gnd[q]["junk"]) if "junk" in gnd[q] else np.empty(0)
-        pos_lists.append(where(q, ok))
-        junk_lists.append(where(q, junk))
+        pos_lists.append(_column_positions(ranks, q, ok))
+        junk_lists.append(_column_positions(ranks, q, junk))
     return map_from_positions(pos_lists, junk_lists, nok, kappas)
 
 
@@ -196,13 +281,10 @@ def labelled_lists(gnd, n):
 
 
 def compute_map_from_scores(scores, gnd, kappas=[], _positions=None):
-    """:func:`compute_map` on scores ``[Q,N]`` (device) instead of a ranking."""
-    oks, junks, nok = labelled_lists(gnd, scores.shape[1])
+    """:func:`compute_map` on scores ``[Q,N]`` (device) instead of a ranking (ids as ``labelled_lists`` reads them)."""
     if _positions is None:
         _positions = _score_positions(scores, gnd)
-    pos_lists = [_positions.of(q, o) for q, o in enumerate(oks)]
-    junk_lists = [_positions.of(q, j) for q, j in enumerate(junks)]
-    return map_from_positions(pos_lists, junk_lists, nok, kappas)
+    return _positions.map(gnd, kappas)
 
 
 def _protocol_gnd(gnd, ok_keys, junk_keys):

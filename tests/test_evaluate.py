@@ -140,3 +140,49 @@ def test_sort_free_route_with_repeated_and_foreign_ids(monkeypatch):
     oks, junks, nok = E.labelled_lists(gnd, n)
     assert [o.tolist() for o in oks] == [[3, 7, 9], [4, 5], [8, 11], []] and nok == [4, 2, 3, 0]
     assert [j.tolist() for j in junks] == [[1, 2], [5, 6], [0], []]
+
+
+def test_vectorised_map_on_fetched_positions_is_bit_identical_to_the_per_query_statement():
+    """`_Positions.map` (what compute_map runs on a GPU ranking and compute_map_from_scores on GPU scores: one lookup pass,
+    junk shift and AP terms for all queries at once) against `compute_map` on the host ranking (np.isin column by column +
+    the reference's loops): same floats bit for bit, same NaNs, same exceptions -- ids in two lists, listed twice, negative,
+    beyond the database, queries without positives, positives that are all missing, no `junk` key, with and without kappas."""
+    from mdir_amd import evaluate as E
+    rng = np.random.default_rng(1)
+    for trial in range(150):
+        n, nq = int(rng.integers(5, 300)), int(rng.integers(1, 9))
+        ranks = np.stack([rng.permutation(n) for _ in range(nq)], axis=1)
+        gnd = []
+        for q in range(nq):
+            k_ok, k_j = int(rng.integers(0, min(n, 12))), int(rng.integers(0, min(n, 8)))
+            ok, junk = rng.integers(-2, n + 3, size=k_ok), rng.integers(-2, n + 3, size=k_j)
+            if k_ok and rng.random() < 0.3:
+                junk = np.concatenate([junk, ok[:2]])
+            if k_ok and rng.random() < 0.3:
+                ok = np.concatenate([ok, ok[:1]])
+            g = {"ok": ok.astype(np.int64)}
+            if rng.random() < 0.85:
+                g["junk"] = junk.astype(np.int64)
+            gnd.append(g)
+        kappas = [1, 5, 10] if rng.random() < 0.7 else []
+
+        def fetch(lists):
+            out = []
+            for q, ids in enumerate(lists):
+                inv = {int(v): i for i, v in enumerate(ranks[:, q])}
+                out.append(np.array([inv.get(int(x), -1) for x in ids], dtype=np.int64))
+            return out
+
+        def run(f):
+            try:
+                return f()
+            except (ValueError, ZeroDivisionError) as exc:
+                return type(exc).__name__
+
+        want = run(lambda: E.compute_map(ranks, gnd, kappas))
+        got = run(lambda: E._Positions(gnd, fetch).map(gnd, kappas))
+        if isinstance(want, str) or isinstance(got, str):
+            assert want == got
+            continue
+        for a, b in zip(want, got):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
