@@ -229,6 +229,13 @@ int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, in
 /* Same with an explicit storage type (mdx_storage).  `src` is fp32 in both cases. */
 int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
                         int64_t row_offset, int storage, void *stream);
+/* The same in memory the caller provides (and keeps alive until mdx_index_destroy, which then frees nothing): `memory` =
+ * mdx_index_bytes(n, d, storage) bytes of device memory at a 256-byte boundary.  hipMalloc + hipFree of an 8 GB shard cost
+ * ~190 ms per create / destroy pair -- seventy times the re-tiling itself; a host that builds an index per evaluation hands
+ * in memory from its own pool (PyTorch's caching allocator in mdir_amd/ops.py). */
+int64_t mdx_index_bytes(int64_t n, int64_t d, int storage);
+int mdx_index_create_in(mdx_index **out, const float *src, int64_t n, int64_t d, int layout, int64_t row_offset,
+                        int storage, void *memory, int64_t memory_bytes, void *stream);
 int mdx_index_destroy(mdx_index *index);
 /* n, d, row_offset and device bytes held. */
 int mdx_index_info(const mdx_index *index, int64_t *n, int64_t *d, int64_t *row_offset,
@@ -251,6 +258,15 @@ int64_t mdx_scores_workspace(int64_t nq, int64_t d);
 int mdx_scores(const mdx_index *index, const float *queries, int64_t nq, int qlayout,
                const float *center, float *scores, void *workspace, int64_t workspace_bytes,
                void *stream);
+
+/* The same similarity for a database that is multiplied ONCE -- the literal `scores = np.dot(vecs.T, qvecs)` of one
+ * evaluation (cirscore.py:69) -- read where it lies: db [n, d] row-major fp32 on the device, no index, no second copy of it
+ * (an index of 1 M x 2048 is another 8.2 GB and 3 ms of re-tiling).  Same kernels, same k order: the scores are bit-identical
+ * to mdx_scores on an index of the same rows.  d must be a multiple of 4 and db 16-byte aligned (rows are fetched in 16-byte
+ * pieces; MDX_ERR_ARG otherwise: build an index).  queries / center / scores / workspace (mdx_scores_workspace(nq, d)) as
+ * in mdx_scores. */
+int mdx_scores_rowmajor(const float *db, int64_t n, int64_t d, const float *queries, int64_t nq, int qlayout,
+                        const float *center, float *scores, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* How mdx_scores_ex multiplies an fp32 shard.
  *   MDX_F32_CHAIN   the exact path of mdx_scores (k-ordered fp32 fma chain on the fp32 MFMA; the parity contract).

@@ -73,10 +73,13 @@ def _declare(lib):
         "mdx_jpeg_pixels": (i32, [p, p, p, p, p, p]),
         "mdx_index_create": (i32, [pp, p, i64, i64, i32, i64, p]),
         "mdx_index_create_ex": (i32, [pp, p, i64, i64, i32, i64, i32, p]),
+        "mdx_index_bytes": (i64, [i64, i64, i32]),
+        "mdx_index_create_in": (i32, [pp, p, i64, i64, i32, i64, i32, p, i64, p]),
         "mdx_index_destroy": (i32, [p]),
         "mdx_index_info": (i32, [p, pi64, pi64, pi64, pi64]),
         "mdx_scores_workspace": (i64, [i64, i64]),
         "mdx_scores": (i32, [p, p, i64, i32, p, p, p, i64, p]),
+        "mdx_scores_rowmajor": (i32, [p, i64, i64, p, i64, i32, p, p, p, i64, p]),
         "mdx_scores_workspace_ex": (i64, [i64, i64, i32]),
         "mdx_scores_ex": (i32, [p, p, i64, i32, p, p, p, i64, i32, p]),
         "mdx_rank_workspace": (i64, [i64, i64]),
@@ -109,8 +112,8 @@ def _declare(lib):
 
 EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
            "mdx_ms_aggregate_batch", "mdx_pool_multi", "mdx_l2n_aggregate", "mdx_bn_act", "mdx_u8_to_chw", "mdx_resample_u8", "mdx_bilinear_pyramid", "mdx_jpeg_probe", "mdx_jpeg_coefficients", "mdx_jpeg_pixels",
-           "mdx_index_create", "mdx_index_create_ex", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
-           "mdx_scores", "mdx_scores_workspace_ex", "mdx_scores_ex", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of", "mdx_rank_positions",
+           "mdx_index_create", "mdx_index_create_ex", "mdx_index_bytes", "mdx_index_create_in", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
+           "mdx_scores", "mdx_scores_rowmajor", "mdx_scores_workspace_ex", "mdx_scores_ex", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of", "mdx_rank_positions",
            "mdx_gather_scores", "mdx_rank_count", "mdx_conv1x1_transpose_weights", "mdx_conv1x1_bn_act", "mdx_clahe_workspace", "mdx_clahe_u8_to_chw", "mdx_gram_f64_workspace", "mdx_gram_f64", "mdx_project_f64_workspace", "mdx_project_f64", "mdx_comm_unique_id", "mdx_comm_init",
            "mdx_comm_destroy", "mdx_comm_info", "mdx_query_bounds", "mdx_allgather_scores", "mdx_exchange_scores")
 

@@ -152,18 +152,18 @@ static int lds_opt_in(const void *kern, int lds, bool *done)
     return MDX_OK;
 }
 
-template <int QT, int R, typename MM, int QR = 0>
+template <int QT, int R, typename MM, int QR = 0, bool RM = false>
 static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
-                            int KB, int nq_valid, hipStream_t s, int passes = 1)
+                            int KB, int nq_valid, hipStream_t s, int passes = 1, int64_t ld = 0)
 {
-    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR>;   // 2 = non-temporal database stream
+    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR, 4, RM>;   // 2 = non-temporal database stream
     constexpr int lds = LC_NSTAGE * (QT + QR + 4 * R) * LC_KC * 1024;
     static bool opted[64];
     int rc = lds_opt_in((const void *)kern, lds, opted);
     if (rc != MDX_OK) return rc;
     const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
-                       (unsigned long long *)nullptr);
+                       (unsigned long long *)nullptr, ld);
     return MDX_OK;
 }
 
@@ -238,6 +238,37 @@ static int dispatch_qt(int qt, int mode, const f32x4 *db, const f32x4 *q, float 
     }
 }
 
+// The same kernels on a row-major database read where it lies (RM = true; mdx_scores_rowmajor)
+template <int R>
+static int dispatch_rowmajor(int qt, bool leftover, const float *db, int64_t ld, const f32x4 *q, float *out, int64_t n, int64_t RT, int KB,
+                             int nq_valid, hipStream_t s)
+{
+    const f32x4 *d4 = (const f32x4 *)db;
+    if constexpr (R == 2) {
+        if (leftover) {
+            switch (qt) {
+                case 2: return launch_scores_lc<1, 2, MmaF32, 1, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+                case 3: return launch_scores_lc<2, 2, MmaF32, 1, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+                case 4: return launch_scores_lc<3, 2, MmaF32, 1, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+                case 5: return launch_scores_lc<4, 2, MmaF32, 1, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+                case 6: return launch_scores_lc<5, 2, MmaF32, 1, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+                case 7: return launch_scores_lc<6, 2, MmaF32, 1, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+                default: return launch_scores_lc<7, 2, MmaF32, 1, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+            }
+        }
+    }
+    switch (qt) {
+        case 1: return launch_scores_lc<1, R, MmaF32, 0, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+        case 2: return launch_scores_lc<2, R, MmaF32, 0, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+        case 3: return launch_scores_lc<3, R, MmaF32, 0, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+        case 4: return launch_scores_lc<4, R, MmaF32, 0, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+        case 5: return launch_scores_lc<5, R, MmaF32, 0, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+        case 6: return launch_scores_lc<6, R, MmaF32, 0, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+        case 7: return launch_scores_lc<7, R, MmaF32, 0, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+        default: return launch_scores_lc<8, R, MmaF32, 0, true>(d4, q, out, n, RT, KB, nq_valid, s, 1, ld);
+    }
+}
+
 // Split-precision launches (mdx_scores_split_kernel.h): 8 consumer waves x R row tiles + 4 loader waves, one workgroup
 // per CU, ring of 3 stages of (3 QT + 16 R) KiB.  Up to SPLIT_QT query tiles per workgroup; more queries = more passes (grid.y).
 constexpr int SPLIT_CW = 8, SPLIT_NSTAGE = 3, SPLIT_QT = 5;
@@ -307,6 +338,7 @@ struct mdx_index {
     int64_t n, d, d_pad, RT, RT_pad, KB, row_offset;
     int64_t bytes;
     int storage;        // MDX_F32 / MDX_F16
+    bool owns;          // tiles came from hipMalloc here (mdx_index_create*) and are freed on destroy; false: the caller's memory
     uint32_t max_bits;  // fp32 shards: bit pattern of the largest finite |x| (read back once at creation): the scale of MDX_F32_SPLIT2
 };
 
@@ -339,16 +371,8 @@ int mdx_index_create(mdx_index **out, const float *src, int64_t n, int64_t d, in
     return mdx_index_create_ex(out, src, n, d, layout, row_offset, MDX_F32, stream);
 }
 
-int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
-                        int64_t row_offset, int storage, void *stream)
+static void index_geometry(mdx_index *ix, int64_t n, int64_t d, int storage)
 {
-    MDX_CHECK_ARG(out && src, "mdx_index_create: NULL pointer");
-    MDX_CHECK_ARG(storage == MDX_F32 || storage == MDX_F16, "mdx_index_create: storage %d", storage);
-    MDX_CHECK_ARG(n > 0 && d > 0, "mdx_index_create: n=%lld d=%lld must be positive",
-                  (long long)n, (long long)d);
-    MDX_CHECK_ARG(layout == MDX_DIM_MAJOR || layout == MDX_ROW_MAJOR, "mdx_index_create: layout %d",
-                  layout);
-    mdx_index *ix = new mdx_index();
     ix->n = n;
     ix->d = d;
     ix->storage = storage;
@@ -357,15 +381,53 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
     ix->RT = ceil_div(n, TILE_ROWS);
     // every wave of every workgroup has a tile to read: 8 row tiles per workgroup, 16 for the split-precision kernel (fp32 shards)
     ix->RT_pad = round_up(ix->RT, storage == MDX_F32 ? 16 : 8);
-    ix->row_offset = row_offset;
     ix->bytes = ix->RT_pad * ix->KB * 1024;
     ix->max_bits = 0;
-    hipError_t e = hipMalloc((void **)&ix->tiles, (size_t)ix->bytes + 256);     // + one word behind the tiles: the |x| maximum
-    if (e != hipSuccess) {
-        set_error("mdx_index_create: hipMalloc(%lld bytes) failed: %s", (long long)ix->bytes,
-                  hipGetErrorString(e));
-        delete ix;
-        return MDX_ERR_NOMEM;
+}
+
+int64_t mdx_index_bytes(int64_t n, int64_t d, int storage)
+{
+    if (n <= 0 || d <= 0 || (storage != MDX_F32 && storage != MDX_F16)) return 0;
+    mdx_index g;
+    index_geometry(&g, n, d, storage);
+    return g.bytes + 256;                                          // + one word behind the tiles: the |x| maximum
+}
+
+int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d, int layout,
+                        int64_t row_offset, int storage, void *stream)
+{
+    return mdx_index_create_in(out, src, n, d, layout, row_offset, storage, nullptr, 0, stream);
+}
+
+int mdx_index_create_in(mdx_index **out, const float *src, int64_t n, int64_t d, int layout, int64_t row_offset, int storage,
+                        void *memory, int64_t memory_bytes, void *stream)
+{
+    MDX_CHECK_ARG(out && src, "mdx_index_create: NULL pointer");
+    MDX_CHECK_ARG(storage == MDX_F32 || storage == MDX_F16, "mdx_index_create: storage %d", storage);
+    MDX_CHECK_ARG(n > 0 && d > 0, "mdx_index_create: n=%lld d=%lld must be positive",
+                  (long long)n, (long long)d);
+    MDX_CHECK_ARG(layout == MDX_DIM_MAJOR || layout == MDX_ROW_MAJOR, "mdx_index_create: layout %d",
+                  layout);
+    mdx_index *ix = new mdx_index();
+    index_geometry(ix, n, d, storage);
+    ix->row_offset = row_offset;
+    ix->owns = memory == nullptr;
+    if (memory) {
+        if (memory_bytes < ix->bytes + 256 || ((uintptr_t)memory & 255)) {
+            set_error("mdx_index_create_in: %lld bytes at a 256-byte boundary needed (mdx_index_bytes), got %lld at %p", (long long)ix->bytes + 256,
+                      (long long)memory_bytes, memory);
+            delete ix;
+            return MDX_ERR_WORKSPACE;
+        }
+        ix->tiles = (f32x4 *)memory;
+    } else {
+        hipError_t e = hipMalloc((void **)&ix->tiles, (size_t)ix->bytes + 256);
+        if (e != hipSuccess) {
+            set_error("mdx_index_create: hipMalloc(%lld bytes) failed: %s", (long long)ix->bytes,
+                      hipGetErrorString(e));
+            delete ix;
+            return MDX_ERR_NOMEM;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     uint32_t *cell = storage == MDX_F32 ? (uint32_t *)((char *)ix->tiles + ix->bytes) : nullptr;
@@ -380,7 +442,7 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
     }
     if (rc != MDX_OK) {
         (void)hipStreamSynchronize(s);
-        (void)hipFree(ix->tiles);
+        if (ix->owns) (void)hipFree(ix->tiles);
         delete ix;
         return rc;
     }
@@ -394,7 +456,7 @@ int mdx_index_create_ex(mdx_index **out, const float *src, int64_t n, int64_t d,
 int mdx_index_destroy(mdx_index *ix)
 {
     if (!ix) return MDX_OK;
-    hipError_t e = hipFree(ix->tiles);
+    const hipError_t e = ix->owns ? hipFree(ix->tiles) : hipSuccess;
     delete ix;
     if (e != hipSuccess) {
         set_error("mdx_index_destroy: hipFree failed: %s", hipGetErrorString(e));
@@ -479,6 +541,41 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
             rc = dispatch_leftover(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
         else
             rc = dispatch_qt(qt, mode, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+        if (rc != MDX_OK) return rc;
+        MDX_LAUNCH_CHECK();
+    }
+    return MDX_OK;
+}
+
+int mdx_scores_rowmajor(const float *db, int64_t n, int64_t d, const float *queries, int64_t nq, int qlayout, const float *center,
+                        float *scores, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    MDX_CHECK_ARG(db && queries && scores, "mdx_scores_rowmajor: NULL pointer");
+    MDX_CHECK_ARG(n > 0 && nq > 0, "mdx_scores_rowmajor: n=%lld nq=%lld must be positive", (long long)n, (long long)nq);
+    MDX_CHECK_ARG(d >= 4 && d % 4 == 0 && ((uintptr_t)db & 15) == 0,
+                  "mdx_scores_rowmajor: d=%lld must be a multiple of 4 and the matrix 16-byte aligned (rows are read in 16-byte pieces); "
+                  "build an index for other shapes", (long long)d);
+    MDX_CHECK_ARG(qlayout == MDX_DIM_MAJOR || qlayout == MDX_ROW_MAJOR, "mdx_scores_rowmajor: qlayout %d", qlayout);
+    const int64_t need = mdx_scores_workspace(nq, d);
+    if (!workspace || workspace_bytes < need) {
+        set_error("mdx_scores_rowmajor: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+        return MDX_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    f32x4 *qtiles = (f32x4 *)workspace;
+    const int64_t QT_total = ceil_div(nq, TILE_ROWS), KB = round_up(d, 64) / TILE_K, RT = ceil_div(n, TILE_ROWS);
+    int rc = retile(queries, nq, d, qlayout, center, qtiles, QT_total, KB, s, MDX_F32);
+    if (rc != MDX_OK) return rc;
+    const bool small = RT < 2048;                     // < 32 768 rows: 64-row workgroups
+    for (int64_t qt0 = 0; qt0 < QT_total; qt0 += MAX_QT) {
+        const int qt = (int)((QT_total - qt0) < MAX_QT ? (QT_total - qt0) : MAX_QT);
+        const int64_t q0 = qt0 * TILE_ROWS;
+        const int nq_valid = (int)((nq - q0) < qt * TILE_ROWS ? (nq - q0) : qt * TILE_ROWS);
+        const int tail = nq_valid - (qt - 1) * TILE_ROWS;      // queries in the last tile of this launch
+        const f32x4 *qp = qtiles + qt0 * KB * 64;
+        float *op = scores + q0 * n;
+        if (small) rc = dispatch_rowmajor<1>(qt, false, db, d, qp, op, n, RT, (int)KB, nq_valid, s);
+        else       rc = dispatch_rowmajor<2>(qt, qt >= 2 && tail <= 8, db, d, qp, op, n, RT, (int)KB, nq_valid, s);
         if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK();
     }

@@ -110,12 +110,20 @@ struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e
 // the 2 x 32 of the padded tile's two 16x16x4 MFMAs per 4 k).  A lane reads the 16 k of "its" query row
 // and of "its" database row with four ds_read_b128 each (the four lane groups g of the tile format hold
 // k = 4t+g) and issues the products in k order, so every output is still the k = 0..D-1 fma chain.
-template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0, int CWAVES = 4>
+//
+// RM = true (mdx_scores_rowmajor: a database that is multiplied ONCE, read where it lies): `db` is the caller's row-major
+// fp32 matrix [n, ld] instead of tiles.  A loader lane (c, j) = (lane >> 4, lane & 15) fetches the 16 bytes of row
+// 16 rt + j at k = 16 kb + 4 c, so a tile's KiB in LDS holds element w of lane (c, j) = k 4 c + w -- the tile format with the
+// roles of lane group and element swapped.  The consumers put "their" operand together from four 4-byte reads 64 lanes
+// apart (two ds_read2st64_b32; 64 different banks): lane (g, j), element t = k 4 t + g, as before -- same MFMAs, same k order,
+// same bits.  Rows >= n read row n-1 (never stored), a chunk past k = ld the row's last one (the query tiles are zero there).
+template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0, int CWAVES = 4, bool RM = false>
 __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
                                                            float *__restrict__ out, int64_t n, int KB,
-                                                           int nq_valid, unsigned long long *dbg = nullptr)
+                                                           int nq_valid, unsigned long long *dbg = nullptr, int64_t ld = 0)
 {
+    static_assert(!RM || (MM::STEPS == 4 && KC == 2), "row-major databases: fp32, two k-blocks per stage");
     constexpr int CW = CWAVES;                      // consumer waves (8: two per SIMD in ONE workgroup per CU, sharing the query stage)
     constexpr int LW = 4;                           // loader waves
     static_assert(QR == 0 || (R == 2 && MM::STEPS == 4), "the 4x4x1 leftover path covers 32 fp32 rows per wave");
@@ -145,6 +153,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
         // this loader's tiles of a stage: i = lw, lw+LW, ...  (query tiles first)
         const f32x4 *src[PER_LOADER];
         int dst[PER_LOADER];
+        int rm_k[PER_LOADER];            // RM: first k of this lane's 16 bytes inside a stage
 #pragma unroll
         for (int t = 0; t < PER_LOADER; ++t) {
             const int i = (lw + t * LW) < STAGE_TILES ? (lw + t * LW) : (STAGE_TILES - 1);
@@ -159,7 +168,13 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                                    // rows, so the shard comes from the L2 instead of HBM: 2.37 ms against 2.70 on the same box
                 src[t] = db + shard_tile((int64_t)(blockIdx.x % 16) * CW * R + tile, kbc, KB) * 64 + lane;
 #else
-                src[t] = db + shard_tile(rt_wg + tile, kbc, KB) * 64 + lane;
+                if constexpr (RM) {
+                    const int64_t row = (rt_wg + tile) * TILE_ROWS + (lane & 15);
+                    src[t] = (const f32x4 *)((const float *)db + (row < n ? row : n - 1) * ld);     // the row; k is added per stage
+                    rm_k[t] = kbc * TILE_K + 4 * (lane >> 4);
+                } else {
+                    src[t] = db + shard_tile(rt_wg + tile, kbc, KB) * 64 + lane;
+                }
 #endif
             }
         }
@@ -171,6 +186,12 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                 // the database stream may be marked non-temporal (DB_AUX = 2) and advances in the shard's order
                 const bool is_db = (lw + t * LW) >= QTILES;
                 const f32x4 *p = src[t] + (is_db ? shard_tile(0, (int64_t)c * KC, KB) : (int64_t)c * KC) * 64;
+                if constexpr (RM) {
+                    if (is_db) {
+                        const int64_t k = (int64_t)c * KC * TILE_K + rm_k[t];
+                        p = (const f32x4 *)((const float *)src[t] + (k + 4 <= ld ? k : ld - 4));
+                    }
+                }
                 if (DB_AUX != 0 && is_db)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                                      (__attribute__((address_space(3))) void *)(slot + dst[t]), 16, 0, DB_AUX);
@@ -223,7 +244,15 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
 #pragma unroll
             for (int q = 0; q < QT; ++q) a[q] = qs[(q * KC + kb) * 64];
 #pragma unroll
-            for (int r = 0; r < R; ++r) b[r] = bs[(r * KC + kb) * 64];
+            for (int r = 0; r < R; ++r) {
+                if constexpr (RM) {
+                    const float *bt = (const float *)(slot + (QTILES + (wave * R + r) * KC + kb) * 64) + 4 * (lane & 15) + (lane >> 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[r][t] = bt[t * 64];
+                } else {
+                    b[r] = bs[(r * KC + kb) * 64];
+                }
+            }
             if constexpr (QR == 0) {
 #pragma unroll
                 for (int t = 0; t < MM::STEPS; ++t)
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
 #pragma unroll
                             for (; done < due; ++done) {
                                 const int st = (t == 3 && done >= 4) ? 3 : t - 1, g = done & 3;
-                                accl = __builtin_amdgcn_mfma_f32_4x4x1f32(al[g][st], bl[g][st], accl, 0, 0, 0);
+                                accl = __builtin_amdgcn_mfma_f32_4x4x1f32(al[g][st], RM ? bl[st][g] : bl[g][st], accl, 0, 0, 0);
                                 __builtin_amdgcn_sched_barrier(PIN);
                             }
                         }

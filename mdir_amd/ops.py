@@ -364,8 +364,12 @@ class DescriptorIndex:
         self.device = vecs.device
         self.n, self.d, self.row_offset = n, d, int(row_offset)
         with torch.cuda.device(self.device):
-            check(_lib.lib().mdx_index_create_ex(ctypes.byref(self._h), vp, n, d, lay, self.row_offset,
-                                                 _lib.STORAGE[storage], _stream()), "mdx_index_create_ex")
+            # the tiles live in PyTorch's caching allocator: hipMalloc + hipFree of an 8 GB shard cost ~190 ms per index, a
+            # block of the pool nothing after the first use
+            need = _lib.lib().mdx_index_bytes(n, d, _lib.STORAGE[storage])
+            self._tiles = torch.empty(need, dtype=torch.uint8, device=self.device)
+            check(_lib.lib().mdx_index_create_in(ctypes.byref(self._h), vp, n, d, lay, self.row_offset, _lib.STORAGE[storage],
+                                                 _vp(self._tiles.data_ptr()), need, _stream()), "mdx_index_create_in")
             # the source tensor may be freed by the caller right after: finish the re-tiling first
             torch.cuda.current_stream().synchronize()
 
@@ -413,6 +417,7 @@ class DescriptorIndex:
         if getattr(self, "_h", None) is not None and self._h.value:
             h, self._h = self._h, None
             check(_lib.lib().mdx_index_destroy(h), "mdx_index_destroy")
+            self._tiles = None          # back to the pool (kernels still reading it are ordered before its next use by the stream)
 
     def __del__(self):
         try:
@@ -466,6 +471,34 @@ def rank_full_segments(blocks, id_offset=0, out=None, workspace=None):
     with torch.cuda.device(dev):
         check(_lib.lib().mdx_rank_full_segments(ptrs, widths, len(blocks), nq, int(id_offset), _dev(out, torch.int64, "ranks"),
                                                 _vp(ws.data_ptr()), ws.numel(), _stream()), "mdx_rank_full_segments")
+    return out
+
+
+def scores_rowmajor(db, queries, qlayout="DN", center=None, out=None):
+    """fp32 ``[nq, n]`` similarities of ``queries`` against the rows of ``db`` -- a row-major ``[n, d]`` fp32 CUDA matrix that
+    is multiplied ONCE and read where it lies (``mdx_scores_rowmajor``): no index build, no second copy of the database.
+    Bit-identical to ``DescriptorIndex(db, "ND").scores(queries, qlayout, center)`` (same kernels, same k order).
+    ``d`` must be a multiple of 4 (rows are fetched in 16-byte pieces); other shapes: build a :class:`DescriptorIndex`."""
+    dp = _dev(db, torch.float32, "db")
+    if db.dim() != 2:
+        raise ValueError("db: a 2-d [n, d] matrix")
+    n, d = db.shape
+    nq, dq, lay = _layout(queries, qlayout, "queries")
+    if dq != d:
+        raise ValueError("query dimension %d != database dimension %d" % (dq, d))
+    qp = _dev(queries, torch.float32, "queries")
+    cp = _dev(center, torch.float32, "center") if center is not None else None
+    if center is not None and center.numel() != d:
+        raise ValueError("center has %d elements, expected %d" % (center.numel(), d))
+    if out is None:
+        out = torch.empty((nq, n), dtype=torch.float32, device=db.device)
+    elif tuple(out.shape) != (nq, n):
+        raise ValueError("out must be [%d,%d]" % (nq, n))
+    need = _lib.lib().mdx_scores_workspace(nq, d)
+    ws = _workspace(need, db.device)
+    with torch.cuda.device(db.device):
+        check(_lib.lib().mdx_scores_rowmajor(dp, n, d, qp, nq, lay, cp, _dev(out, torch.float32, "out"), _vp(ws.data_ptr()), need,
+                                             _stream()), "mdx_scores_rowmajor")
     return out
 
 

@@ -96,6 +96,10 @@ class DescriptorIndex:
         pass
 
 
+def scores_rowmajor(db, queries, qlayout="DN", center=None, out=None):
+    return DescriptorIndex(db, "ND").scores(queries, qlayout, center=center, out=out)
+
+
 def rank_full(scores, id_offset=0, out=None, workspace=None):
     return torch.from_numpy(OC.rank_full(scores.detach().numpy()) + id_offset)
 
@@ -158,7 +162,7 @@ def project_f64(p, x, center=None):
     return torch.from_numpy(p.detach().numpy() @ xv)
 
 
-NAMES = ("clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "rank_full", "topk", "rank_of",
+NAMES = ("clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "scores_rowmajor", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 

@@ -622,3 +622,38 @@ def test_retile_odd_shapes_both_layouts_and_storages(n, d, nq):
         got16 = ix16.scores(dev(q), lay, center=dev(m)).cpu().numpy()
         ref16 = (qv - m).astype(np.float16).astype(np.float64) @ db.astype(np.float16).astype(np.float64).T
         np.testing.assert_allclose(got16, ref16, rtol=0, atol=3e-5)
+
+
+# ---------------------------------------------------------------- a11: the database read where it lies (one evaluation = one product)
+
+@pytest.mark.parametrize("n,d,nq", [(4993, 2048, 70), (6322, 2048, 70), (1000, 512, 1), (333, 100, 17), (16, 64, 16), (5000, 256, 130), (70, 2048, 70),
+                                    (40000, 128, 24), (32768, 32, 33), (33000, 64, 100), (50000, 48, 120), (70000, 64, 1), (66001, 100, 17),
+                                    (70001, 256, 130), (65600, 2048, 70), (65537, 32, 128), (131072, 96, 33), (1125, 512, 1125), (3000, 128, 300),
+                                    (40000, 64, 389), (2000, 256, 256), (33333, 4, 9), (40001, 36, 72)])
+def test_scores_rowmajor_bit_exact_vs_chain(n, d, nq):
+    """mdx_scores_rowmajor (the row-major database read in place by the same loader/consumer kernels: 16-byte pieces of 16 rows
+    per LDS-DMA instruction, operands assembled from four 4-byte LDS reads) on the 21 shapes of the exact kernel's own test
+    + d = 4 and a d that is not a multiple of 16 or 32: the k-ordered fma chain bit for bit, both query layouts, with the
+    centre; the same bits as the index route."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(n + d + nq)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    qv = rng.standard_normal((nq, d)).astype(np.float32)
+    qv /= np.linalg.norm(qv, axis=1, keepdims=True)
+    m = rng.normal(0, 0.02, d).astype(np.float32)
+    want = OC.scores_chain(np.ascontiguousarray(db.T), np.ascontiguousarray(qv.T))
+    dbd = dev(db)
+    np.testing.assert_array_equal(ops.scores_rowmajor(dbd, dev(qv), "ND").cpu().numpy(), want)
+    np.testing.assert_array_equal(ops.scores_rowmajor(dbd, dev(np.ascontiguousarray(qv.T)), "DN").cpu().numpy(), want)
+    want_c = OC.scores_chain(np.ascontiguousarray(db.T), np.ascontiguousarray((qv - m).T))
+    got_c = ops.scores_rowmajor(dbd, dev(qv), "ND", center=dev(m))
+    np.testing.assert_array_equal(got_c.cpu().numpy(), want_c)
+    assert torch.equal(got_c, ops.DescriptorIndex(dbd, "ND").scores(dev(qv), "ND", center=dev(m)))
+
+
+def test_scores_rowmajor_refuses_what_it_cannot_read_in_16_byte_pieces():
+    from mdir_amd import ops
+    x = torch.zeros((100, 30), device=DEV)
+    with pytest.raises(Exception, match="multiple of 4"):
+        ops.scores_rowmajor(x, torch.zeros((3, 30), device=DEV), "ND")
