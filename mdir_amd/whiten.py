@@ -32,7 +32,8 @@ def whitenapply(X, m, P, dimensions=None, device="cuda"):
 # descriptors): the low-variance directions of a 2048-d covariance sit below fp32 noise, so the D x D Gram
 # matrices and the projection are float64 here too -- libmdx's own f64 matrix-core kernels (mdx_gram_f64,
 # SYRK-shaped; mdx_project_f64 with the centring fused into the operand load; csrc/mdx_gram.hip), not the fp32 chain
-# kernel of the hot path.  The small dense factorisations stay on the host, as in the reference.
+# kernel of the hot path.  Of the small dense factorisations only the Cholesky (a yes / no decision of the reference's LAPACK
+# call) stays on the host; the symmetric eigen-decomposition runs next to the data (rocSOLVER through torch.linalg).
 # ---------------------------------------------------------------------------
 
 def _as_f64(a, device):
@@ -66,32 +67,57 @@ def cholesky(S):
             print(">>>> whiten.py::cholesky: Matrix is not positive definite, adding {:.0e} on the diagonal".format(alpha))
 
 
+def _eigh_descending(M):
+    """Eigenvalues (descending) and eigenvectors (columns) of a symmetric float64 matrix ON ITS DEVICE.  The reference calls
+    ``np.linalg.eig`` and sorts (whiten.py:23-26, :47-49): on a symmetric matrix the same decomposition, but LAPACK's
+    general solver takes 10.3 s for 2048 x 2048 on the host (89 % of one whitening learning, tools/whitenlearn_bench.py)
+    where the symmetric solver next to the data takes 0.06 s.  Eigenvectors are defined up to sign either way (the tests
+    compare rows of P up to sign; whitened dot products do not see it)."""
+    w, v = torch.linalg.eigh(M)
+    return torch.flip(w, [0]), torch.flip(v, [1])
+
+
+def _inverse_lower(L, device):
+    """``np.linalg.inv`` of a Cholesky factor (whiten.py:43), as a triangular solve on the device."""
+    Ld = _as_f64(L, device)
+    return torch.linalg.solve_triangular(Ld, torch.eye(Ld.shape[0], dtype=torch.float64, device=Ld.device), upper=False)
+
+
 def pcawhitenlearn(X, shrink=None, device="cuda"):
-    """PCA whitening without annotations (``whiten.py:14-35``): returns ``(m, P)``."""
+    """PCA whitening without annotations (``whiten.py:14-35``): returns ``(m, P)``.  The descriptors go to the device once;
+    mean, covariance (``mdx_gram_f64`` with the centring fused), eigen-decomposition and scaling happen there."""
     N = X.shape[1]
-    m = X.mean(axis=1, keepdims=True)
-    Xcov = gram(X, device, center=m)
-    Xcov = (Xcov + Xcov.T) / (2 * N)
-    eigval, eigvec = np.linalg.eig(Xcov)
-    order = eigval.argsort()[::-1]
-    eigval, eigvec = eigval[order], eigvec[:, order]
+    Xd = _as_f64(X, device)
+    m = Xd.mean(dim=1, keepdim=True)
+    Xcov = ops.gram_f64(Xd, m.reshape(-1).contiguous())
+    Xcov = (Xcov + Xcov.t()) / (2 * N)
+    eigval, eigvec = _eigh_descending(Xcov)
     if shrink:
         b = eigval[shrink - 1]
         eigval = (1 - b) * eigval + b
-    P = np.dot(np.linalg.inv(np.sqrt(np.diag(eigval))), eigvec.T)
-    return m, P
+    P = (1.0 / torch.sqrt(eigval))[:, None] * eigvec.t()       # inv(sqrt(diag(eigval))) @ eigvec.T
+    return m.cpu().numpy(), P.cpu().numpy()
 
 
 def whitenlearn(X, qidxs, pidxs, device="cuda"):
-    """Learned whitening from matching pairs (``whiten.py:37-53``): returns ``(m, P)``."""
-    m = X[:, qidxs].mean(axis=1, keepdims=True)
-    df = X[:, qidxs] - X[:, pidxs]
-    S = gram(df, device) / df.shape[1]
-    P = np.linalg.inv(cholesky(S))
-    df = project(P, X, m, device)
-    D = gram(df, device)
-    eigval, eigvec = np.linalg.eig(D)
-    order = eigval.argsort()[::-1]
-    eigvec = eigvec[:, order]
-    P = np.dot(eigvec.T, P)
-    return m, P
+    """Learned whitening from matching pairs (``whiten.py:37-53``): returns ``(m, P)``.  One copy of the descriptors to the
+    device; pair differences, the two Gram matrices (``mdx_gram_f64``), the projection (``mdx_project_f64``), the
+    triangular inverse, the eigen-decomposition and the final product happen there.  The Cholesky factorisation -- with
+    the reference's retry rule on a matrix that is not positive definite, a yes / no decision of ITS LAPACK call -- stays
+    on the host.  D = 2048, 20 000 pairs of 40 000 descriptors: 11.6 s -> 0.6 s (tools/whitenlearn_bench.py)."""
+    Xd = _as_f64(X, device)
+    qi = torch.as_tensor(np.asarray(qidxs, dtype=np.int64), device=Xd.device)
+    pi = torch.as_tensor(np.asarray(pidxs, dtype=np.int64), device=Xd.device)
+    Xq = Xd[:, qi]
+    m = Xq.mean(dim=1, keepdim=True)
+    df = (Xq - Xd[:, pi]).contiguous()
+    del Xq
+    S = ops.gram_f64(df) / df.shape[1]
+    del df
+    P = _inverse_lower(cholesky(S.cpu().numpy()), device)
+    df = ops.project_f64(P.contiguous(), Xd, m.reshape(-1).contiguous())
+    D = ops.gram_f64(df)
+    del df
+    _, eigvec = _eigh_descending(D)
+    P = ops.project_f64(eigvec.t().contiguous(), P.contiguous())     # np.dot(eigvec.T, P)
+    return m.cpu().numpy(), P.cpu().numpy()
