@@ -38,6 +38,12 @@ for it in range(iters):
                 if not (np.abs(got3 - want).max() <= 2e-6):
                     bad += 1
                     print("%s MISMATCH it=%d rep=%d n=%d d=%d nq=%d: max diff %.3g" % (mode, it, rep, n, d, nq, np.abs(got3 - want).max()))
+        if storage == "f32" and rep % 2 == 1:       # the same rows read in place (mdx_scores_rowmajor): bit-exact too; both query layouts
+            dbd = torch.from_numpy(db).cuda()
+            got_rm = (ops.scores_rowmajor(dbd, qd, "ND") if rep == 1 else ops.scores_rowmajor(dbd, qd.t().contiguous(), "DN")).cpu().numpy()
+            if not np.array_equal(got_rm, want):
+                bad += 1
+                print("rowmajor MISMATCH it=%d rep=%d n=%d d=%d nq=%d: %d wrong" % (it, rep, n, d, nq, int((got_rm != want).sum())))
         if not ok:
             bad += 1
             w = np.argwhere(got != want) if storage == "f32" else np.argwhere(np.abs(got - want) > 2e-6)
