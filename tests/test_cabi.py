@@ -120,3 +120,26 @@ def test_ops_refuse_cpu_tensors():
         ops.pool_l2n(torch.zeros(1, 2, 3, 3), "gem")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.rank_full(torch.zeros(2, 5))
+
+
+def test_late_round4_entry_points_check_their_arguments():
+    """mdx_scores_rowmajor, mdx_index_bytes / mdx_index_create_in and mdx_rank_positions refuse what they cannot do before
+    touching a device."""
+    import ctypes
+    from mdir_amd import _lib
+    h = _lib.lib()
+    P = ctypes.c_void_p
+    ws = h.mdx_scores_workspace(70, 2048)
+    assert h.mdx_scores_rowmajor(None, 10, 8, P(16), 1, 1, None, P(16), P(16), ws, None) == -1 and b"NULL" in h.mdx_last_error()
+    assert h.mdx_scores_rowmajor(P(16), 10, 30, P(16), 1, 1, None, P(16), P(16), ws, None) == -1 and b"multiple of 4" in h.mdx_last_error()
+    assert h.mdx_scores_rowmajor(P(24), 10, 32, P(16), 1, 1, None, P(16), P(16), ws, None) == -1           # not 16-byte aligned
+    assert h.mdx_scores_rowmajor(P(16), 10, 32, P(16), 70, 1, None, P(16), P(16), 8, None) == -4            # workspace too small
+    # an fp32 shard of 1 004 993 x 2048: 62 816 row tiles x 128 k-blocks of 1 KiB + the cell of its maximum
+    assert h.mdx_index_bytes(1004993, 2048, 0) == 62816 * 128 * 1024 + 256
+    assert h.mdx_index_bytes(1004993, 2048, 1) == 62816 * 64 * 1024 + 256 and h.mdx_index_bytes(0, 8, 0) == 0 and h.mdx_index_bytes(8, 8, 7) == 0
+    out = P()
+    assert h.mdx_index_create_in(ctypes.byref(out), P(16), 100, 64, 1, 0, 0, P(256), 1024, None) == -4 and b"mdx_index_bytes" in h.mdx_last_error()
+    assert h.mdx_index_create_in(ctypes.byref(out), P(16), 100, 64, 1, 0, 0, P(264), 1 << 30, None) == -4   # not at a 256-byte boundary
+    assert h.mdx_rank_positions(None, 10, 1, 10, P(16), P(16), 1, P(16), None) == -1
+    assert h.mdx_rank_positions(P(16), 10, 1, 5, P(16), P(16), 1, P(16), None) == -1                          # row stride < n
+    assert h.mdx_rank_positions(P(16), 10, 1, 10, P(16), P(16), 0, P(16), None) == 0                          # nothing to look up
