@@ -599,6 +599,24 @@ def main():
             kms = extra.get("roofline", {}).get("kernel_ms") or 0.0
             sec["configs2_top100"] = {"workload": "N=%d Q=%d: exact top-100 per query instead of the full ranking" % (n_total, NQ),
                                       "topk_ms": round(t_k, 4), "queries_per_s_with_the_fp32_similarity": round(NQ / ((kms + t_k) * 1e-3), 1) if kms else None}
+            # one evaluation multiplies its database once: the same exact product on the row-major [N,D] matrix read where it lies
+            # (mdx_scores_rowmajor: no index, no second 8 GB), next to what building an index for one product costs
+            sc_rm = torch.empty_like(sc)
+            t_rm = timed(lambda: ops.scores_rowmajor(rows, qvecs, "DN", out=sc_rm), reps=10)
+
+            def build_multiply():
+                ix1 = ops.DescriptorIndex(rows, "ND")
+                ix1.scores(qvecs, "DN", out=sc_rm)
+                ix1.close()
+            t_bm = timed(build_multiply, reps=5)
+            sec["configs2_one_evaluation"] = {
+                "workload": "N=%d Q=%d D=%d fp32: the exact similarity of ONE evaluation, descriptors row-major on the device" % (n_total, NQ, DIM),
+                "in_place_ms": round(t_rm, 4), "index_build_plus_multiply_ms": round(t_bm, 4), "resident_index_ms": kms or None,
+                "bit_identical_to_the_index_route": bool(torch.equal(sc_rm, sc)),
+                "what": "mdx_scores_rowmajor (the kernels of the headline on the caller's matrix) against mdx_index_create_in + mdx_scores + "
+                        "destroy with the tiles in PyTorch's pool (own hipMalloc + hipFree of the 8 GB shard: ~190 ms per pair)"}
+            assert sec["configs2_one_evaluation"]["bit_identical_to_the_index_route"]
+            del sc_rm
             # the LABELLED split-precision modes on the SAME fp32 shard (not the headline, not the parity contract -- timed beside it
             # with what they do to the result): MDX_F32_SPLIT3 = three bf16 pieces per operand, six products on the bf16 MFMA;
             # MDX_F32_SPLIT2 = block floating point, two fp16 pieces with a scaled residual, three products on the fp16 MFMA
