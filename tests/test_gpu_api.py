@@ -178,6 +178,24 @@ def test_full_size_scores_bit_exact_on_samples(big):
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)        # vs the reference's BLAS: north-star tolerance
 
 
+def test_full_size_in_place_product_and_device_ranking_map(big):
+    """At the headline size: mdx_scores_rowmajor (the row-major matrix read where it lies) gives the index route's 70 M scores
+    bit for bit (those are pinned to the chain oracle above), and compute_map on the device ranking (mdx_rank_positions)
+    equals compute_map from the scores (mdx_rank_of) for random labelled sets."""
+    from mdir_amd import ops
+    from mdir_amd.evaluate import compute_map, compute_map_from_scores
+    got = ops.scores_rowmajor(big["rows"], big["q"].contiguous(), "ND")
+    assert torch.equal(got, big["sc"])
+    del got
+    rng = np.random.default_rng(4)
+    gnd = [{"ok": rng.choice(big["n"], 25, replace=False), "junk": rng.choice(big["n"], 10, replace=False)} for _ in range(big["nq"])]
+    gnd[3]["ok"] = np.array([77, 123, 900_000, 5], dtype=np.int64)          # tied rows and the zero vector
+    a = compute_map(big["rk"].t(), gnd, [1, 5, 10])
+    b = compute_map_from_scores(big["sc"], gnd, [1, 5, 10])
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("mode", ["split3", "split2"])
 def test_full_size_split_modes_on_the_same_shard(big, mode):
     """MDX_F32_SPLIT3 / MDX_F32_SPLIT2 at BASELINE's full size, on the index the exact tests use (no second copy): every score within the
