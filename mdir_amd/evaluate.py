@@ -169,21 +169,32 @@ class _Positions:
         aps = np.zeros(nq)
         pr = np.zeros(len(kappas))
         prs = np.zeros((nq, len(kappas)))
+        live = [q for q in range(nq) if nok[q]]
+        if len(kappas) and live:
+            # P@k for all queries at once (evaluate.py:102-106): kq = min(max(pos) + 1, kappa), (pos + 1 <= kq).sum() / kq
+            if any(counts[q] == 0 for q in live):
+                raise ValueError("zero-size array to reduction operation maximum which has no identity")   # max(pos) of no positive
+            pos1 = adj + 1
+            seg = first[:-1][counts > 0]                                       # reduceat: only non-empty segments
+            top = np.zeros(nq, dtype=np.int64)
+            top[counts > 0] = np.maximum.reduceat(pos1, seg)
+            for i, kappa in enumerate(kappas):
+                kq = np.minimum(top, kappa)
+                hits = np.zeros(nq, dtype=np.int64)
+                hits[counts > 0] = np.add.reduceat((pos1 <= kq[q_o]).astype(np.int64), seg)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    prs[:, i] = hits / kq
         total, nempty = 0.0, 0
+        term_list = terms.tolist()
         for q in range(nq):
             if nok[q] == 0:
                 aps[q] = float("nan")
                 prs[q, :] = float("nan")
                 nempty += 1
                 continue
-            a, b = first[q], first[q + 1]
-            ap = float(np.cumsum(terms[a:b])[-1]) if b > a else 0.0
-            if len(kappas):
-                pos1 = adj[a:b] + 1
-                top = int(pos1.max())
-                for i, kappa in enumerate(kappas):
-                    kq = min(top, kappa)
-                    prs[q, i] = (pos1 <= kq).sum() / kq
+            ap = 0.0
+            for t in term_list[first[q]:first[q + 1]]:                          # left to right, as compute_ap adds them
+                ap += t
             aps[q] = ap
             total += ap
             pr = pr + prs[q, :]
