@@ -258,14 +258,13 @@ def positions_from_scores(scores, id_lists):
     return [pos[off[q]:off[q + 1]] for q in range(len(id_lists))]
 
 
-def _score_positions(scores, gnd):
-    """:class:`_Positions` from device scores: ids outside ``[0, n)`` are not database rows and have no position
-    (``np.in1d`` finds nothing for them, evaluate.py:80-81)."""
-    n = scores.shape[1]
-
+def _positions_of_rows(n, gnd, positions_of):
+    """:class:`_Positions` from a function that ranks database rows: ``positions_of(id_lists)`` -> one array of positions
+    per query for ids in ``[0, n)``; ids outside ``[0, n)`` are not database rows and have no position (``np.in1d`` finds
+    nothing for them, evaluate.py:80-81)."""
     def fetch(lists):
         inside = [ids[ids < n] for ids in lists]
-        got = positions_from_scores(scores, inside)
+        got = positions_of(inside)
         out = []
         for ids, sub, p in zip(lists, inside, got):
             full = np.full(len(ids), -1, dtype=np.int64)
@@ -273,6 +272,11 @@ def _score_positions(scores, gnd):
             out.append(full)
         return out
     return _Positions(gnd, fetch)
+
+
+def _score_positions(scores, gnd):
+    """:class:`_Positions` from device scores ``[Q,N]`` (the counting kernel, no ranking)."""
+    return _positions_of_rows(scores.shape[1], gnd, lambda lists: positions_from_scores(scores, lists))
 
 
 def labelled_lists(gnd, n):

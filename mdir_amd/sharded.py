@@ -517,7 +517,7 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
     slice of the database (which stays resident as its shard) and its slice of the queries, query
     descriptors are all-gathered, similarities are computed against the local shard, and mAP comes
     from the sort-free position counts.  Returns the same ``(averages, per_query)`` on every rank."""
-    from .evaluate import _evaluate, labelled_lists, map_from_positions
+    from .evaluate import _evaluate, _positions_of_rows
     import numpy as np
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if len(images) < world:
@@ -540,15 +540,14 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
     index = ShardedIndex(vecs, "ND", len(images), group=group, backend=backend, storage=storage, compute=compute)
     s_local = index.local_scores(qvecs.contiguous(), "ND")
 
-    def one_map(g, kappas):
-        oks, junks, nok = labelled_lists(g, len(images))         # unique, in range: the meaning np.in1d gives them
-        pos, off = index.positions(s_local, [np.concatenate([o, j]) for o, j in zip(oks, junks)])
+    def positions_of(lists):
+        pos, off = index.positions(s_local, lists)              # partial counts of every shard, summed (one all-reduce)
         pos = pos.cpu().numpy()
-        pl = [pos[off[q]:off[q] + len(oks[q])] for q in range(len(g))]
-        jl = [pos[off[q] + len(oks[q]):off[q + 1]] for q in range(len(g))]
-        return map_from_positions(pl, jl, nok, kappas)
+        return [pos[off[q]:off[q + 1]] for q in range(len(lists))]
 
-    result = _evaluate(dataset, gnd, [1, 5, 10], one_map)
+    # every labelled id of every protocol level is ranked ONCE (one counting pass per shard + one collective), then looked up
+    positions = _positions_of_rows(len(images), gnd, positions_of)
+    result = _evaluate(dataset, gnd, [1, 5, 10], lambda g, kappas: positions.map(g, kappas))
     if lap:
         lap("compute_score")
     return result
