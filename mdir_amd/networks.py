@@ -265,12 +265,12 @@ class _Sequential:
 
 def batched_loop(loader, order, device, describe, store, missing=None, progress=None, batches=True):
     """Drive ``describe`` over a batch-size-1 loader: consecutive equal-sized images go through the
-    network as ONE batch of ``MDIR_AMD_BATCH`` (default 4; only under graph replay, where equal sizes
+    network as ONE batch of ``MDIR_AMD_BATCH`` (default 8, then 4 for what is left of a size; only under graph replay, where equal sizes
     have been made consecutive) -- larger GEMMs, fewer launches per image; anything else one by one.
     ``store(index, descriptor)`` receives every result, ``missing(index)`` every unreadable image
     (a loader item that is ``{}``).  ``batches=False`` for a network that only takes one image at a
     time (the reference's protocol; this package's networks declare ``supports_batches``)."""
-    bmax = max(1, int(os.environ.get("MDIR_AMD_BATCH", "4"))) if batches and graphs_enabled(device) else 1
+    bmax = max(1, int(os.environ.get("MDIR_AMD_BATCH", "8"))) if batches and graphs_enabled(device) else 1
     buf = []
 
     def flush():
@@ -278,13 +278,17 @@ def batched_loop(loader, order, device, describe, store, missing=None, progress=
             # how many images of this size are still to come (the sampler ordered them): a graph is only captured
             # when enough replays will follow (ShapeGraphs.PAYOFF_IMAGES)
             describe.upcoming = buf[0][2] if buf and buf[0][2] is not None else None
-        if len(buf) == bmax and bmax > 1:
-            rows = describe(torch.cat([t for _, t, _ in buf], dim=0))
-            for (i, _, _), row in zip(buf, rows):
-                store(i, row)
-        else:
-            for i, t, _ in buf:
-                store(i, describe(t))
+        # whole batches of bmax; what is left of a size goes as one batch of bmax / 2 if there is that much, then one by one
+        # (at most three launch shapes -- and graphs -- per image size)
+        k = 0
+        for width in (bmax, bmax // 2):
+            while width > 1 and len(buf) - k >= width:
+                rows = describe(torch.cat([t for _, t, _ in buf[k:k + width]], dim=0))
+                for (i, _, _), row in zip(buf[k:k + width], rows):
+                    store(i, row)
+                k += width
+        for i, t, _ in buf[k:]:
+            store(i, describe(t))
         buf.clear()
 
     for done, item in enumerate(loader):

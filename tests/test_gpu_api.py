@@ -462,6 +462,7 @@ def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
     monkeypatch.setattr(ShapeGraphs, "__init__", spy)
     monkeypatch.setattr(ShapeGraphs, "PAYOFF_IMAGES", 0)      # capture even for a dozen images (default: only when >= 32 follow)
     monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    monkeypatch.setenv("MDIR_AMD_BATCH", "4")                 # the counts below are those of batches of four (default: 8, then 4)
     from mdir_amd.networks import _same_shape_order
     assert _same_shape_order(paths, None) == [0, 5, 10, 15, 1, 2, 3, 4, 6, 7, 8, 9, 11, 12, 13, 14]      # equal sizes consecutive
     graphed = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
@@ -471,9 +472,14 @@ def test_graph_replay_extraction_equals_eager(tmp_path, monkeypatch):
     single = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
     assert len(made) == 2 and made[1].replays == 16 - 2 and len(made[1].graphs) == 2 and not made[1].refused
     np.testing.assert_allclose(graphed.cpu().numpy(), single.cpu().numpy(), rtol=0, atol=2e-6)
+    # the default: batches of eight, what is left of a size as one batch of four, then one by one (12 = 8 + 4, 4 = 4)
+    monkeypatch.delenv("MDIR_AMD_BATCH")
+    by8 = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
+    np.testing.assert_allclose(by8.cpu().numpy(), single.cpu().numpy(), rtol=0, atol=2e-6)
+    n_made = len(made)
     monkeypatch.setenv("MDIR_AMD_GRAPHS", "0")
     eager = extract_vectors_device(net, paths, 160, tr, ms=ms, msp=net.pool.p_value(), device=DEV)
-    assert len(made) == 2
+    assert len(made) == n_made
     np.testing.assert_allclose(graphed.cpu().numpy(), eager.cpu().numpy(), rtol=0, atol=2e-6)
     # GPU-side `pil2np | totensor | normalize` (uint8 through the loader) == the host transform chain
     assert tr.device_tail() is not None
