@@ -732,9 +732,9 @@ def main():
             with contextlib.redirect_stdout(sys.stderr):
                 ex = measure_list("resnet101", workers=8, short=4, mid=max(8, args.extract_images // 2), long=max(16, args.extract_images))
                 ex["resident_single_shape"] = measure(types.SimpleNamespace(arch="resnet101", images=24, channels_last=False,
-                                                                            miopen_find=False, batch=4))
+                                                                            miopen_find=False, batch=8))
                 if world == 1:      # configs[4]'s network: VGG16-GeM, 3 scales + learned whitening, one resident 1024x768 shape
-                    vg = measure(types.SimpleNamespace(arch="vgg16", images=24, channels_last=False, miopen_find=False, batch=4))
+                    vg = measure(types.SimpleNamespace(arch="vgg16", images=24, channels_last=False, miopen_find=False, batch=8))
                     ex["vgg16_resident_single_shape_descriptors_per_s"] = vg["value"]
         except Exception as exc:        # an untimed side leg must not cost the ranking result (or hang the other ranks)
             err = "%s: %s" % (type(exc).__name__, exc)

@@ -157,7 +157,7 @@ def measure(args):
             "roofline_tail": {"bound": "hbm", "bytes_per_image": tail_bytes, "achieved": round(tail_bytes / (t_tail * 1e-3) / 1e9, 1),
                               "peak": 8000.0, "unit": "GB/s", "frac": round(tail_bytes / (t_tail * 1e-3) / 1e9 / 8000.0, 4),
                               "what": "GeM of the three maps (one launch), their L2Ns + the aggregation (one launch), whitening of the "
-                                      "finished [N,D] matrix / N: two short dependent launches per image (or per batch of 4), so launch "
+                                      "finished [N,D] matrix / N: two short dependent launches per image (or per batch of 8), so launch "
                                       "latency, not bandwidth, bounds it"},
             "tail_max_abs_diff_vs_torch_ops": err, "dtype": "f32", "data": "synthetic",
             "hipgraph_replays": getattr(describe, "replays", 0)}
