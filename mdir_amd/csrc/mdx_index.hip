@@ -41,7 +41,7 @@ void set_error(const char *fmt, ...)
 // contiguous direction), parks it in LDS and every wave assembles tiles from there; the row stride of the LDS block makes the
 // 64 lanes of an assembling read hit 64 different banks.  The tiles leave as before, one coalesced KiB per wave-store.
 //   ROWMAJOR  (element (row, k) at src[row * d + k]):  block = 16 rows x 256 k
-//   otherwise (element (row, k) at src[k * n + row]):  block = 16 (fp16: 32) k x 256 rows
+//   otherwise (element (row, k) at src[k * n + row]):  block = 32 k x 256 rows (two fp32 k blocks or one fp16 k block)
 // ---------------------------------------------------------------------------
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // a 16-byte load at dword alignment (any n, d)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -55,14 +55,15 @@ __global__ __launch_bounds__(256) void retile_block_kernel(const float *__restri
     // direction is the fast one: consecutive blocks read adjacent KiB of the same lines
     const unsigned bx = ROWMAJOR ? blockIdx.x / inner : blockIdx.x % inner, by = ROWMAJOR ? blockIdx.x % inner : blockIdx.x / inner;
     constexpr int TK = F16 ? 32 : 16;                       // k per tile
-    constexpr int LINES = ROWMAJOR ? 16 : TK;               // 1-KiB runs of the source per block: rows, or k rows
+    constexpr int KBS = (!ROWMAJOR && !F16) ? 2 : 1;        // dimension-major fp32: two k blocks per block, so that a row tile's two tiles leave as one 2-KiB run
+    constexpr int LINES = ROWMAJOR ? 16 : TK * KBS;         // 1-KiB runs of the source per block: rows, or k rows
     constexpr int LD = ROWMAJOR ? 260 : (F16 ? 258 : 272);  // floats per line in LDS (bank spread of the assembling reads)
     __shared__ __attribute__((aligned(16))) float blk[LINES * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     uint32_t best = 0;
     // ---- the block, in runs of 1 KiB: line `l`, floats 4 * lane .. 4 * lane + 3
-    const int64_t line0 = ROWMAJOR ? (int64_t)bx * 16 : (int64_t)by * TK;      // first row / first k
+    const int64_t line0 = ROWMAJOR ? (int64_t)bx * 16 : (int64_t)by * TK * KBS;      // first row / first k
     const int64_t col0 = (ROWMAJOR ? (int64_t)by : (int64_t)bx) * 256 + 4 * lane;   // first k / first row of this lane
     const int64_t nlines = ROWMAJOR ? n : d, ncols = ROWMAJOR ? d : n;
     const int64_t ld_src = ncols;
@@ -103,22 +104,23 @@ __global__ __launch_bounds__(256) void retile_block_kernel(const float *__restri
     }
     __syncthreads();
     // ---- tiles: 16 (fp16: 8) of them per block, 4 (2) per wave
-    constexpr int TILES = ROWMAJOR ? 256 / TK : 16;
+    constexpr int TILES = ROWMAJOR ? 256 / TK : 16 * KBS;       // dimension-major: tile tl = (row tile tl / KBS, k block tl % KBS)
 #pragma unroll
     for (int i = 0; i < TILES / 4; ++i) {
         const int tl = wave * (TILES / 4) + i;                          // tile of the block: along k (ROWMAJOR) or along rows
-        const int64_t rt = ROWMAJOR ? (int64_t)bx : (int64_t)bx * 16 + tl;
-        const int64_t kb = ROWMAJOR ? (int64_t)by * TILES + tl : (int64_t)by;
+        const int rl = ROWMAJOR ? 0 : tl / KBS, kl = ROWMAJOR ? 0 : tl % KBS;       // dimension-major: row tile and k block inside the block
+        const int64_t rt = ROWMAJOR ? (int64_t)bx : (int64_t)bx * 16 + rl;
+        const int64_t kb = ROWMAJOR ? (int64_t)by * TILES + tl : (int64_t)by * KBS + kl;
         if (rt >= RT || kb >= KB) continue;
         f32x4 out;
         if constexpr (F16) {
             f16x8 h;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) h[e] = (_Float16)(ROWMAJOR ? blk[j * LD + tl * 32 + 8 * g + e] : blk[(8 * g + e) * LD + tl * 16 + j]);
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)(ROWMAJOR ? blk[j * LD + tl * 32 + 8 * g + e] : blk[(8 * g + e) * LD + rl * 16 + j]);
             out = __builtin_bit_cast(f32x4, h);
         } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) out[t] = ROWMAJOR ? blk[j * LD + tl * 16 + 4 * t + g] : blk[(4 * t + g) * LD + tl * 16 + j];
+            for (int t = 0; t < 4; ++t) out[t] = ROWMAJOR ? blk[j * LD + tl * 16 + 4 * t + g] : blk[(kl * 16 + 4 * t + g) * LD + rl * 16 + j];
         }
         tiles[(rt * KB + kb) * 64 + lane] = out;
     }
@@ -351,9 +353,9 @@ static int retile(const float *src, int64_t n, int64_t d, int layout, const floa
                   f32x4 *tiles, int64_t RT, int64_t KB, hipStream_t s, int storage = MDX_F32, uint32_t *absmax = nullptr)
 {
     const bool rowmajor = layout != MDX_DIM_MAJOR, f16 = storage == MDX_F16;
-    // blocks: 16 rows x 256 k (row-major) or one k block x 256 rows (dimension-major); the second grid dimension is the short one
+    // blocks: 16 rows x 256 k (row-major) or 32 k x 256 rows (dimension-major: two fp32 k blocks or one fp16 k block)
     const int64_t gx = rowmajor ? RT : ceil_div(RT, (int64_t)16);
-    const int64_t gy = rowmajor ? ceil_div(KB * (f16 ? 32 : 16), (int64_t)256) : KB;
+    const int64_t gy = rowmajor ? ceil_div(KB * (f16 ? 32 : 16), (int64_t)256) : (f16 ? KB : ceil_div(KB, (int64_t)2));
     MDX_CHECK_ARG(gx * gy < (1ll << 31), "matrix too large to re-tile in one launch");
     const dim3 grid((unsigned)(gx * gy)), block(256);
     const unsigned inner = (unsigned)(rowmajor ? gy : gx);
