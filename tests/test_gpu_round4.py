@@ -657,3 +657,51 @@ def test_scores_rowmajor_refuses_what_it_cannot_read_in_16_byte_pieces():
     x = torch.zeros((100, 30), device=DEV)
     with pytest.raises(Exception, match="multiple of 4"):
         ops.scores_rowmajor(x, torch.zeros((3, 30), device=DEV), "ND")
+
+
+def test_ranking_beyond_the_packed_formats_limit():
+    """n > 2^24 rows: ids no longer fit the 24 bits of the packed intermediate words, the sort takes its (key word, id word)
+    passes for real (tests elsewhere force them on small n).  Exact full ranking, top-k and rank positions of a 16.8 M-row
+    column pair against the C oracle / numpy; ties (a block of equal scores across the 2^24 boundary) in ascending id order."""
+    from mdir_amd import ops
+    n, nq = (1 << 24) + 4097, 2
+    rng = np.random.default_rng(8)
+    sc = rng.standard_normal((nq, n)).astype(np.float32)
+    sc[:, (1 << 24) - 300:(1 << 24) + 300] = 0.25                     # 600 tied scores straddling 2^24
+    sc[1, ::3] = sc[1, 1::3][:len(sc[1, ::3])]                        # many more ties in the second column
+    scd = dev(sc)
+    rk = ops.rank_full(scd)
+    want = OC.rank_full(sc)
+    assert torch.equal(rk.cpu(), torch.from_numpy(want))
+    ids, vals = ops.topk(scd, 100)
+    np.testing.assert_array_equal(ids.cpu().numpy(), want[:, :100])
+    lists = [np.array([0, (1 << 24) - 1, 1 << 24, n - 1, 12345678]), np.array([(1 << 24) + 17, 5])]
+    pos, off = ops.rank_positions(rk, lists)
+    pos2, _, _ = ops.rank_of(scd, lists)
+    inv = [np.empty(n, dtype=np.int64) for _ in range(nq)]
+    for q in range(nq):
+        inv[q][want[q]] = np.arange(n)
+    expect = np.concatenate([inv[q][lists[q]] for q in range(nq)])
+    np.testing.assert_array_equal(pos.cpu().numpy(), expect)
+    np.testing.assert_array_equal(pos2.cpu().numpy(), expect)
+
+
+def test_similarity_on_more_than_2_pow_24_rows():
+    """16.8 M rows (d = 32): tile and row indices past 2^24 in the re-tiling, the exact kernel on an index, the in-place product and
+    the fp16 shard; bit-exact vs the chain on three slices (head, the 2^24 boundary, tail) -- the oracle would take minutes on all."""
+    from mdir_amd import ops
+    n, d, nq = (1 << 24) + 4097, 32, 3
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    db = torch.randn((n, d), generator=g, device=DEV)
+    q = torch.randn((nq, d), generator=g, device=DEV)
+    got = ops.DescriptorIndex(db, "ND").scores(q, "ND")
+    assert torch.equal(ops.scores_rowmajor(db, q, "ND"), got)
+    got16 = ops.DescriptorIndex(db, "ND", storage="f16").scores(q, "ND")
+    qh = q.cpu().numpy()
+    for lo, hi in ((0, 5000), ((1 << 24) - 2500, (1 << 24) + 2500), (n - 5000, n)):
+        sub = db[lo:hi].cpu().numpy()
+        want = OC.scores_chain(np.ascontiguousarray(sub.T), np.ascontiguousarray(qh.T))
+        np.testing.assert_array_equal(got[:, lo:hi].cpu().numpy(), want)
+        ref16 = qh.astype(np.float16).astype(np.float64) @ sub.astype(np.float16).astype(np.float64).T
+        np.testing.assert_allclose(got16[:, lo:hi].cpu().numpy(), ref16, rtol=0, atol=2e-3)
