@@ -705,3 +705,18 @@ def test_similarity_on_more_than_2_pow_24_rows():
         np.testing.assert_array_equal(got[:, lo:hi].cpu().numpy(), want)
         ref16 = qh.astype(np.float16).astype(np.float64) @ sub.astype(np.float16).astype(np.float64).T
         np.testing.assert_allclose(got16[:, lo:hi].cpu().numpy(), ref16, rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("n,d,nq", [(512, 64, 30000), (2048, 128, 5000), (130, 36, 70001)])
+def test_many_queries_against_a_small_index(n, d, nq):
+    """The whitening-as-index shape (wrapper.py:193-195 / whitenapply on a whole [D,N] matrix: the descriptors are the QUERIES,
+    the rows of P the database): tens of thousands of queries in groups of 128 per launch (grid.y), the in-place product too;
+    bit-exact vs the chain."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(n + nq)
+    db = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    qv = (rng.standard_normal((nq, d)) / np.sqrt(d)).astype(np.float32)
+    want = OC.scores_chain(np.ascontiguousarray(db.T), np.ascontiguousarray(qv.T))
+    got = ops.DescriptorIndex(dev(db), "ND").scores(dev(qv), "ND")
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert torch.equal(ops.scores_rowmajor(dev(db), dev(qv), "ND"), got)
