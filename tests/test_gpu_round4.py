@@ -720,3 +720,29 @@ def test_many_queries_against_a_small_index(n, d, nq):
     got = ops.DescriptorIndex(dev(db), "ND").scores(dev(qv), "ND")
     np.testing.assert_array_equal(got.cpu().numpy(), want)
     assert torch.equal(ops.scores_rowmajor(dev(db), dev(qv), "ND"), got)
+
+
+def test_similarity_with_non_finite_and_denormal_values():
+    """What the reference's np.dot does with the values a descriptor file can hold beyond ordinary numbers: a NaN row
+    (unreadable image, infer.py:50-51) gives NaN scores for that row only, infinities propagate (Inf - Inf = NaN), denormal
+    inputs and products are kept (the fp32 MFMA does not flush them): the chain oracle's values, NaN where it has NaN."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(2)
+    n, d, nq = 40_000, 64, 21
+    db = (rng.standard_normal((n, d)) / 8).astype(np.float32)
+    qv = (rng.standard_normal((nq, d)) / 8).astype(np.float32)
+    db[7] = np.nan
+    db[100, 3] = np.inf
+    db[101, 3], db[101, 4] = np.inf, -np.inf
+    db[200] = 1e-41                                   # denormal inputs
+    db[201] = 0.0
+    db[201, 0] = 3e-39
+    qv[5] = 0.0
+    qv[5, 0] = 1.0                                    # picks column 0: products stay denormal
+    qv[6, 3], qv[6, 4] = 1.0, 1.0                     # Inf - Inf on row 101
+    qv[9] = np.nan
+    want = OC.scores_chain(np.ascontiguousarray(db.T), np.ascontiguousarray(qv.T))
+    assert np.isnan(want[:, 7]).all() and np.isnan(want[9]).all() and np.isnan(want[6, 101]) and want[5, 201] == np.float32(3e-39)
+    for got in (ops.DescriptorIndex(dev(db), "ND").scores(dev(qv), "ND"), ops.scores_rowmajor(dev(db), dev(qv), "ND"),
+                ops.DescriptorIndex(dev(np.ascontiguousarray(db.T)), "DN").scores(dev(np.ascontiguousarray(qv.T)), "DN")):
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
