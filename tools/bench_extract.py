@@ -202,11 +202,12 @@ def _conv_flops(net, scales, h, w):
     return float(total[0])
 
 
-def measure_list(arch="resnet101", workers=8, short=4, mid=40, long=64):
+def measure_list(arch="resnet101", workers=8, short=12, mid=40, long=64):
     """Descriptors/sec of ``extract_vectors_device`` on an image LIST: 16 sizes, JPEG files through the real loader
     (decode + thumbnail in worker processes, uint8 over PCIe, /255-mean-std on the GPU), 3 scales + learned whitening
-    through the wrapper chain.  The FIRST list of the process (``short`` images per size) pays for what a new size costs
-    (MIOpen picks and loads its kernels); two later lists (``mid`` / ``long`` per size, both long enough for a graph per
+    through the wrapper chain.  The FIRST list of the process (``short`` images per size: 12 = one batch of eight + one of
+    four, the two batch shapes extraction uses) pays for what a new size costs (MIOpen picks and loads its kernels for every
+    (size, scale, batch)); two later lists (``mid`` / ``long`` per size, both long enough for a graph per
     size: one eager batch, one capture, replays) differ only in replays, which gives the steady state."""
     import tempfile
     from mdir_amd.datasets import ImagesFromList, initialize_transforms
@@ -265,7 +266,7 @@ def measure_list(arch="resnet101", workers=8, short=4, mid=40, long=64):
     # of two such timings -- the steady state between captures -- swings with the box and is a derived estimate only
     return {"value": round(nl / times["warm_long"], 2), "unit": "descriptors/s",
             "what": "extract_vectors_device on a whole list of %d JPEG files of %d sizes (%s, 3 scales + whitening), %d loader "
-                    "threads, start to finish, after the process has seen every size once (graph captures of this list included)"
+                    "threads, start to finish, after the process has seen every (size, batch) once (graph captures of this list included)"
                     % (nl, len(LIST_SHAPES), arch, workers),
             "ms_per_image": round(1e3 * times["warm_long"] / nl, 3),
             "steady_state_estimate": {"descriptors_per_s": round(1.0 / steady, 2),

@@ -71,6 +71,9 @@ rows = [
      "%s / %s / %s ms, bit-identical %s" % (f(g(sec, "configs2_one_evaluation", "in_place_ms")), f(g(sec, "configs2_one_evaluation", "index_build_plus_multiply_ms")),
                                            f(g(sec, "configs2_one_evaluation", "resident_index_ms")), g(sec, "configs2_one_evaluation", "bit_identical_to_the_index_route")),
      "`secondary_configs.configs2_one_evaluation`"),
+    ("ONE whole evaluation on resident descriptors, wall clock (product in place + mAP): default route / literal route",
+     "%s / %s ms" % (f(g(sec, "configs2_one_evaluation", "evaluation_ms_default_route"), "%.2f"), f(g(sec, "configs2_one_evaluation", "evaluation_ms_literal_route"), "%.2f")),
+     "`secondary_configs.configs2_one_evaluation`, `profiles/r04_eval_path.md`"),
     ("exact top-100 of 1 M x 70 (serving form)", "%s ms" % f(g(sec, "configs2_top100", "topk_ms")), "`secondary_configs.configs2_top100`"),
     ("whitening learning, float64: Gram / projection (D = 2048, n = 20 000)", "%s ms = %s of the f64 MFMA peak / %s ms = %s"
      % (f(g(sec, "whitening_learning_f64", "gram_ms"), "%.2f"), f(g(sec, "whitening_learning_f64", "roofline_gram", "frac")),
