@@ -554,8 +554,9 @@ int mdx_scores_rowmajor(const float *db, int64_t n, int64_t d, const float *quer
 {
     MDX_CHECK_ARG(db && queries && scores, "mdx_scores_rowmajor: NULL pointer");
     MDX_CHECK_ARG(n > 0 && nq > 0, "mdx_scores_rowmajor: n=%lld nq=%lld must be positive", (long long)n, (long long)nq);
-    MDX_CHECK_ARG(d >= 4 && d % 4 == 0 && ((uintptr_t)db & 15) == 0,
-                  "mdx_scores_rowmajor: d=%lld must be a multiple of 4 and the matrix 16-byte aligned (rows are read in 16-byte pieces); "
+    // 16-byte LDS-DMA pieces are served from any 4-byte-aligned address (tools/align_probe.py: bit-exact at every offset)
+    MDX_CHECK_ARG(d >= 4 && d % 4 == 0 && ((uintptr_t)db & 3) == 0,
+                  "mdx_scores_rowmajor: d=%lld must be a multiple of 4 (rows are read in pieces of four values) and the matrix 4-byte aligned; "
                   "build an index for other shapes", (long long)d);
     MDX_CHECK_ARG(qlayout == MDX_DIM_MAJOR || qlayout == MDX_ROW_MAJOR, "mdx_scores_rowmajor: qlayout %d", qlayout);
     const int64_t need = mdx_scores_workspace(nq, d);

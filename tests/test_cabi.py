@@ -132,7 +132,7 @@ def test_late_round4_entry_points_check_their_arguments():
     ws = h.mdx_scores_workspace(70, 2048)
     assert h.mdx_scores_rowmajor(None, 10, 8, P(16), 1, 1, None, P(16), P(16), ws, None) == -1 and b"NULL" in h.mdx_last_error()
     assert h.mdx_scores_rowmajor(P(16), 10, 30, P(16), 1, 1, None, P(16), P(16), ws, None) == -1 and b"multiple of 4" in h.mdx_last_error()
-    assert h.mdx_scores_rowmajor(P(24), 10, 32, P(16), 1, 1, None, P(16), P(16), ws, None) == -1           # not 16-byte aligned
+    assert h.mdx_scores_rowmajor(P(18), 10, 32, P(16), 1, 1, None, P(16), P(16), ws, None) == -1           # not 4-byte aligned
     assert h.mdx_scores_rowmajor(P(16), 10, 32, P(16), 70, 1, None, P(16), P(16), 8, None) == -4            # workspace too small
     # an fp32 shard of 1 004 993 x 2048: 62 816 row tiles x 128 k-blocks of 1 KiB + the cell of its maximum
     assert h.mdx_index_bytes(1004993, 2048, 0) == 62816 * 128 * 1024 + 256

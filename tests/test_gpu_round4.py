@@ -659,6 +659,22 @@ def test_scores_rowmajor_refuses_what_it_cannot_read_in_16_byte_pieces():
         ops.scores_rowmajor(x, torch.zeros((3, 30), device=DEV), "ND")
 
 
+@pytest.mark.parametrize("offset", [1, 2, 3])
+def test_scores_rowmajor_from_a_matrix_at_4_byte_alignment(offset):
+    """A view into a larger buffer (rows start at any multiple of 4 bytes): the 16-byte LDS-DMA pieces are served all the same."""
+    from mdir_amd import ops
+    rng = np.random.default_rng(offset)
+    n, d, nq = 40001, 64, 21
+    db = (rng.standard_normal((n, d)) / 8).astype(np.float32)
+    qv = (rng.standard_normal((nq, d)) / 8).astype(np.float32)
+    base = torch.zeros(n * d + 8, device=DEV)
+    view = base[offset:offset + n * d].view(n, d)
+    view.copy_(dev(db))
+    assert view.data_ptr() % 16 == 4 * offset
+    want = OC.scores_chain(np.ascontiguousarray(db.T), np.ascontiguousarray(qv.T))
+    np.testing.assert_array_equal(ops.scores_rowmajor(view, dev(qv), "ND").cpu().numpy(), want)
+
+
 def test_ranking_beyond_the_packed_formats_limit():
     """n > 2^24 rows: ids no longer fit the 24 bits of the packed intermediate words, the sort takes its (key word, id word)
     passes for real (tests elsewhere force them on small n).  Exact full ranking, top-k and rank positions of a 16.8 M-row
