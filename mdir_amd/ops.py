@@ -417,7 +417,11 @@ class DescriptorIndex:
         if getattr(self, "_h", None) is not None and self._h.value:
             h, self._h = self._h, None
             check(_lib.lib().mdx_index_destroy(h), "mdx_index_destroy")
-            self._tiles = None          # back to the pool (kernels still reading it are ordered before its next use by the stream)
+            # back to the pool -- after every kernel that may still read the tiles, on whatever stream it was launched
+            # (what the library's own hipFree guaranteed by being device-synchronous; here without its ~100 ms)
+            if self._tiles is not None and self._tiles.is_cuda:
+                torch.cuda.synchronize(self._tiles.device)
+            self._tiles = None
 
     def __del__(self):
         try:
