@@ -141,14 +141,33 @@ class _Positions:
         ``compute_ap`` / ``compute_map`` (evaluate.py:3-37, :85-106) is kept, in its order: the terms are the same
         expressions elementwise, each query's AP is the left-to-right sum of its terms (``np.cumsum``), the means add up
         in query order -- bit-identical to the per-query statement (tests/test_evaluate.py)."""
-        nq = len(gnd)
         empty = np.empty(0, dtype=np.int64)
         oks = [np.asarray(g["ok"], dtype=np.int64).reshape(-1) for g in gnd]
         nok = [len(o) for o in oks]
         junks = [np.asarray(g["junk"], dtype=np.int64).reshape(-1) if ("junk" in g and n) else empty for g, n in zip(gnd, nok)]
+        order, valid_s = self._flat()[2], self._flat()[5]
+        return self._map_of_masks(self._mark(oks)[order] & valid_s, self._mark(junks)[order] & valid_s, nok, kappas)
+
+    def map_levels(self, gnd, ok_keys, junk_keys, kappas=()):
+        """:meth:`map` for the revisited protocol's levels (evaluate.py:123-147: ``ok`` = the concatenation of ``gnd[q][k]``
+        for k in ``ok_keys``, ``junk`` likewise): the membership of every fetched id in ``easy`` / ``hard`` / ``junk`` is
+        looked up once and the three levels combine the masks."""
+        if getattr(self, "_key_masks", None) is None:
+            self._key_masks = {}
+        order, valid_s = self._flat()[2], self._flat()[5]
+        for k in tuple(ok_keys) + tuple(junk_keys):
+            if k not in self._key_masks:
+                self._key_masks[k] = self._mark([np.asarray(g[k], dtype=np.int64).reshape(-1) for g in gnd])[order] & valid_s
+        nok = [sum(len(np.asarray(g[k]).reshape(-1)) for k in ok_keys) for g in gnd]
+        ok_s = np.logical_or.reduce([self._key_masks[k] for k in ok_keys])
+        junk_s = np.logical_or.reduce([self._key_masks[k] for k in junk_keys])
+        return self._map_of_masks(ok_s, junk_s, nok, kappas)
+
+    def _map_of_masks(self, ok_s, junk_s, nok, kappas):
+        """The arithmetic of :meth:`map` on membership masks over the (query, position)-ordered pairs (junk of a query
+        without positives is never looked at: the query is skipped)."""
+        nq = len(nok)
         _, _, order, q_s, pos_s, valid_s, starts = self._flat()
-        ok_s = self._mark(oks)[order] & valid_s
-        junk_s = self._mark(junks)[order] & valid_s
         jcum = np.cumsum(junk_s)
         before = jcum - junk_s                                                  # junk strictly earlier in the whole array
         base = np.where(starts[:-1] > 0, jcum[np.maximum(starts[:-1], 1) - 1], 0) if len(jcum) else np.zeros(nq, dtype=np.int64)
@@ -312,8 +331,9 @@ _LEVELS = (("easy", ("easy",), ("junk", "hard")),
            ("hard", ("hard",), ("junk", "easy")))
 
 
-def _evaluate(dataset, gnd, kappas, one_map):
-    """Protocol dispatch shared by the ranking- and the scores-based entry points."""
+def _evaluate(dataset, gnd, kappas, one_map, positions=None):
+    """Protocol dispatch shared by the ranking- and the scores-based entry points (``positions``: a :class:`_Positions` of
+    this ``gnd`` -- the revisited protocol's levels then share its membership masks)."""
     if "ok" in gnd[0]:  # old protocol (evaluate.py:117-120)
         m, aps, _, _ = one_map(gnd, [])
         print(">> {}: mAP {:.2f}".format(dataset, np.around(m * 100, decimals=2)))
@@ -321,7 +341,10 @@ def _evaluate(dataset, gnd, kappas, one_map):
     if dataset.startswith("roxford5k") or dataset.startswith("rparis6k"):  # evaluate.py:123-152
         avg, per, mpr = {}, {}, {}
         for level, ok_keys, junk_keys in _LEVELS:
-            m, aps, pr, _ = one_map(_protocol_gnd(gnd, ok_keys, junk_keys), list(kappas))
+            if positions is not None:
+                m, aps, pr, _ = positions.map_levels(gnd, ok_keys, junk_keys, list(kappas))
+            else:
+                m, aps, pr, _ = one_map(_protocol_gnd(gnd, ok_keys, junk_keys), list(kappas))
             avg["map_" + level], per["ap_" + level], mpr[level] = m, aps, pr
         r = lambda v: np.around(v * 100, decimals=2)
         print(">> {}: mAP E: {}, M: {}, H: {}".format(dataset, r(avg["map_easy"]), r(avg["map_medium"]),
@@ -336,10 +359,10 @@ def compute_map_and_print(dataset, ranks, gnd, kappas=[1, 5, 10]):
     """``(averages, per_query)`` dicts with the reference's keys (evaluate.py:114-152).  A ranking on the GPU is searched
     once for every labelled id (all protocol levels share the positions)."""
     positions = _Positions(gnd, lambda lists: positions_in_ranking(ranks, lists)) if _is_device_tensor(ranks) else None
-    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map(ranks, g, k, _positions=positions))
+    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map(ranks, g, k, _positions=positions), positions)
 
 
 def compute_map_and_print_from_scores(dataset, scores, gnd, kappas=[1, 5, 10]):
     """Same as :func:`compute_map_and_print`, from device scores ``[Q,N]`` (one counting pass for all protocol levels)."""
     positions = _score_positions(scores, gnd)
-    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map_from_scores(scores, g, k, _positions=positions))
+    return _evaluate(dataset, gnd, kappas, lambda g, k: compute_map_from_scores(scores, g, k, _positions=positions), positions)

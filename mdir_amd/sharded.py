@@ -547,7 +547,7 @@ def sharded_retrieval_map(net, images, qimages, bbxs, gnd, dataset, image_size, 
 
     # every labelled id of every protocol level is ranked ONCE (one counting pass per shard + one collective), then looked up
     positions = _positions_of_rows(len(images), gnd, positions_of)
-    result = _evaluate(dataset, gnd, [1, 5, 10], lambda g, kappas: positions.map(g, kappas))
+    result = _evaluate(dataset, gnd, [1, 5, 10], lambda g, kappas: positions.map(g, kappas), positions)
     if lap:
         lap("compute_score")
     return result

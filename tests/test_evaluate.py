@@ -186,3 +186,47 @@ def test_vectorised_map_on_fetched_positions_is_bit_identical_to_the_per_query_s
             continue
         for a, b in zip(want, got):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_protocol_levels_on_shared_masks_equal_the_concatenated_lists():
+    """`_Positions.map_levels` (easy / hard / junk memberships looked up once, the three levels of evaluate.py:123-147
+    combine the masks) against `map` on the concatenated lists and against the host statement -- ids shared between keys,
+    duplicates, ids without a position, queries without positives."""
+    from mdir_amd import evaluate as E
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        n, nq = int(rng.integers(20, 400)), int(rng.integers(1, 8))
+        ranks = np.stack([rng.permutation(n) for _ in range(nq)], axis=1)
+        gnd = []
+        for q in range(nq):
+            g = {k: rng.integers(-1, n + 2, size=int(rng.integers(0, 9))).astype(np.int64) for k in ("easy", "hard", "junk")}
+            if rng.random() < 0.3 and len(g["easy"]):
+                g["junk"] = np.concatenate([g["junk"], g["easy"][:1]])
+            if rng.random() < 0.2:
+                g["easy"], g["hard"] = g["easy"][:0], g["hard"][:0]
+            gnd.append(g)
+
+        def fetch(lists):
+            out = []
+            for q, ids in enumerate(lists):
+                inv = {int(v): i for i, v in enumerate(ranks[:, q])}
+                out.append(np.array([inv.get(int(x), -1) for x in ids], dtype=np.int64))
+            return out
+
+        for _, ok_keys, junk_keys in E._LEVELS:
+            level = E._protocol_gnd(gnd, ok_keys, junk_keys)
+
+            def run(f):
+                try:
+                    return f()
+                except (ValueError, ZeroDivisionError) as exc:
+                    return type(exc).__name__
+            want = run(lambda: E.compute_map(ranks, level, [1, 5, 10]))
+            a = run(lambda: E._Positions(gnd, fetch).map(level, [1, 5, 10]))
+            b = run(lambda: E._Positions(gnd, fetch).map_levels(gnd, ok_keys, junk_keys, [1, 5, 10]))
+            if isinstance(want, str):
+                assert a == want and b == want
+                continue
+            for x, y, z in zip(want, a, b):
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(z))
