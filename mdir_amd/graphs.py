@@ -68,6 +68,12 @@ class ShapeGraphs:
         self.captures = 0
         self.max_graphs = max_graphs or int(os.environ.get("MDIR_AMD_MAX_GRAPHS", "32"))
         self.graphs = collections.OrderedDict()
+        # ONE memory pool for all captures of this object (MDIR_AMD_GRAPH_SHARED_POOL=0: a private pool per graph).  The
+        # graphs are replayed one after the other on one stream, a graph's intermediates are dead when its replay ends and its
+        # input / output tensors stay allocated, so a later capture may live in the memory an earlier one used in between:
+        # 16 image sizes x 2 batch shapes of a ResNet101 pyramid reserve the largest graph's memory instead of the sum
+        # (tools/extract_mem_probe.py)
+        self.pool = torch.cuda.graph_pool_handle() if os.environ.get("MDIR_AMD_GRAPH_SHARED_POOL", "1") != "0" and torch.cuda.is_available() else None
         self.seen = collections.Counter()
         self.refused = set()
         self.replays = 0
@@ -94,7 +100,7 @@ class ShapeGraphs:
 
     def _capture(self, x, key):
         while len(self.graphs) >= self.max_graphs:
-            self.graphs.popitem(last=False)          # frees that graph's private memory pool
+            self.graphs.popitem(last=False)          # frees that graph (and, without the shared pool, its private memory pool)
         entry = _Entry()
         entry.static_in = x.clone()
         entry.graph = torch.cuda.CUDAGraph()
@@ -102,7 +108,7 @@ class ShapeGraphs:
             # thread_local: the loader's pin-memory thread and RCCL's watchdog thread keep making HIP
             # calls (host allocations, event queries) while this thread captures; only calls made by
             # the capturing thread itself may invalidate the capture
-            with torch.cuda.graph(entry.graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(entry.graph, pool=self.pool, capture_error_mode="thread_local"):
                 entry.static_out = self.fn(entry.static_in)
         except Exception as err:                     # keep extracting eagerly; never silently change results
             torch.cuda.synchronize()
