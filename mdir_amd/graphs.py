@@ -66,7 +66,7 @@ class ShapeGraphs:
         self.warmup = warmup
         self.upcoming = None               # images of the current shape still to come, if the caller knows (else None)
         self.captures = 0
-        self.max_graphs = max_graphs or int(os.environ.get("MDIR_AMD_MAX_GRAPHS", "32"))
+        self.max_graphs = max_graphs or int(os.environ.get("MDIR_AMD_MAX_GRAPHS", "64"))   # with the shared pool a graph costs its input + output tensors
         self.graphs = collections.OrderedDict()
         # ONE memory pool for all captures of this object (MDIR_AMD_GRAPH_SHARED_POOL=0: a private pool per graph).  The
         # graphs are replayed one after the other on one stream, a graph's intermediates are dead when its replay ends and its
