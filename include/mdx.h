@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 1
+/* 2: round 4's additions (mdx_index_bytes, mdx_index_create_in, mdx_scores_rowmajor, mdx_scores_ex / _workspace_ex,
+ * mdx_rank_positions) and the stream synchronisation inside mdx_index_create* for fp32 shards (the shard maximum is read
+ * back): a host built against version 1 must not load this library unnoticed. */
+#define MDX_ABI_VERSION 2
 
 typedef enum mdx_status {
     MDX_OK = 0,

@@ -28,6 +28,7 @@ class MdxError(RuntimeError):
 _STATUS_EXC = {-1: ValueError, -2: MdxError, -3: MemoryError, -4: ValueError}
 
 _lib = None
+ABI_VERSION = 2        # include/mdx.h MDX_ABI_VERSION this binding was written against
 
 
 def build(force=False):
@@ -131,8 +132,9 @@ def lib():
         import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         _declare(handle)
-        if handle.mdx_abi_version() != 1:
-            raise MdxError("libmdx.so ABI version %d, expected 1" % handle.mdx_abi_version())
+        if handle.mdx_abi_version() != ABI_VERSION:
+            raise MdxError("libmdx.so ABI version %d, this package binds version %d (include/mdx.h MDX_ABI_VERSION): rebuild "
+                           "with `make -C mdir_amd/csrc`" % (handle.mdx_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

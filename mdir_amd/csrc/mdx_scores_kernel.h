@@ -31,6 +31,9 @@ __host__ __device__ __forceinline__ int64_t shard_tile(int64_t rt, int64_t kb, i
 #ifndef MDX_XCD_BLOCKS
 #define MDX_XCD_BLOCKS 1
 #endif
+// sixteen zero bytes in device memory: what the row-major loader reads for k >= d (a padded chunk multiplied real row values
+// by the zero query tiles before: 0 * Inf = NaN where np.dot has Inf -- ADVICE round 4)
+__device__ __attribute__((aligned(16))) float mdx_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 #ifdef MDX_XCD_BLOCKS_RUNTIME        // tools/split_ablate.hip: both orders in one process
 __device__ int mdx_xcd_blocks_flag = 1;
 #endif
@@ -116,7 +119,7 @@ struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e
 // 16 rt + j at k = 16 kb + 4 c, so a tile's KiB in LDS holds element w of lane (c, j) = k 4 c + w -- the tile format with the
 // roles of lane group and element swapped.  The consumers put "their" operand together from four 4-byte reads 64 lanes
 // apart (two ds_read2st64_b32; 64 different banks): lane (g, j), element t = k 4 t + g, as before -- same MFMAs, same k order,
-// same bits.  Rows >= n read row n-1 (never stored), a chunk past k = ld the row's last one (the query tiles are zero there).
+// same bits.  Rows >= n read row n-1 (never stored), a piece past k = ld reads mdx_zero16 (zeros, as the tiled shard holds there).
 template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0, int CWAVES = 4, bool RM = false>
 __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                 if constexpr (RM) {
                     if (is_db) {
                         const int64_t k = (int64_t)c * KC * TILE_K + rm_k[t];
-                        p = (const f32x4 *)((const float *)src[t] + (k + 4 <= ld ? k : ld - 4));
+                        p = k + 4 <= ld ? (const f32x4 *)((const float *)src[t] + k) : (const f32x4 *)mdx_zero16;
                     }
                 }
                 if (DB_AUX != 0 && is_db)

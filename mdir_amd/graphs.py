@@ -95,6 +95,11 @@ class ShapeGraphs:
         entry.static_in.copy_(x, non_blocking=True)
         entry.graph.replay()
         self.replays += 1
+        # INVARIANT of the shared pool: `static_out` is valid only until the next replay of ANY graph of this pool (replay
+        # order is LRU, not capture order: an earlier graph's intermediates may occupy the memory a later graph's output
+        # lives in).  It holds because static_in is allocated outside the pool, everything runs on ONE stream and the output
+        # is cloned here, on that stream, before anything else is replayed -- never return static_out itself or read it
+        # from another stream (tests/test_gpu_round5.py replays in reverse capture order against eager).
         out = entry.static_out
         return out.clone() if isinstance(out, torch.Tensor) else type(out)(o.clone() for o in out)
 

@@ -19,7 +19,11 @@ MFMA: 0.75 of the exact kernel's time, scores within 2e-6 of it; ``"split2"``: t
 block floating point, 0.63 of the exact kernel's time, same bound for data of ordinary dynamic range; default ``"exact"`` =
 the k-ordered fp32 chain).
 """
+import gzip
+import json
+import lzma
 import os.path
+from collections import OrderedDict
 
 from . import ops
 from .datasets import configdataset, get_data_root, initialize_transforms
@@ -29,18 +33,47 @@ from .scenario import StopWatch, path_join
 from .trace import range_
 
 
-def _read_table(path, keys):
-    """TSV/CSV with a header row; list-valued cells are JSON (daan file_readers.py:100-130)."""
-    import csv
-    import json
-    with open(path, newline="") as handle:
-        rows = list(csv.DictReader(handle, delimiter="\t" if path.endswith(".tsv") else ","))
-    out = {k: [] for k in keys}
-    for row in rows:
-        for k in keys:
-            cell = row[k]
-            out[k].append(json.loads(cell) if cell[:1] in "[{" else cell)
-    return out
+_TABLE_SUFFIXES = (".tsv", ".tsv.gz", ".tsv.xz", ".csv", ".csv.gz", ".csv.xz")
+
+
+def _cell(value):
+    """``GenericReader.str2collection`` (daan/data/file_readers.py:89-98): an empty cell is None, a cell bracketed
+    on BOTH ends by [] or {} is JSON, everything else stays the string it is."""
+    if not value:
+        return None
+    if (value[0], value[-1]) in {("[", "]"), ("{", "}")}:
+        return json.loads(value)
+    return value
+
+
+def _read_table(path, keys=None):
+    """Columns of a .tsv/.csv table (optionally .gz/.xz), as ``initialize_file_reader(path, keys=keys).get()`` returns them
+    (daan/data/file_readers.py:101-135,243-252).  The reader is restated with its plain-split semantics, not ``csv``:
+    the separator is a tab iff one of the last two dot-separated path pieces is "tsv" (:111), the header line is stripped
+    on both sides (:115), data lines lose only their "\n" (:126), so a "\r" or a quote character stays in the cell; a key
+    absent from the header is ``list.index``'s ValueError (:120), a short line an IndexError (:128).  An unreadable path is
+    a ValueError as in ``GenericReader.open`` (:68-76) -- without its 1 + 8 + 27 seconds of retries."""
+    base, suffix = path.rsplit(".", 1)
+    if suffix in ("gz", "xz"):
+        suffix = base.rsplit(".", 1)[1]
+    if suffix not in ("tsv", "csv"):
+        raise ValueError("Suffix '%s' is not supported ('%s')" % (suffix, path))
+    assert path.endswith(_TABLE_SUFFIXES), path
+    separator = "\t" if "tsv" in path.rsplit(".", 2) else ","
+    fopen = lzma.open if path.endswith(".xz") else gzip.open if path.endswith(".gz") else open
+    try:
+        handle = fopen(path, "rb")
+    except (FileNotFoundError, OSError, EOFError):
+        raise ValueError("Error with path '%s' (try %s)" % (path, 1))
+    with handle:
+        header = next(handle).decode("utf8").strip().split(separator)
+        indexes = [header.index(x) for x in keys] if keys else list(range(len(header)))
+        columns = [[] for _ in indexes]
+        for line in handle:
+            cells = line.decode("utf8").strip("\n").split(separator)
+            for column, j in zip(columns, indexes):
+                column.append(_cell(cells[j]))
+    return OrderedDict(zip([header[i] for i in indexes], columns))
 
 
 class CirDatasetAp:

@@ -72,8 +72,14 @@ def _eigh_descending(M):
     ``np.linalg.eig`` and sorts (whiten.py:23-26, :47-49): on a symmetric matrix the same decomposition, but LAPACK's
     general solver takes 10.3 s for 2048 x 2048 on the host (89 % of one whitening learning, tools/whitenlearn_bench.py)
     where the symmetric solver next to the data takes 0.06 s.  Eigenvectors are defined up to sign either way (the tests
-    compare rows of P up to sign; whitened dot products do not see it)."""
-    w, v = torch.linalg.eigh(M)
+    compare rows of P up to sign; whitened dot products do not see it).  With REPEATED eigenvalues the two solvers may return
+    different (equally valid) bases of the shared eigenspace, so P can then differ from the reference's by more than row
+    signs; P.T @ P -- all that distances between whitened descriptors depend on -- is the same.  A failure of the solver is
+    raised as the reference's callers expect it (mdir/stages/whiten.py catches ``np.linalg.LinAlgError``)."""
+    try:
+        w, v = torch.linalg.eigh(M)
+    except RuntimeError as e:               # torch's _LinAlgError is a RuntimeError
+        raise np.linalg.LinAlgError(str(e)) from e
     return torch.flip(w, [0]), torch.flip(v, [1])
 
 

@@ -335,6 +335,7 @@ def main():
                                for c in overlay],
                    "list_merge_raises": list_err, "three_way": three, "metadata": meta_out}, f, indent=1)
     make_next_rows()
+    make_tables()
     print("golden fixtures written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-28s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))
@@ -470,6 +471,52 @@ def make_next_rows():
         g15["case%d_out" % ci] = dsl[0]
         g15["case%d_spec" % ci] = np.array([repr((name, imsize, bbx))])
     np.savez_compressed(os.path.join(HERE, "g15_loader.npz"), **g15)
+
+
+def make_tables():
+    """G16: the TSV/CSV dataset branch of CirDatasetAp (mdir/components/optim/score/cirscore.py:24-38) -- what
+    daan/data/file_readers.py's TsvReader returns for small tables (empty cells, bracketed and half-bracketed cells, "\r",
+    quotes, .gz/.xz, csv), and the lists CirDatasetAp.__init__ builds from a db/queries pair."""
+    import base64
+    import gzip
+    import lzma
+    from daan.data.file_readers import initialize_file_reader
+    from mdir.components.optim.score.cirscore import CirDatasetAp
+    queries = ("query\tbbx\tok\tjunk\tnote\n"
+               "q/a.jpg\t[1, 2, 30, 40]\t[\"x.jpg\", \"y.jpg\"]\t[]\tfirst\n"
+               "q/b.jpg\t\t[\"z.jpg\"]\t[\"x.jpg\"]\t \n"
+               "q/c.jpg\t[]\t[\"w.jpg\",\"x.jpg\"]\t[\"y.jpg\",\"z.jpg\"]\t\"quoted, cell\"\n")
+    db = "identifier,width\nx.jpg,640\ny.jpg,\nz.jpg,480\nw.jpg,[1\n"
+    odd = (" name\tvalue\tlast \n"                      # header stripped on both sides
+           "a\t{\"k\": [1, 2]}\t{}\n"
+           "b\t[1, 2\t2]\n"                             # bracketed on one side only: stays a string
+           "c\t{\"k\": 1}]\tplain\r\n"                  # mismatched pair; "\r" survives strip("\n")
+           "\t3.5\ttrue\n")                             # empty first cell; numbers and literals stay strings
+    files = {"queries.tsv": queries.encode(), "db.csv": db.encode(), "odd.tsv": odd.encode(),
+             "queries.tsv.gz": gzip.compress(queries.encode(), mtime=0), "db.csv.xz": lzma.compress(db.encode()),
+             "tsv.v2.csv": b"a,b\tc\n1,2\t3\n"}          # separator rule: "tsv" among the last two dot pieces -> tab
+    reads = [("queries.tsv", ["query", "bbx", "ok", "junk"]), ("queries.tsv", None), ("db.csv", ["identifier"]),
+             ("db.csv", None), ("odd.tsv", None), ("odd.tsv", ["last", "name"]), ("queries.tsv.gz", ["junk", "query"]),
+             ("db.csv.xz", ["width", "identifier"]), ("tsv.v2.csv", None)]
+    g16 = {"files": {k: base64.b64encode(v).decode() for k, v in files.items()}, "reads": [], "datasets": []}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, data in files.items():
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(data)
+        for name, keys in reads:
+            with initialize_file_reader(os.path.join(tmp, name), keys=keys) as reader:
+                got = reader.get()
+            g16["reads"].append({"file": name, "keys": keys, "columns": list(got.keys()), "out": list(got.values())})
+        for qname, dbname in (("queries.tsv", "db.csv"), ("queries.tsv.gz", "db.csv.xz")):
+            score = CirDatasetAp({"image_size": 64, "transforms": "pil2np | totensor | normalize",
+                                  "mean_std": [[0.4, 0.4, 0.4], [0.2, 0.2, 0.2]],
+                                  "dataset": {"name": "toy", "imgdir": "/img", "queries": os.path.join(tmp, qname),
+                                              "db": os.path.join(tmp, dbname)}})
+            g16["datasets"].append({"queries": qname, "db": dbname, "name": score.dataset, "images": score.images,
+                                    "qimages": score.qimages, "bbxs": [list(b) if b else None for b in score.bbxs],
+                                    "gnd": score.gnd})
+    with open(os.path.join(HERE, "g16_tables.json"), "w") as f:
+        json.dump(g16, f, indent=1)
 
 
 def _jsonable(o):
