@@ -100,11 +100,11 @@ def plant_positives(rows, lo, hi, gnd, qid, device):
                     rows[i - lo] = v / v.norm()
 
 
-def cpu_baseline(vecs_dn_host, qvecs_host):
+def cpu_baseline(vecs_dn_host, qvecs_host, reps=3):
     """The reference's two ranking statements through the numpy oracle, host cores."""
     from oracle import oracle as O
     dots, sorts = [], []
-    for _ in range(3):               # median of 3 (SURVEY.md section 8d)
+    for _ in range(reps):            # median of 3 (SURVEY.md section 8d)
         t0 = time.perf_counter()
         sc = O.scores(vecs_dn_host, qvecs_host)
         t1 = time.perf_counter()
@@ -127,6 +127,32 @@ def cpu_dot_three_threads(vecs_dn_host, qvecs_host):
         t0 = time.perf_counter()
         O.scores(vecs_dn_host, qvecs_host)
         return time.perf_counter() - t0
+
+
+def spread(values, digits=4):
+    """min / median / max of the per-step figures of the timed region (>= 20 timed reps, median)."""
+    v = np.asarray(values, dtype=np.float64)
+    return {"min": round(float(v.min()), digits), "median": round(float(np.median(v)), digits), "max": round(float(v.max()), digits)}
+
+
+def committed_traffic():
+    """The newest committed PMC summary (profiles/rNN_traffic.json: FETCH_SIZE x2 + WRITE_SIZE per launch, separate rocprofv3
+    --pmc passes, tools/profile_round.sh).  NOT measured in the bench run; a summary taken with other kernel sources is
+    reported as stale and its figure dropped.  Returns (file's dict, similarity bytes per launch, ranking bytes, sources)."""
+    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not tf:
+        return {}, None, None, None, None
+    whole = json.load(open(tf[-1]))
+    name = os.path.relpath(tf[-1], ROOT)
+    src = "committed PMC summary %s (not measured in this run)" % name
+    traffic, rank_traffic, rank_src = whole.get("scores_kernel_hbm_bytes_per_launch"), ranking_traffic(whole), src
+    prof = whole
+    if whole.get("scores_kernel_source_sha16") != scores_source_sha16():
+        traffic, prof = None, {}
+        src += ": STALE (similarity kernel sources changed since; re-profile with tools/profile_round.sh)"
+    if whole.get("rank_source_sha16") not in (None, rank_source_sha16()):
+        rank_traffic, rank_src = None, rank_src + ": STALE (mdx_rank.hip changed since)"
+    return prof, traffic, src, rank_traffic, rank_src
 
 
 def scores_source_sha16():
@@ -335,13 +361,17 @@ def main():
             if i is not None:
                 ev[i][2].record()
     else:
-        ev = []
+        ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(args.steps)]
         keep = {}
 
         sharded.reuse_buffers = True           # the loop keeps only the newest result: one receive buffer per chunk
 
         def step(i=None):
+            if i is not None:
+                ev[i][0].record()
             keep["rk"], keep["sc"], keep["q"] = sharded.rank_queries(qvecs, "DN")
+            if i is not None:
+                ev[i][1].record()
 
     for _ in range(args.warmup):
         step()
@@ -351,7 +381,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i if world == 1 else None)
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -381,17 +411,9 @@ def main():
         algo_bytes = 4.0 * n_total * DIM + 4.0 * NQ * DIM + 4.0 * NQ * n_total
         # HBM traffic is NOT measured in this run: it is the per-launch PMC figure (FETCH_SIZE x2 + WRITE_SIZE, separate
         # rocprofv3 --pmc passes, tools/profile_round.sh) of the newest committed profile -- named in traffic_source
-        traffic, traffic_source, prof = None, None, {}
-        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-        if tf:
-            prof = json.load(open(tf[-1]))
-            traffic = prof.get("scores_kernel_hbm_bytes_per_launch")
-            traffic_source = "committed PMC summary %s (not measured in this run)" % os.path.relpath(tf[-1], ROOT)
-            # a profile of ANOTHER kernel says nothing about this one: the summary records the hash of the similarity
-            # kernel's sources it was taken with (tools/summarize_profile.py); any other hash nulls the figure
-            if prof.get("scores_kernel_source_sha16") != scores_source_sha16():
-                traffic, prof = None, {}
-                traffic_source += ": STALE (similarity kernel sources changed since; re-profile with tools/profile_round.sh)"
+        # a profile of ANOTHER kernel says nothing about this one: the summary records the hash of the similarity
+        # kernel's sources it was taken with (tools/summarize_profile.py); any other hash nulls the figure
+        prof, traffic, traffic_source, rank_traffic, rank_src = committed_traffic()
         full_tiles, tail = divmod(NQ, 16)
         if n_total >= 32768 and 0 < tail <= 8 and full_tiles >= 1:
             kernel = "mdx::scores_lc_kernel<QT=%d,R=2,QR=1>: %d query tiles on v_mfma_f32_16x16x4 + the last %d queries on " \
@@ -414,18 +436,18 @@ def main():
             roofline["frac_of_peak_at_profiled_clock"] = round(achieved / (PEAK_F32_MFMA_TFLOPS * ghz / 2.4), 4)
         extra["roofline"] = roofline
         extra["rank_ms_per_step"] = round(rank_ms, 4)
+        # how noisy THIS run was: the three HIP events of every timed step (one process's q/s swings +-2.5 % between processes
+        # with the device's power state; the headline `value` stays steps / wall time)
+        step_ms = [a.elapsed_time(c) for a, _, c in ev]
+        extra["spread_over_timed_steps"] = {
+            "kernel_ms": spread([a.elapsed_time(b) for a, b, _ in ev]), "rank_ms": spread([b.elapsed_time(c) for _, b, c in ev]),
+            "step_ms": spread(step_ms), "value": spread([NQ / (t * 1e-3) for t in step_ms], 1), "steps": args.steps,
+            "what": "HIP events on the launch stream around the similarity and the ranking of every timed step"}
         extra["step_ms_minus_kernels"] = round(elapsed / args.steps * 1e3 - kernel_ms - rank_ms, 4)     # host / launch gaps: ~0
         # the second kernel family of the step: np.argsort(-scores, axis=0) (cirscore.py:70) as a 4-pass LSD radix sort.
         # HBM-bound; algorithmic bytes = the argsort itself (4 B read + 8 B written per element), traffic = what
         # the four passes really move (committed PMC summary, like the similarity kernel's)
         rank_algo = 12.0 * NQ * n_total
-        rank_traffic = rank_src = None
-        if tf:
-            whole = json.load(open(tf[-1]))
-            rank_traffic = ranking_traffic(whole)
-            rank_src = "committed PMC summary %s (not measured in this run)" % os.path.relpath(tf[-1], ROOT)
-            if whole.get("rank_source_sha16") not in (None, rank_source_sha16()):
-                rank_traffic, rank_src = None, rank_src + ": STALE (mdx_rank.hip changed since)"
         extra["roofline_rank"] = {
             "kernel": "mdx::sort_hist_kernel / sort_scan_kernel / sort_scatter_kernel x 4 passes (8-bit LSD radix, packed intermediates)",
             "bound": "hbm", "achieved": round(rank_algo / (rank_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -482,10 +504,22 @@ def main():
             per_rank_tf.append(round(2.0 * NQ * (rh - rl) * DIM / (t_s * 1e-3) / 1e12, 2) if t_s > 0 else None)
             per_rank_gbs.append(round(12.0 * qb * n_total / (t_r * 1e-3) / 1e9, 1) if t_r > 0 and qb else None)
         tf_ok = [x for x in per_rank_tf if x]
+        # HBM traffic per rank: the committed single-GPU PMC figure scaled by the shard's share of the rows (the kernel streams
+        # its rows once, the traffic is linear in them: 1.007x algorithmic at N = 1 M) -- derived, labelled, not measured here
+        _, t1, t1_src, r1, r1_src = committed_traffic()
+        n_big = max(_sb(n_total, world, r)[1] - _sb(n_total, world, r)[0] for r in range(world))
+        q_big = -(-NQ // world)
+        n_prof = N_ROXFORD + N_DISTRACTORS
+        traffic_rank = round(t1 * n_big / n_prof, 1) if t1 else None
+        traffic_sort = round(r1 * (q_big * n_total) / (NQ * n_prof), 1) if r1 else None
         if tf_ok:
             extra["roofline"] = {"kernel": "mdx::scores_lc_kernel (fp32 MFMA 16x16x4 [+ 4x4x1 leftover]; 4 MFMA + 4 LDS-DMA loader waves), per rank on its shard",
                                  "bound": "mfma", "achieved": min(tf_ok), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU (slowest rank)",
-                                 "frac": round(min(tf_ok) / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "per_rank_achieved": per_rank_tf,
+                                 "frac": round(min(tf_ok) / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic_rank,
+                                 "traffic_source": (t1_src + "; x %d / %d rows: the largest shard's share of the single-GPU launch" % (n_big, n_prof)) if t1_src else None,
+                                 "algorithmic_flops_per_rank": 2.0 * NQ * n_big * DIM,
+                                 "algorithmic_bytes_per_rank": 4.0 * n_big * DIM + 4.0 * NQ * DIM + 4.0 * NQ * n_big,
+                                 "per_rank_achieved": per_rank_tf,
                                  "kernel_ms_per_rank": [round(float(x), 4) for x in table[:, 0]],
                                  "what": "HIP events on each rank's compute stream around the similarity kernels of the last timed step "
                                          "(chunked shards: the sum of the chunks' launches)"}
@@ -493,8 +527,13 @@ def main():
         if gb_ok:
             extra["roofline_rank"] = {"kernel": "mdx::sort_* x 4 passes over the peer blocks (mdx_rank_full_segments), per rank on its queries",
                                       "bound": "hbm", "achieved": min(gb_ok), "peak": PEAK_HBM_GBS, "unit": "GB/s per GPU (slowest rank)",
-                                      "frac": round(min(gb_ok) / PEAK_HBM_GBS, 4), "traffic": None, "per_rank_achieved": per_rank_gbs,
+                                      "frac": round(min(gb_ok) / PEAK_HBM_GBS, 4), "traffic": traffic_sort,
+                                      "traffic_source": (r1_src + "; x (%d x %d) / (%d x %d) elements" % (q_big, n_total, NQ, n_prof)) if r1_src else None,
+                                      "per_rank_achieved": per_rank_gbs,
                                       "algorithmic_bytes_per_rank": [12.0 * ((NQ // world) + (1 if r < NQ % world else 0)) * n_total for r in range(world)]}
+        step_ms = [a.elapsed_time(b) for a, b in ev]
+        extra["spread_over_timed_steps"] = {"step_ms": spread(step_ms), "value": spread([NQ / (t * 1e-3) for t in step_ms], 1), "steps": args.steps,
+                                            "what": "rank 0: HIP events on its compute stream around every timed step (similarity, exchange wait, sort)"}
         extra["comm"] = "mdx (C ABI: mdx_exchange_scores over RCCL)" if getattr(sharded, "_comm", None) is not None else "torch.distributed"
         extra["phases_ms_per_rank"] = {"scores": [round(float(x), 4) for x in table[:, 0]],
                                        "exchange_exposed": [round(float(x), 4) for x in table[:, 1]],
@@ -566,6 +605,43 @@ def main():
             del vecs_host, rk_cpu
         except Exception as exc:          # the reported baseline must not cost the measured line
             extra["cpu_baseline"] = {"value": None, "unit": "queries/s", "error": "%s: %s" % (type(exc).__name__, exc)}
+
+    if world > 1 and not args.no_cpu_baseline:
+        # The CPU reference beside an N > 1 line too (a SCALE line without it reads as unmeasured): after the timed region rank
+        # 0 regenerates the WHOLE database (block-seeded rows: the same bits the shards hold), runs the reference's two
+        # statements ONCE on the host cores (bounded: one repetition instead of the single-GPU line's median of 3) and checks the
+        # job's mAP against the CPU path's; the other ranks wait at the barrier (their host threads idle).
+        if rank == 0:
+            try:
+                full = gen_rows(0, n_total, device)
+                plant_positives(full, 0, n_total, gnd, qid, device)
+                vecs_host = full.t().contiguous().cpu().numpy()       # reference layout [D,N]
+                del full
+                _, rk_cpu, t_dot, t_sort = cpu_baseline(vecs_host, qvecs.cpu().numpy(), reps=1)
+                import multiprocessing
+                with contextlib.redirect_stdout(sys.stderr):
+                    avg_cpu, _ = compute_map_and_print("roxford5k", rk_cpu, gnd)
+                extra["cpu_baseline"] = {
+                    "value": round(NQ / (t_dot + t_sort), 3), "unit": "queries/s",
+                    "cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else multiprocessing.cpu_count(),
+                    "kind": "port",
+                    "sample": "full workload, ONE repetition on rank 0's host cores while the other %d ranks wait: np.dot %.2f s (BLAS, all "
+                              "cores) + np.argsort %.2f s (1 thread), N=%d Q=%d D=%d fp32" % (world - 1, t_dot, t_sort, n_total, NQ, DIM)}
+                extra["map_medium_cpu"] = avg_cpu["map_medium"]
+                # same statement as the single-GPU line: BLAS order vs the k-ordered chain may swap rows inside near-ties only
+                assert abs(avg_cpu["map_medium"] - extra["map_medium"]) <= 1e-5, (avg_cpu["map_medium"], extra["map_medium"])
+                extra["map_equals_cpu_path"] = bool(avg_cpu["map_medium"] == extra["map_medium"])
+                # rank 0's queries: the head of its rows of the sharded ranking against the CPU ranking's columns
+                rk0, (q0lo, q0hi) = keep["rk"], keep["q"]
+                if q0hi > q0lo:
+                    head = rk0[:, :100].t().cpu().numpy()
+                    extra["cpu_top100_id_agreement"] = round(float((rk_cpu[:100, q0lo:q0hi] == head).mean()), 6)
+                del vecs_host, rk_cpu
+            except AssertionError:
+                raise
+            except Exception as exc:          # the reported baseline must not cost the measured line
+                extra["cpu_baseline"] = {"value": None, "unit": "queries/s", "error": "%s: %s" % (type(exc).__name__, exc)}
+        dist.barrier()
 
     if rank == 0 and world == 1 and not args.no_secondary:
         # BASELINE.json's other single-GPU configurations, timed beside the headline (side legs: they cannot cost the
@@ -783,8 +859,10 @@ def main():
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic" + (" (DRY RUN: all ranks on one GPU over gloo -- not a measurement)" if dryrun else ""),
-                "config": {"workload": "configs[2]: roxford5k+1M synthetic distractors, N=%d Q=%d D=%d, "
-                                       "similarity + exact full ranking per step" % (n_total, NQ, DIM),
+                "config": {"workload": ("configs[2]: roxford5k+1M synthetic distractors, N=%d Q=%d D=%d, "
+                                        "similarity + exact full ranking per step" % (n_total, NQ, DIM)) if world == 1 else
+                                       ("configs[3]: the configs[2] database (N=%d Q=%d D=%d) row-sharded x%d, exchange of the per-shard partial "
+                                        "scores over %s, query-split exact full ranking per step" % (n_total, NQ, DIM, world, "gloo (dry run)" if dryrun else "RCCL/xGMI")),
                            "db_rows_per_gpu": n_local, "parallelism": "db-row-shard x%d, query-split sort" % world,
                            "index_build_s": round(build_s, 4)}}
         line.update(extra)

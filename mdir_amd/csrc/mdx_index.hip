@@ -141,6 +141,9 @@ __global__ __launch_bounds__(256) void retile_block_kernel(const float *__restri
 // for shards of >= 32 768 rows; R = 1 (64-row workgroups) below, so that small shards still
 // spread over the CUs -- measured crossover, tools/scores_ablate.hip.
 constexpr int LC_KC = 2, LC_NSTAGE = 3;
+#ifndef MDX_SCORES_PIPE_DEFAULT
+#define MDX_SCORES_PIPE_DEFAULT 1      // profiles/r05_scores_schedule.md: -1.0 ... -1.2 % (bit-equal); MDX_SCORES_PIPE=0 keeps the round-4 schedule
+#endif
 
 // > 64 KiB of dynamic LDS needs an opt-in per kernel and device: done once, not on every launch
 static int lds_opt_in(const void *kern, int lds, bool *done)
@@ -158,12 +161,25 @@ template <int QT, int R, typename MM, int QR = 0, bool RM = false>
 static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
                             int KB, int nq_valid, hipStream_t s, int passes = 1, int64_t ld = 0)
 {
-    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR, 4, RM>;   // 2 = non-temporal database stream
     constexpr int lds = LC_NSTAGE * (QT + QR + 4 * R) * LC_KC * 1024;
+    const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
+    if constexpr (MM::STEPS == 4 && !RM && R == 2) {
+        // the pipelined consumer (PIPE): MDX_SCORES_PIPE=0/1 picks the form per launch (A/B in one process: tools/chain_power_probe.py)
+        const char *e = getenv("MDX_SCORES_PIPE");
+        if (e ? e[0] == '1' : MDX_SCORES_PIPE_DEFAULT) {
+            auto kp = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR, 4, RM, true>;
+            static bool opted_p[64];
+            int rcp = lds_opt_in((const void *)kp, lds, opted_p);
+            if (rcp != MDX_OK) return rcp;
+            hipLaunchKernelGGL(kp, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
+                               (unsigned long long *)nullptr, ld);
+            return MDX_OK;
+        }
+    }
+    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR, 4, RM>;   // 2 = non-temporal database stream
     static bool opted[64];
     int rc = lds_opt_in((const void *)kern, lds, opted);
     if (rc != MDX_OK) return rc;
-    const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
                        (unsigned long long *)nullptr, ld);
     return MDX_OK;

@@ -120,7 +120,14 @@ struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e
 // roles of lane group and element swapped.  The consumers put "their" operand together from four 4-byte reads 64 lanes
 // apart (two ds_read2st64_b32; 64 different banks): lane (g, j), element t = k 4 t + g, as before -- same MFMAs, same k order,
 // same bits.  Rows >= n read row n-1 (never stored), a piece past k = ld reads mdx_zero16 (zeros, as the tiled shard holds there).
-template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0, int CWAVES = 4, bool RM = false>
+//
+// PIPE = true (fp32 tiles, KC = 2; round 5, the f64 GEMM's schedule of mdx_gram.hip): the consumer keeps TWO register sets of
+// operands.  The operands of k-block 1 are read while k-block 0 multiplies; the stage hand-over -- lgkmcnt(0), the raw
+// s_barrier B_{c+1}, the reads of the next stage's k-block 0 -- sits in front of the LAST step (k 12-15) of a stage's last
+// k-block: the 8 + 8 MFMAs that follow need nothing from the new stage, so the matrix pipe runs through the barrier and through
+// the LDS round trip that otherwise opens every chunk.  Same MFMAs, same k order per output: same bits.
+template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0, int CWAVES = 4, bool RM = false,
+          bool PIPE = false>
 __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
                                                            float *__restrict__ out, int64_t n, int KB,
@@ -234,6 +241,90 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     unsigned long long t_wait = 0, t_work = 0, ts0 = 0, ts1 = 0;      // STAMPS: diagnostic build only
     unsigned long long tr0 = 0, tc0 = 0;
     if (STAMPS) { tr0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory"); tc0 = ts0; }
+    if constexpr (PIPE) {
+        static_assert(MM::STEPS == 4 && KC == 2 && !RM && !STAMPS, "pipelined consumer: fp32 tiles, two k-blocks per stage");
+        // Registers: a full second operand set does not fit beside the accumulators and the leftover operands (128 registers per
+        // wave at two workgroups per CU), so only what a block's FIRST MFMAs need is read ahead -- its database operands bn[] and
+        // query tile 0 (an0); query tiles 1.. are read into a[1..] during the previous block's last step, each right after the
+        // last MFMA that used the register's old contents (that step multiplies tile 0 LAST, the next block's first step tile 0
+        // FIRST: every read has >= 8 MFMAs = 256 cycles to come back).
+        f32x4 a[QT > 0 ? QT : 1], b[R], bn[R], an0;
+        f32x4 al[4], bl[4];
+        constexpr int PIN = 0x0002 | 0x0004 | 0x0070 | 0x0380 | 0x0400;
+        auto read_first = [&](const f32x4 *slot, int kb) __attribute__((always_inline)) {
+            const f32x4 *bs = slot + (QTILES + wave * R * KC) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < R; ++r) bn[r] = bs[(r * KC + kb) * 64];
+            an0 = slot[kb * 64 + lane];
+        };
+        auto read_left = [&](const f32x4 *slot, int kb) __attribute__((always_inline)) {
+            if constexpr (QR != 0) {
+                const f32x4 *ql = slot + (QT * KC + kb) * 64 + l_q;
+                const f32x4 *bw = slot + (QTILES + wave * R * KC + kb) * 64 + l_boff;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { al[g] = ql[16 * g]; bl[g] = bw[16 * g]; }
+            }
+        };
+        // One k-block.  `late` (in front of the last step): at a stage's end the hand-over, else nothing; then `nslot`/`nkb` = where
+        // the NEXT block's operands lie (nullptr: no next block).  `first_here`: the next block's bn / an0 are read after step 0
+        // (same stage: its tiles are there already) instead of inside `late`.
+        auto block = [&](const f32x4 *nslot, int nkb, bool first_here, auto late) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = bn[r];
+            a[0] = an0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t == 3) { __builtin_amdgcn_sched_barrier(0); late(); __builtin_amdgcn_sched_barrier(0); }
+                const int n_small = QR == 0 ? 0 : (t == 0 ? 0 : (t == 3 ? 8 : 4));
+                int done = 0, issued = 0;
+#pragma unroll
+                for (int qq = 0; qq < QT; ++qq) {
+                    const int q = t == 3 ? (qq + 1) % QT : qq;          // last step: tile 0 last
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[r][q] = MM::step(t, a[q], b[r], acc[r][q]);
+                        __builtin_amdgcn_sched_barrier(PIN);
+                        ++issued;
+                        if constexpr (QR != 0) {
+                            const int due = (issued * n_small) / (R * QT);
+#pragma unroll
+                            for (; done < due; ++done) {
+                                const int st = (t == 3 && done >= 4) ? 3 : t - 1, g = done & 3;
+                                accl = __builtin_amdgcn_mfma_f32_4x4x1f32(al[g][st], bl[g][st], accl, 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(PIN);
+                            }
+                        }
+                    }
+                    if (t == 3 && q != 0 && nslot) {                    // a[q] is dead: the next block's tile q
+                        __builtin_amdgcn_sched_barrier(0);
+                        a[q] = nslot[(q * KC + nkb) * 64 + lane];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (t == 0 && first_here) { __builtin_amdgcn_sched_barrier(0); read_first(nslot, nkb); __builtin_amdgcn_sched_barrier(0); }
+            }
+        };
+        __builtin_amdgcn_s_barrier();                                       // B_0
+        read_first(ring, 0);
+#pragma unroll
+        for (int q = 1; q < QT; ++q) a[q] = ring[(q * KC) * 64 + lane];
+        for (int c = 0; c < nchunks; ++c) {
+            const f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
+            const f32x4 *next = ring + ((c + 1) % NSTAGE) * (STAGE_TILES * 64);
+            const bool more = c + 1 < nchunks;
+            read_left(slot, 0);
+            block(slot, 1, true, []() {});
+            read_left(slot, 1);
+            block(more ? next : nullptr, 0, false, [&]() __attribute__((always_inline)) {
+                if (more) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): every read of this stage is back
+                    __builtin_amdgcn_s_barrier();                           // B_{c+1}: the next stage has landed; this one may be refilled
+                    read_first(next, 0);
+                }
+            });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else
     for (int c = 0; c < nchunks; ++c) {
         __builtin_amdgcn_s_barrier();                                       // B_c
         __builtin_amdgcn_sched_barrier(0);

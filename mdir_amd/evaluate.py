@@ -230,9 +230,7 @@ def positions_in_ranking(ranks, id_lists):
     lists.  One int64 array per query aligned with ``id_lists[q]`` (non-negative, unique), -1 where absent."""
     from . import ops
     rows = ranks.t()
-    if rows.shape[1] == 1:
-        rows = rows.reshape(-1, 1)          # one-row database: any stride describes it; make it the contiguous [Q,1]
-    elif rows.stride(1) != 1:
+    if rows.shape[1] != 1 and rows.stride(1) != 1:      # (a one-row database: [Q,1], whatever the stride of its only column)
         rows = rows.contiguous()
     pos, off = ops.rank_positions(rows, id_lists)
     pos = pos.cpu().numpy()

@@ -560,7 +560,7 @@ def rank_positions(ranks, id_lists):
     occur in row q) and the CSR offsets.  ``np.arange(N)[np.in1d(ranks[:, q], ids)]`` of evaluate.py:80-81 in one pass."""
     if not (isinstance(ranks, torch.Tensor) and ranks.is_cuda and ranks.dtype == torch.int64 and ranks.dim() == 2):
         raise ValueError("ranks: a 2-d int64 CUDA tensor [Q, N]")
-    if ranks.stride(1) != 1:
+    if ranks.shape[1] != 1 and ranks.stride(1) != 1:        # (the stride of a one-element row means nothing)
         raise ValueError("ranks: every query's row must be contiguous (pass the [Q, N] matrix, not a copy of its transpose)")
     nq, n = ranks.shape
     if len(id_lists) != nq:

@@ -95,7 +95,7 @@ def test_shared_pool_graphs_replayed_in_reverse_capture_order():
     for i in order:
         x = torch.randn(shapes[i], device=DEV)
         kept.append((x, sg(x)))
-    assert sg.replays == len(order) + 0 and sg.captures == len(shapes)
+    assert sg.replays == len(shapes) + len(order) and sg.captures == len(shapes)      # a capture is followed by its first replay
     torch.cuda.synchronize()
     for x, (a, b) in kept:                                               # outputs survive later replays (they are clones)
         ea, eb = fn(x)
@@ -130,3 +130,52 @@ def test_eigh_failure_is_numpy_linalgerror():
     except np.linalg.LinAlgError:
         return
     assert torch.isnan(w).all()         # some solver builds return NaNs instead of raising: nothing to convert then
+
+
+# ---------------------------------------------------------------- configs[3]: eight ranks of the real kernels (dry run on one GPU)
+
+def _bench(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, text=True,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert proc.returncode == 0, (proc.stdout[-2000:], proc.stderr[-4000:])
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def one_rank_line():
+    return _bench(["--rows", "200000", "--steps", "3", "--warmup", "1", "--no-secondary", "--no-pipelined", "--extract-images", "0"], {})
+
+
+@pytest.mark.parametrize("form", ["all_to_all", "all_gather", "all_to_all_chunks2"])
+def test_bench_with_eight_ranks_on_one_gpu(form, one_rank_line):
+    """`bench.py --gpus 8` as the driver will launch it, here with all eight rank processes on this GPU over gloo
+    (MDIR_AMD_DRYRUN_ONE_GPU: functional, never a measurement): the real kernels on eight shards, the query-split exchange
+    (default), the literal all-gather of partial scores, and the chunked exchange -- each gives the single-process mAP, names
+    configs[3], carries roofline + cpu_baseline + the per-step spread, and every rank's rows of the ranking verify on the device."""
+    env = {"MDIR_AMD_DRYRUN_ONE_GPU": "1"}
+    if form == "all_gather":
+        env["MDIR_AMD_EXCHANGE"] = "allgather"
+    if form == "all_to_all_chunks2":
+        env["MDIR_AMD_EXCHANGE_CHUNKS"] = "2"
+    line = _bench(["--gpus", "8", "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-secondary", "--extract-images", "0"], env)
+    one = one_rank_line
+    assert line["n_gpus"] == 8 and line["nranks_seen"] == 8 and "DRY RUN" in line["data"]
+    assert line["config"]["workload"].startswith("configs[3]") and "x8" in line["config"]["workload"]
+    assert one["config"]["workload"].startswith("configs[2]")
+    assert line["config"]["db_rows_per_gpu"] == 25000
+    assert line["map_medium"] == one["map_medium"]
+    assert line["phases_ms_per_rank"]["exchange"] == ("all_gather" if form == "all_gather" else "all_to_all")
+    assert line["phases_ms_per_rank"]["chunks"] == (2 if form == "all_to_all_chunks2" else 1)
+    assert len(line["phases_ms_per_rank"]["scores"]) == 8 and "ranking_verified_on_device" in line
+    for ln in (line, one):
+        assert ln["roofline"]["bound"] == "mfma" and ln["roofline"]["frac"] > 0 and "traffic" in ln["roofline"]
+        assert ln["cpu_baseline"]["value"] > 0 and ln["cpu_baseline"]["kind"] == "port" and ln["cpu_baseline"]["cores"] >= 1
+        assert abs(ln["map_medium_cpu"] - ln["map_medium"]) <= 1e-5
+        sp = ln["spread_over_timed_steps"]
+        assert sp["steps"] == 3 and sp["step_ms"]["min"] <= sp["step_ms"]["median"] <= sp["step_ms"]["max"]
+        assert sp["value"]["min"] <= sp["value"]["median"] <= sp["value"]["max"]
+    assert set(one["spread_over_timed_steps"]) >= {"kernel_ms", "rank_ms", "step_ms", "value"}
+    assert line["roofline"]["algorithmic_flops_per_rank"] == 2.0 * 70 * 25000 * 2048
