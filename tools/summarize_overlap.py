@@ -1,0 +1,110 @@
+"""gpurun_out/overlap_r05 (tools/overlap_trace.sh) -> profiles/r05_overlap.md: where the sort's launches sit in time when
+they are queued on a second stream beside the next batch's similarity kernel."""
+import csv
+import os
+import re
+import statistics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "overlap_r05")
+out = os.path.join(ROOT, "profiles", "r05_overlap.md")
+
+
+def short(k):
+    return re.sub(r"scores_lc_kernel<.*", "scores_lc_kernel", k.replace("mdx::", ""))
+
+
+def load(st):
+    rows = list(csv.DictReader(open(os.path.join(SRC, "trace_nstage%d.csv" % st))))
+    for r in rows:
+        r["s"], r["e"] = int(r["start_ns"]), int(r["end_ns"])
+    return rows
+
+
+def piped_steps(rows):
+    """Similarity launches that have a sort kernel of ANOTHER queue running at their start: the piped arrangement."""
+    sims = [r for r in rows if "scores_lc" in r["kernel"]]
+    steps = []
+    for i, sim in enumerate(sims[:-1]):
+        inside = [r for r in rows if r["queue"] != sim["queue"] and "sort_" in r["kernel"] and r["s"] < sim["e"] and r["e"] > sim["s"]]
+        if not inside:
+            continue
+        after = [r for r in rows if r["queue"] != sim["queue"] and "sort_" in r["kernel"] and sim["e"] <= r["s"] < sims[i + 1]["s"]]
+        steps.append((sim, inside, after, sims[i + 1]))
+    return steps
+
+
+def timings(name):
+    t = {"serial": [], "piped": []}
+    for line in open(os.path.join(SRC, name)):
+        m = re.match(r"(serial|piped)\s+([\d.]+) ms/step", line)
+        if m:
+            t[m.group(1)].append(float(m.group(2)))
+    return t
+
+
+READING = """## Reading
+
+The sort IS dispatched beside the similarity kernel -- and starves.  Its first histogram and scan get through while the
+similarity grid ramps up (3-4x their own duration), then `sort_scatter_kernel<0>` sits for the WHOLE similarity launch: a few of
+its workgroups become resident whenever a CU happens to hold fewer than two similarity workgroups, and the launch completes
+~25 us after the similarity kernel's last workgroup has gone.  The remaining three passes (~0.6 ms) then run alone.  A batch costs
+`similarity + 0.6-0.65 ms` instead of `similarity + 0.84`, minus what the co-running launches take from the similarity
+kernel (2.75-2.86 ms in the trace against 2.66 alone): 3.44 against 3.48 ms, the +1 % of the bench leg.
+
+It is NOT the LDS (the verdict's hypothesis): with a two-stage ring two similarity workgroups leave 56 KiB per CU, enough for a
+44-KiB scatter workgroup -- and the picture is the same.  It is the REGISTER FILE: the similarity kernel's waves hold 124 -> 128
+VGPRs each, and its two workgroups per CU are 16 waves = 4 per SIMD x 128 = all 512 registers of every SIMD's file.  No wave of
+any other kernel fits on a CU that runs two similarity workgroups, whatever its LDS need.  (The loader waves use a fraction of
+their allocation, but a kernel's waves are all allocated alike.)
+
+What would make room costs the similarity kernel what the overlap could return: ONE workgroup per CU (8 consumer + 4 loader waves:
+3 x 128 registers per SIMD, one wave slot of <= 128 registers free) was measured at the same speed alone in round 3, but then the
+sort's 8-wave workgroups still only get one wave per SIMD = a quarter of the scatter's own rate, and the similarity kernel is
+power-limited (1.97-2.0 GHz): every byte the sort moves beside it comes out of its clock.  Partitioning CUs (a CU-masked stream
+for the sort) is zero-sum for an MFMA-bound kernel: 32 CUs to the sort = +14 % similarity time (3.04 ms) for a sort that then runs
+at an eighth of the chip.  The arithmetic bound the verdict quotes (12.7 GB per batch / 6.3 TB/s = 2.0 ms < 2.65 ms of MFMA time)
+needs the two kernels to share CUs at full occupancy each, which the register file forbids.
+
+**Decision**: the `pipelined_two_streams` leg is removed from bench.py (it measured +0.2 ... +1 %); the headline stays the
+one-stream step.  The probe-only two-stage similarity kernel (`MDX_SCORES_NSTAGE=2`) existed for this measurement only and is
+not in the library.
+"""
+
+with open(out, "w") as f:
+    f.write("# r05: why the two-stream form gains nothing (VERDICT round 4, item 4)\n\n"
+            "`tools/overlap_trace.sh`: `tools/overlap_run.py` (bench.py's former `pipelined_two_streams` leg: the ranking of batch k on a\n"
+            "second stream while the similarity of batch k+1 runs; N = 1 004 993, Q = 70, D = 2048) under `rocprofv3 --kernel-trace`\n"
+            "and again without the profiler, with the shipped similarity kernel (3-stage ring: 2 x 78 KiB of a CU's 160 KiB LDS) and with\n"
+            "a probe-only 2-stage ring (2 x 52 KiB: the LDS-residency hypothesis of the verdict).  Rankings identical in all arrangements.\n\n"
+            "## Wall clock, ms per batch (no profiler; two measurements each)\n\n| similarity ring | serial (one stream) | piped (two streams) |\n|---|---|---|\n")
+    for st in (3, 2):
+        t = timings("plain_nstage%d.log" % st)
+        f.write("| %d stages (%d KiB per workgroup) | %s | %s |\n" % (st, 26 * st, " / ".join("%.3f" % x for x in t["serial"]), " / ".join("%.3f" % x for x in t["piped"])))
+    f.write("\n## Where the sort's twelve launches run (kernel trace, one piped batch from the middle of the run)\n\n")
+    for st in (3, 2):
+        rows = load(st)
+        # the usual batch: histogram, scan and scatter of pass 0 beside the similarity kernel, the other nine launches after it (the tenth
+        # launch before the next similarity kernel is the next batch's first histogram)
+        steps = [(a, b, sorted(c, key=lambda r: r["s"])[:9], d) for a, b, c, d in piped_steps(rows) if len(b) == 3 and len(c) == 10]
+        if not steps:
+            continue
+        sims = [r for r in rows if "scores_lc" in r["kernel"]]
+        alone = {}
+        for r in rows:          # the serial arrangement of the same process: sort launches on the similarity kernel's own queue
+            if "sort_" in r["kernel"] and r["queue"] == sims[0]["queue"]:
+                alone.setdefault(short(r["kernel"]), []).append((r["e"] - r["s"]) / 1e3)
+        sim, inside, after, nxt = steps[len(steps) // 2]
+        f.write("### %d-stage ring (similarity launch %.3f ms; %d piped batches in the trace)\n\n"
+                "| sort launch (second stream) | starts, us after the similarity kernel's start | ends | duration us | alone (serial arrangement) us |\n|---|---|---|---|---|\n"
+                % (st, (sim["e"] - sim["s"]) / 1e6, len(steps)))
+        for r in sorted(inside + after, key=lambda r: r["s"]):
+            al = alone.get(short(r["kernel"]))
+            f.write("| `%s` | %.0f | %.0f | %.0f | %s |\n" % (short(r["kernel"]), (r["s"] - sim["s"]) / 1e3, (r["e"] - sim["s"]) / 1e3, (r["e"] - r["s"]) / 1e3,
+                                                            ("%.0f" % statistics.mean(al)) if al else "-"))
+        stuck = [(r["e"] - sim["e"]) / 1e3 for x in steps for r in x[1] if "sort_scatter_kernel<0" in r["kernel"] for sim in [x[0]]]
+        tail = [(max(r["e"] for r in x[2]) - x[0]["e"]) / 1e3 for x in steps if x[2]]
+        f.write("\nOver the %d batches: the first scatter ends %.0f us (median) after the similarity kernel it was queued beside; the sort's "
+                "remaining launches then take %.0f us (median) with the chip to themselves.\n\n" % (len(steps), statistics.median(stuck), statistics.median(tail)))
+    f.write(READING)
+print(open(out).read())
