@@ -202,8 +202,10 @@ def verify_ranking(sc, rk):
 
 
 def side_legs(args, sharded, qvecs, sc, rk, ws, gnd, device, extra):
-    """Two side legs of the single-GPU run that launch the headline's kernels in other arrangements (skipped by
-    --no-pipelined / --profile: overlapped launches blur a kernel trace of the run)."""
+    """Side leg of the single-GPU run that launches the headline's similarity kernel with the sort-free evaluation (skipped by
+    --no-pipelined / --profile).  The two-stream leg of rounds 2-4 (ranking of batch k beside the similarity of batch k+1) is
+    gone: it measured +0.2 ... +1 %, and profiles/r05_overlap.md shows why -- the similarity kernel's 16 waves per CU hold every
+    SIMD's whole register file, so the sort's workgroups only become resident when it ends."""
     from mdir_amd import ops
     # the same evaluation without materialising a ranking: similarity + rank positions of the labelled
     # ids (mdx_rank_of) -- what compute_map actually needs; identical mAP (asserted above), reported beside
@@ -222,38 +224,6 @@ def side_legs(args, sharded, qvecs, sc, rk, ws, gnd, device, extra):
     extra["sort_free_map_route"] = {"value": round(NQ / t_pos, 2), "unit": "queries/s", "ms_per_step": round(t_pos * 1e3, 4),
                                     "what": "similarity + rank positions of the %d labelled ids (no full ranking), same mAP"
                                             % int(ids_t.numel())}
-    # throughput form for a stream of batches: the ranking of batch k on a second stream while the similarity of batch
-    # k+1 runs (two score / rank buffers).  Reported beside the headline, which stays the one-stream step: overlapped,
-    # the two kernels share HBM and neither's own duration is a clean roofline figure any more.
-    sc2, rk2, ws2 = torch.empty_like(sc), torch.empty_like(rk), torch.empty_like(ws)
-    bufs, side, cur = ((sc, rk, ws), (sc2, rk2, ws2)), torch.cuda.Stream(device=device), torch.cuda.current_stream(device)
-
-    def piped(steps):
-        done = [None, None]
-        for k in range(steps):
-            b = k & 1
-            if done[b] is not None:
-                cur.wait_event(done[b])            # the ranking that read this score buffer two batches ago is finished
-            sharded.index.scores(qvecs, "DN", out=bufs[b][0])
-            ready = torch.cuda.Event()
-            ready.record(cur)
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                ops.rank_full(bufs[b][0], out=bufs[b][1], workspace=bufs[b][2])
-                done[b] = torch.cuda.Event()
-                done[b].record(side)
-        cur.wait_stream(side)
-    piped(4)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    piped(args.steps)
-    torch.cuda.synchronize()
-    t_pipe = (time.perf_counter() - t1) / args.steps
-    assert bool((rk2 == rk).all())
-    extra["pipelined_two_streams"] = {"value": round(NQ / t_pipe, 2), "unit": "queries/s", "ms_per_step": round(t_pipe * 1e3, 4),
-                                      "what": "same kernels and work per batch; ranking of batch k overlapped with the similarity "
-                                              "of batch k+1 on a second stream (not the headline: see bench.py)"}
-    del sc2, rk2, ws2
 
 
 def launch_ranks(n):
@@ -287,8 +257,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] side legs")
     ap.add_argument("--extract-images", type=int, default=40,
                     help="images PER SIZE (16 sizes) of the (untimed) descriptors/sec leg: ResNet101-GeM, 3 scales + whitening; 0 = skip")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-stream throughput leg and the sort-free leg (side legs "
-                    "that launch the same kernels overlapped: they blur a kernel trace of the run)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the sort-free evaluation leg (name kept from the rounds that also had a "
+                    "two-stream leg here)")
     ap.add_argument("--profile", action="store_true", help="the headline loop only: --no-cpu-baseline --no-secondary --no-pipelined --extract-images 0")
     ap.add_argument("--comm", choices=("torch", "mdx"), default=None,
                     help="N > 1: the exchange of partial scores through torch.distributed (default) or through the C-ABI communicator "

@@ -266,7 +266,7 @@ int mdx_scores(const mdx_index *index, const float *queries, int64_t nq, int qla
  * evaluation (cirscore.py:69) -- read where it lies: db [n, d] row-major fp32 on the device, no index, no second copy of it
  * (an index of 1 M x 2048 is another 8.2 GB and 3 ms of re-tiling).  Same kernels, same k order: the scores are bit-identical
  * to mdx_scores on an index of the same rows.  d must be a multiple of 4 (rows are fetched in pieces of four values, from any
- * 4-byte-aligned address; MDX_ERR_ARG otherwise: build an index).  queries / center / scores / workspace (mdx_scores_workspace(nq, d)) as
+ * 4-byte-aligned address; MDX_ERR_INVALID otherwise: build an index).  queries / center / scores / workspace (mdx_scores_workspace(nq, d)) as
  * in mdx_scores. */
 int mdx_scores_rowmajor(const float *db, int64_t n, int64_t d, const float *queries, int64_t nq, int qlayout,
                         const float *center, float *scores, void *workspace, int64_t workspace_bytes, void *stream);

@@ -163,18 +163,6 @@ static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_
 {
     constexpr int lds = LC_NSTAGE * (QT + QR + 4 * R) * LC_KC * 1024;
     const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
-    if constexpr (MM::STEPS == 4 && !RM && R == 2 && QT == 4 && QR == 1) {
-        // probe only (tools/overlap_trace.sh, profiles/r05_overlap.md): the 70-query kernel with a TWO-stage ring -- 52 KiB per
-        // workgroup, so that two of them leave 56 KiB of a CU's LDS to a co-resident sort workgroup (44 KiB)
-        const char *e2 = getenv("MDX_SCORES_NSTAGE");
-        if (e2 && e2[0] == '2') {
-            auto k2 = scores_lc_kernel<QT, R, LC_KC, 2, 2, false, MM, QR, 4, RM, true>;
-            constexpr int lds2 = 2 * (QT + QR + 4 * R) * LC_KC * 1024;
-            hipLaunchKernelGGL(k2, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds2, s, db, qt, out, n, KB, nq_valid,
-                               (unsigned long long *)nullptr, ld);
-            return MDX_OK;
-        }
-    }
     if constexpr (MM::STEPS == 4 && !RM && R == 2) {
         // the pipelined consumer (PIPE): MDX_SCORES_PIPE=0/1 picks the form per launch (A/B in one process: tools/chain_power_probe.py)
         const char *e = getenv("MDX_SCORES_PIPE");

@@ -1,4 +1,6 @@
-// The similarity kernel of libmdx.so (also built into tools/scores_ablate.hip for measurements).
+// The similarity kernel of libmdx.so.  (The MDX_ABL_* / MDX_SHARD_BLOCKED / STAMPS switches below are timing-only forms that the
+// ablation harnesses of rounds 2-4 built -- tools/scores_ablate.hip, tools/split_ablate.hip, in the history at commit 47a9fe2; the
+// library is built without any of them.)
 #pragma once
 #include "mdx_common.h"
 

@@ -1,0 +1,124 @@
+"""What ONE rank does per step at G = 8 (n_local = 125 625 of 1 004 993 rows, 9 of 70 queries), measured on one GPU with the
+real kernels; the exchange cannot run here (one GPU per box) and enters as a stated model.  Writes the table of
+profiles/r05_g8_budget.md.
+
+    python tools/g8_budget.py [--md profiles/r05_g8_budget.md]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from mdir_amd import ops
+from mdir_amd.sharded import chunk_bounds, exchange_chunks, shard_bounds
+
+N, NQ, D, G = 1004993, 70, 2048, 8
+dev = torch.device("cuda:0")
+
+
+def timed(fn, reps=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    lo, hi = shard_bounds(N, G, 0)
+    n_local = hi - lo
+    rows = torch.randn((n_local, D), generator=g, device=dev)
+    rows /= rows.norm(dim=1, keepdim=True)
+    q = rows[torch.randperm(n_local, device=dev)[:NQ]].contiguous()
+    qlo, qhi = shard_bounds(NQ, G, 0)
+    nq_mine = qhi - qlo
+    out = []
+    # --- similarity of the shard: one launch, and the shard cut into chunks (each chunk its own index and launch, as ShardedIndex does)
+    cuts = {"1 launch": [(0, n_local)],
+            "2 chunks, halving (4/6, 2/6: chunk_bounds)": [(a - lo, b - lo) for a, b in chunk_bounds(lo, hi, 2)],
+            "2 chunks, equal": [(0, n_local // 2), (n_local // 2, n_local)],
+            "2 chunks, first = one full round of 512 workgroups (65 536 rows)": [(0, 65536), (65536, n_local)],
+            "3 chunks, halving (4/7, 2/7, 1/7)": [(a - lo, b - lo) for a, b in chunk_bounds(lo, hi, 3)]}
+    sims = {}
+    for name, pieces in cuts.items():
+        ixs = [ops.DescriptorIndex(rows[a:b].contiguous(), "ND") for a, b in pieces]
+        scs = [torch.empty((NQ, b - a), dtype=torch.float32, device=dev) for a, b in pieces]
+        per = [timed(lambda ix=ix, sc=sc: ix.scores(q, "ND", out=sc)) for ix, sc in zip(ixs, scs)]
+
+        def all_chunks():
+            for ix, sc in zip(ixs, scs):
+                ix.scores(q, "ND", out=sc)
+        sims[name] = (timed(all_chunks), per, [b - a for a, b in pieces])
+        for ix in ixs:
+            ix.close()
+    # --- the sort of this rank's 9 queries over all N rows, read from the peer blocks in place (8 x chunks segments)
+    sorts = {}
+    full = torch.randn((nq_mine, N), generator=g, device=dev) * 0.022
+    for chunks in (1, 2, 3):
+        widths = []
+        for r in range(G):
+            for a, b in chunk_bounds(*shard_bounds(N, G, r), chunks):
+                widths.append(b - a)
+        blocks, o = [], 0
+        for w in widths:
+            blocks.append(full[:, o:o + w].contiguous())
+            o += w
+        sorts[chunks] = timed(lambda: ops.rank_full_segments(blocks))
+    dense = timed(lambda: ops.rank_full(full))
+    # --- the exchange, MODELLED: rank r sends (Q - 9) x n_local x 4 B in 7 pieces, one per xGMI link (153 GB/s each, MI355X_MICROARCH.md)
+    sent = 4.0 * (NQ - nq_mine) * n_local
+    model = {"optimistic (0.7 of the 7 links, 30 us)": 0.03 + sent / (7 * 153e9 * 0.7) * 1e3,
+             "honest (uneven pieces, half the link rate, 80 us of RCCL launch + sync)": 0.08 + sent / (7 * 153e9 * 0.5) * 1e3,
+             "pessimistic (a quarter of the link rate, 100 us)": 0.10 + sent / (7 * 153e9 * 0.25) * 1e3}
+    one = 3.47          # the single-GPU step of this round's bench line (similarity 2.63 + ranking 0.84 ms)
+    lines = ["# r05: the G = 8 budget of one rank (VERDICT round 4, item 2c)", "",
+             "`tools/g8_budget.py` on one MI355X: rank 0's work of a step of `bench.py --gpus 8` -- the similarity of 70 queries against its "
+             "%d-row shard and the exact sort of its %d queries over all %d rows -- with the real kernels; the exchange "
+             "(%.1f MB sent per rank, one piece per peer link) is a MODEL, three of them.  Nothing here is a scaling measurement." % (n_local, nq_mine, N, sent / 1e6), "",
+             "## Similarity of the shard (fp32 chain, pipelined consumer), ms", "",
+             "| shard cut | rows per launch | workgroups per launch (512 slots) | per launch ms | all launches back to back ms |", "|---|---|---|---|---|"]
+    for name, (tot, per, sizes) in sims.items():
+        lines.append("| %s | %s | %s | %s | **%.3f** |" % (name, " / ".join(str(s) for s in sizes), " / ".join(str(-(-s // 128)) for s in sizes),
+                                                         " / ".join("%.3f" % p for p in per), tot))
+    lines += ["", "Ideal = the single-GPU launch / 8 = %.3f ms." % (2.63 / 8), "",
+              "## Sort of %d queries x %d rows (`mdx_rank_full_segments` on the peer blocks), ms" % (nq_mine, N), "",
+              "| input | ms |", "|---|---|", "| dense [9, N] (`mdx_rank_full`) | %.3f |" % dense]
+    for chunks, t in sorts.items():
+        lines.append("| %d segments (8 peers x %d chunk%s) | %.3f |" % (8 * chunks, chunks, "" if chunks == 1 else "s", t))
+    lines += ["", "Ideal = the single-GPU ranking x 9 / 70 = %.3f ms." % (0.84 * 9 / 70), "",
+              "## Step of the slowest rank and speed-up over the single-GPU step (%.2f ms), by exchange model" % one, "",
+              "One launch: step = similarity + exchange + sort (nothing overlaps).  Chunks: the transfer of chunk c runs while chunk c+1 "
+              "multiplies; exposed = what is left of the earlier transfers when the last kernel ends + the last chunk's transfer.", "",
+              "| exchange model | whole exchange ms | 1 launch: step ms (speed-up) | 2 chunks (full round first): exposed ms, step ms (speed-up) | 2 equal chunks | 3 chunks halving |", "|---|---|---|---|---|---|"]
+    for mname, t_x in model.items():
+        lat = 0.03 if "optimistic" in mname else (0.08 if "honest" in mname else 0.10)
+        cells = []
+        for key, chunks in (("1 launch", 1), ("2 chunks, first = one full round of 512 workgroups (65 536 rows)", 2), ("2 chunks, equal", 2),
+                            ("3 chunks, halving (4/7, 2/7, 1/7)", 3)):
+            tot, per, sizes = sims[key]
+            xfer = [lat + (t_x - lat) * s / n_local for s in sizes]          # every chunk pays the latency
+            busy = 0.0          # when the link is free again, relative to the start of the first kernel
+            t = 0.0
+            for k, (p, x) in enumerate(zip(per, xfer)):
+                t += p                                                    # kernel k ends
+                busy = max(busy, t) + x                                   # its transfer starts when the kernel has ended and the link is free
+            exposed = busy - t
+            step = t + exposed + sorts[chunks]
+            cells.append("%.3f exposed, %.3f (%.2fx)" % (exposed, step, one / step) if chunks > 1 else "%.3f (%.2fx)" % (step, one / step))
+        lines.append("| %s | %.3f | %s |" % (mname, t_x, " | ".join(cells)))
+    text = "\n".join(lines) + "\n"
+    print(text)
+    if "--md" in sys.argv:
+        with open(sys.argv[sys.argv.index("--md") + 1], "w") as f:
+            f.write(text)
+
+
+main()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Why does the two-stream form gain nothing?  Kernel trace of tools/overlap_run.py (serial + piped arrangements of the headline
 # kernels) with the shipped similarity kernel (3-stage ring: 2 x 78 KiB of a CU's 160 KiB LDS) and with the probe-only two-stage
-# ring (2 x 52 KiB: a 44-KiB sort workgroup fits beside them).  Summarised by tools/summarize_overlap.py -> profiles/r05_overlap.md.
+# ring (2 x 52 KiB: a 44-KiB sort workgroup fits beside them; the MDX_SCORES_NSTAGE=2 switch exists in commit 47a9fe2 only --
+# with the current library both passes run the shipped kernel).  Summarised by tools/summarize_overlap.py -> profiles/r05_overlap.md.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/overlap_r05; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for st in 3 2; do
   W=/tmp/ovl_$st; rm -rf $W

@@ -67,8 +67,8 @@ at an eighth of the chip.  The arithmetic bound the verdict quotes (12.7 GB per 
 needs the two kernels to share CUs at full occupancy each, which the register file forbids.
 
 **Decision**: the `pipelined_two_streams` leg is removed from bench.py (it measured +0.2 ... +1 %); the headline stays the
-one-stream step.  The probe-only two-stage similarity kernel (`MDX_SCORES_NSTAGE=2`) existed for this measurement only and is
-not in the library.
+one-stream step.  The probe-only two-stage similarity kernel (`MDX_SCORES_NSTAGE=2`) existed for this measurement only (commit 47a9fe2) and
+is not in the library.
 """
 
 with open(out, "w") as f:
