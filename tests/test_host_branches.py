@@ -1,0 +1,244 @@
+"""Branches of the host surface that restate a reference line and that no other test entered (profiles/r05_host_branches.md,
+VERDICT round 4 item 1b): error paths, representations, the non-default arguments of the transform / validation / network layer.
+CPU only (tests/fake_ops.py stands in for the kernels where one is reached)."""
+import copy
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import fake_ops
+
+
+@pytest.fixture()
+def fops(monkeypatch):
+    fake_ops.install(monkeypatch)
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    return fake_ops
+
+
+def test_normalize_strict_shape_argument():
+    """core_transforms.py:40-54: `strict_shape` may arrive as the string "false" from the transform DSL; non-strict takes the
+    first c means / stds of a picture with fewer channels, strict refuses it."""
+    from mdir_amd.datasets import Normalize
+    mean, std = [0.5, 0.4, 0.3], [0.2, 0.25, 0.5]
+    grey = torch.full((1, 2, 2), 0.9)
+    loose = Normalize(mean, std, strict_shape="False")
+    assert loose.strict_shape is False
+    np.testing.assert_allclose(loose(grey)[0].numpy(), np.full((1, 2, 2), (0.9 - 0.5) / 0.2), rtol=1e-6)
+    two = torch.rand(2, 3, 3)
+    np.testing.assert_allclose(loose(two)[0].numpy(), (two.numpy() - np.array(mean[:2]).reshape(2, 1, 1)) / np.array(std[:2]).reshape(2, 1, 1), rtol=1e-5)
+    with pytest.raises(AssertionError):
+        loose(torch.rand(4, 2, 2))                       # more channels than means
+    assert Normalize(mean, std, strict_shape="true").strict_shape is True and Normalize(mean, std, strict_shape=0).strict_shape is False
+    with pytest.raises(AssertionError):
+        Normalize(mean, std)(grey)
+    with pytest.raises(AssertionError):
+        Normalize(mean, std[:2])
+
+
+def test_init_cirnet_requires_its_keys_and_init_network_refuses_what_is_out_of_scope():
+    """cirnet.py:10-13 (every key of the list must be given); imageretrievalnet.py:155-164 architectures; regional pooling and
+    'rmac' are named as outside the path instead of silently building something else."""
+    from mdir_amd.network import init_cirnet
+    from mdir_amd.networks import init_network
+    full = {"cir_architecture": "alexnet", "local_whitening": False, "pooling": "gem", "regional": False, "whitening": False, "pretrained": False}
+    for key in ("local_whitening", "pooling", "regional", "whitening", "pretrained"):
+        params = dict(full)
+        del params[key]
+        with pytest.raises(ValueError, match="Key '%s' not in params" % key):
+            init_cirnet(**params)
+    net = init_cirnet(**dict(full))
+    assert net.meta["in_channels"] == 3 and net.meta["out_channels"] == net.meta["outputdim"] == 256
+    assert net.meta["mean"] == [0.485, 0.456, 0.406] and net.meta["std"] == [0.229, 0.224, 0.225]
+    with pytest.raises(ValueError, match="Unsupported or unknown architecture"):
+        init_network({"architecture": "resnet7", "pretrained": False})
+    with pytest.raises(NotImplementedError, match="regional"):
+        init_network({"architecture": "alexnet", "regional": True, "pretrained": False})
+    with pytest.raises(KeyError, match="rmac"):
+        init_network({"architecture": "alexnet", "pooling": "rmac", "pretrained": False})
+
+
+def test_network_repr_out_dim_and_local_feature_file(tmp_path, capsys):
+    """imageretrievalnet.py:117-136 (`meta_repr` in the module's repr), :291 (`meta['out_channels']`, upstream key `outputdim`),
+    :155-164 with the download replaced by a file already on disk (`features_file`, looked up in `model_dir`)."""
+    from mdir_amd.networks import _local_file, _out_dim, init_network
+    torch.manual_seed(0)
+    donor = init_network({"architecture": "alexnet", "pretrained": False})
+    text = repr(donor)
+    assert "(meta): dict(" in text and "architecture: alexnet" in text and "outputdim: 256" in text and "mean: [0.485" in text
+    assert text.rstrip().endswith(")") and "(features)" in text
+    assert _out_dim(donor) == 256
+    donor.meta["out_channels"] = 255
+    assert _out_dim(donor) == 255
+    torch.save(donor.features.state_dict(), str(tmp_path / "alexnet-features.pth"))
+    assert _local_file(None, str(tmp_path)) is None and _local_file("", str(tmp_path)) is None
+    assert _local_file(str(tmp_path / "alexnet-features.pth"), "/nowhere") == str(tmp_path / "alexnet-features.pth")
+    assert _local_file("http://example.org/models/alexnet-features.pth", str(tmp_path)) == str(tmp_path / "alexnet-features.pth")
+    assert _local_file("http://example.org/models/other.pth", str(tmp_path)) is None
+    loaded = init_network({"architecture": "alexnet", "pretrained": True, "model_dir": str(tmp_path),
+                           "features_file": "http://example.org/models/alexnet-features.pth"})
+    assert "features loaded from" in capsys.readouterr().out
+    for a, b in zip(donor.features.state_dict().values(), loaded.features.state_dict().values()):
+        assert torch.equal(a, b)
+    init_network({"architecture": "alexnet", "pretrained": True, "model_dir": str(tmp_path / "none")})
+    assert "built with random weights" in capsys.readouterr().out
+
+
+def test_forward_with_local_whitening_and_a_foreign_pooling_module(fops):
+    """imageretrievalnet.py:93-115: the local-whitening branch (:97-103: a Linear over the channel axis of every location) and a
+    pooling module the library does not know (the generic `norm(pool(o))` statement) against the statements written out in torch."""
+    from mdir_amd.layers import L2N
+    from mdir_amd.networks import ImageRetrievalNet
+    torch.manual_seed(1)
+    features = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU())
+    lwhiten = nn.Linear(8, 6)
+
+    class Pool(nn.Module):                       # not MAC / SPoC / GeM: no fused kernel for it
+        def forward(self, x):
+            return torch.nn.functional.adaptive_avg_pool2d(x.clamp(min=1e-6) ** 2, 1) ** 0.5
+
+    net = ImageRetrievalNet(features, lwhiten, Pool(), None, {"architecture": "toy", "local_whitening": True, "pooling": "custom",
+                                                              "regional": False, "whitening": False, "outputdim": 6}).eval()
+    assert net.fusable_tail() is None
+    x = torch.rand(2, 3, 9, 7)
+    with torch.no_grad():
+        got = net(x)
+        o = features(x)
+        s = o.size()
+        o = lwhiten(o.permute(0, 2, 3, 1).contiguous().view(-1, s[1])).view(s[0], s[2], s[3], 6).permute(0, 3, 1, 2)
+        want = L2N()(Pool()(o)).squeeze(-1).squeeze(-1).permute(1, 0)
+    assert tuple(got.shape) == (6, 2)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_wrapper_representations_lists_and_single_scale(fops):
+    """wrapper.py:39-41,138-139,196-197 (`__repr__`s), :94-103 (a LIST of tensors goes through the pyramid one by one and comes
+    back as a list of aggregated descriptors, :126-136), :95-96 (one scale: the tensor is passed on untouched), :44-57 base class."""
+    from mdir_amd.wrapper import CirMultiscaleAggregation, CirtorchWhiten, Compose, Wrapper, initialize_wrappers
+    ms = CirMultiscaleAggregation([1, 0.5], "cpu")
+    assert repr(ms) == "CirMultiscaleAggregation(scales=[1, 0.5])"
+    base = Wrapper("cpu")
+    t = torch.rand(1, 3, 8, 8)
+    assert base.preprocess(t, None) == (t, None) and base.postprocess(t, None, None) is t
+    rng = np.random.default_rng(0)
+    wh = CirtorchWhiten({"P": rng.standard_normal((4, 4)), "m": rng.standard_normal((4, 1))}, 3, "cpu")
+    assert repr(wh) == "CirtorchWhiten(dimensions=3)"
+    chain = Compose([wh, ms], "cpu")
+    assert repr(chain).startswith("Compose([\n    CirtorchWhiten(dimensions=3)\n    CirMultiscaleAggregation(scales=") and repr(Compose([], "cpu")) == "Compose([])"
+    # one scale: nothing is resized; the flag says whether a list came in
+    one = CirMultiscaleAggregation([1], "cpu")
+    out, waslist = one.preprocess(t, None)
+    assert out[0] is t and waslist is False
+    out, waslist = one.preprocess([t, t], None)
+    assert out[0] is t and len(out) == 2 and waslist is True
+    # a list of two images -> 2 x 2 pyramid levels, flagged; descriptors come back per image
+    pyr, waslist = ms.preprocess([t, torch.rand(1, 3, 6, 10)], None)
+    assert waslist is True and [tuple(p.shape[2:]) for p in pyr] == [(8, 8), (4, 4), (6, 10), (3, 5)]
+
+    class Model:
+        meta = {"pooling": "gem", "regional": False, "whitening": False, "out_channels": 4}
+
+        class pool:
+            p = torch.tensor([3.0])
+    vecs = [torch.rand(4) for _ in range(4)]
+    agg = ms.postprocess([v.clone() for v in vecs], Model, True)
+    assert len(agg) == 2
+    for i in range(2):
+        want = ((vecs[2 * i] ** 3 + vecs[2 * i + 1] ** 3) / 2) ** (1 / 3)
+        np.testing.assert_allclose(agg[i].numpy(), (want / want.norm()).numpy(), rtol=1e-5)
+    with pytest.raises(AssertionError):
+        ms.postprocess(vecs[:3], Model, True)
+    # whitening of a list: element by element (wrapper.py:181-195)
+    both = wh.postprocess([vecs[0].clone(), vecs[1].clone()], Model, None)
+    single = wh.postprocess(vecs[0].clone(), Model, None)
+    assert isinstance(both, list) and len(both) == 2 and tuple(both[0].shape) == (3,)
+    np.testing.assert_allclose(both[0].numpy(), single.numpy(), rtol=1e-6)
+    assert repr(chain) == "Compose([\n    CirtorchWhiten(dimensions=3)\n    CirMultiscaleAggregation(scales=[1, 0.5])\n])"        # wrapper.py:39-41
+    assert initialize_wrappers("", "cpu").wrappers == [] and initialize_wrappers(None, "cpu").wrappers == []
+    named = initialize_wrappers("cirmultiscale:True", "cpu")
+    assert len(named.wrappers) == 1 and isinstance(named.wrappers[0], CirMultiscaleAggregation) and len(named.wrappers[0].scales) == 3
+
+
+def test_validation_initialize_frequency_and_overlay(fops, tmp_path, monkeypatch):
+    """learning/validation.py:37-58 (criterion 'default' with and without a default, a data loader is refused here), :60-64
+    (`validations` / `should_validate`: epoch None always, else every `frequency` epochs), network.py:128-136 (`overlay_params`
+    returns a frozen copy with the overlaid runtime section and leaves the overlay dict consumed)."""
+    from mdir_amd.network import CirNetwork, SingleNetwork
+    from mdir_amd.networks import init_network
+    from mdir_amd.validation import VALIDATIONS
+    cls = next(iter(VALIDATIONS.values()))
+    sentinel = object()
+    val = cls.initialize({"data": None, "criterion": "default", "network_overlay": {}, "frequency": 2}, None, {}, sentinel, {})
+    assert val.criterion is sentinel
+    assert [bool(val.should_validate(e)) for e in (None, 0, 1, 2, 3)] == [True, False, True, False, True]
+    assert val.validations(None) == [("val", val)] and val.validations(0) == [] and val.validations(1) == [("val", val)]
+    never = cls.initialize({"data": None, "criterion": "default", "network_overlay": {}, "frequency": 0}, None, {}, sentinel, {})
+    assert not never.should_validate(5) and never.should_validate(None)
+    with pytest.raises(ValueError, match="Criterion cannot be 'default'"):
+        cls.initialize({"data": None, "criterion": "default", "network_overlay": {}, "frequency": 1}, None, {}, None, {})
+    with pytest.raises(NotImplementedError):
+        cls.initialize({"data": "val_set", "criterion": "default", "network_overlay": {}, "frequency": 1}, None, {"val_set": {}}, sentinel, {})
+    with pytest.raises(AssertionError):
+        cls.initialize({"data": None, "criterion": "default", "network_overlay": {}, "frequency": 1, "extra": 1}, None, {}, sentinel, {})
+    torch.manual_seed(0)
+    model = init_network({"architecture": "alexnet", "pretrained": False})
+    model.meta["in_channels"], model.meta["out_channels"] = 3, 256
+    net = CirNetwork(model, SingleNetwork.NetworkParams({"architecture": "cirnet"}, {"wrappers": "", "data": {"transforms": "pil2np | totensor | normalize"}}),
+                     "cpu", frozen=False)
+    assert net.overlay_params({}, "cpu") is net and net.overlay_params(None, "cpu") is net
+    overlay = {"runtime": {"wrappers": {"train": None, "eval": {"1_cirmultiscale": {"scales": True}}}, "data": {"transforms": "pil2np | totensor | normalize"}}}
+    over = net.overlay_params(overlay, "cpu")
+    assert over is not net and over.model is net.model and over.frozen is True and overlay == {}
+    assert over.network_params.runtime["frozen"] is True and over.network_params.model == net.network_params.model
+    with pytest.raises(AssertionError):
+        net.overlay_params({"runtime": {"wrappers": ""}, "model": {}}, "cpu")
+
+
+def test_unknown_network_type_path_join_overlay_of_one_and_non_scalar_events():
+    """learning/network.py NETWORKS lookup (a SequentialNetwork checkpoint is named as out of scope, not mis-loaded);
+    daan/ml/tools path_join (a later absolute path or URL wins, empty parts are skipped); daan/core/experiments dict_deep_overlay
+    of ONE dict; tools/eventprocessor.py:79-80 (rows whose dtype is not scalar/* are not registered)."""
+    from mdir_amd.events import MetadataKeeper
+    from mdir_amd.network import initialize_network
+    from mdir_amd.scenario import dict_deep_overlay, path_join
+    with pytest.raises(NotImplementedError, match="SequentialNetwork"):
+        initialize_network({}, "cpu", state={"net": {"type": "SequentialNetwork"}})
+    with pytest.raises(AssertionError):
+        initialize_network({}, "cpu", state=None)
+    assert path_join("/data", "img", "a.jpg") == "/data/img/a.jpg" and path_join("/data", "/abs/a.jpg") == "/abs/a.jpg"
+    assert path_join("/data", "", None, "a.jpg") == "/data/a.jpg" and path_join("/data", "http://host/a.jpg") == "http://host/a.jpg"
+    assert path_join("", "rel") == "rel" and path_join() == ""
+    only = {"a": {"b": 1}}
+    assert dict_deep_overlay(only) is only
+    assert dict_deep_overlay({"a": {"b": 1, "c": 2}}, {"a": {"b": 3}}, {"a": {"d": [1]}}) == {"a": {"b": 3, "c": 2, "d": [1]}}
+    keeper = MetadataKeeper()
+    keeper.register_epoch_data(0, {"img": {"dtype": "image/rgb", "data": {"x": [1, 2]}}, "score": {"dtype": "scalar/score", "data": {"ap": [0.5, float("nan"), 1.0]}}})
+    assert all(k[0] != "img" for k in keeper.data) and ("score", "ap") in keeper.data
+
+
+def test_images_from_list_len_and_position_lookup_of_a_set():
+    """genericdataset.py:72-73 (`__len__`); evaluate.py:80-81 through the positions route: `of` answers for an arbitrary SET of
+    ids with what np.arange(N)[np.in1d(ranks[:, q], ids)] gives (ids absent from the ranking drop out, duplicates count once)."""
+    from mdir_amd.datasets import ImagesFromList
+    from mdir_amd.evaluate import _Positions
+    ds = ImagesFromList("", ["a.jpg", "b.jpg", "c.jpg"], imsize=32)
+    assert len(ds) == 3
+    ranks = np.array([[4, 1], [2, 0], [0, 3], [1, 2], [3, 4]])            # [N, Q]
+    gnd = [{"ok": [0, 2], "junk": [3]}, {"ok": [4], "junk": []}]
+
+    def fetch(lists):
+        out = []
+        for q, ids in enumerate(lists):
+            inv = {int(v): i for i, v in enumerate(ranks[:, q])}
+            out.append(np.array([inv.get(int(i), -1) for i in ids], dtype=np.int64))
+        return out
+    pos = _Positions(gnd, fetch)
+    for q, ids in ((0, [2, 0]), (0, [3, 3, 0]), (0, []), (0, [1]), (1, [4]), (1, [0, 4])):
+        want = np.arange(5)[np.isin(ranks[:, q], ids)]
+        labelled = set(np.concatenate([np.asarray(gnd[q][k]) for k in ("ok", "junk")]).tolist())
+        want = np.array([p for p in want if ranks[p, q] in labelled], dtype=np.int64)        # the route only knows labelled ids
+        np.testing.assert_array_equal(pos.of(q, ids), want)
