@@ -66,6 +66,12 @@ typedef enum mdx_pool_kind { MDX_POOL_GEM = 0, MDX_POOL_MAC = 1, MDX_POOL_SPOC =
 
 int mdx_abi_version(void);
 const char *mdx_last_error(void);
+/* After a stream capture that was INVALIDATED (a call that is illegal while capturing: a synchronisation, a host read): ends the
+ * capture if `stream` is still in it (the half-built graph is destroyed) and clears the runtime's per-thread last-error, which
+ * otherwise makes the next -- perfectly legal -- launch check of the host framework report "operation failed due to a previous
+ * error during capture".  The host of this path captures one graph per input shape (mdir_amd/graphs.py) and stays eager for a shape
+ * whose capture was refused; without this call it could not.  No reference counterpart (the reference has no graphs). */
+int mdx_capture_recover(void *stream);
 
 /* ---------------------------------------------------------------- extraction */
 

@@ -363,6 +363,20 @@ struct mdx_index {
 extern "C" {
 
 int mdx_abi_version(void) { return MDX_ABI_VERSION; }
+
+int mdx_capture_recover(void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(s, &g);       // an invalidated capture ends with an error and no graph
+        if (g) (void)hipGraphDestroy(g);
+    }
+    (void)hipGetLastError();                    // the sticky (non-fatal) error of the failed capture
+    (void)hipGetLastError();
+    return MDX_OK;
+}
 const char *mdx_last_error(void) { return mdx::g_err; }
 
 static int retile(const float *src, int64_t n, int64_t d, int layout, const float *center,

@@ -62,24 +62,40 @@ enum { FMT_SCORES = 0, FMT_KV = 1, FMT_A = 2, FMT_B = 3, FMT_C = 4, FMT_RANKS = 
 // Scores that arrive as column blocks (the peer blocks of the multi-GPU exchange: block g is a [nq, width_g] row-major
 // matrix, row q of the problem = its rows q side by side): pass 0 reads them where they lie instead of a re-blocked copy.
 constexpr int MAX_SEG = 32;
+// The table travels in the kernel arguments (536 bytes).  Launches that do not read column blocks -- passes 1-3 of every
+// ranking, all passes of a dense one -- take the empty NoSeg instead: twelve 600-byte argument blocks per ranking cost ~20 us.
+struct NoSeg { static constexpr bool HAS = false; };
 struct SegTable {
+    static constexpr bool HAS = true;
     const float *p[MAX_SEG];
     int64_t start[MAX_SEG + 1];     // first column of block g; start[nseg] = n
     int nseg;                       // 0: plain [nq, n] scores
+    uint32_t inv_w;                 // floor(2^32 / ceil(n / nseg)): where equally wide blocks would put a column (seg_find's guess)
 };
 
-__device__ __forceinline__ int seg_of(const SegTable &t, int64_t i)
+// The table lives in the kernel arguments: every look into it is a scalar load that the tile's data loads wait for, and a
+// workgroup that walked it from block 0 had four or five such round trips in a row at the start of a 3-10 us life (9-query
+// ranking at G = 8, tools/g8_budget.py: 163-194 us over 8-24 peer blocks against 140 dense; per kernel hist<0> 14 against 8 us,
+// scatter<0> 33 against 23).  The peer blocks of an exchange are equally wide to within a row, so the block is GUESSED from the
+// column (where equal widths would put it) and its pointer and bounds are fetched together: one round trip when the guess
+// holds; any widths stay correct, a wrong guess walks from there.
+struct SegHit { const float *p; int64_t s0, s1; };
+
+__device__ __forceinline__ SegHit seg_find(const SegTable &t, int64_t i)
 {
-    int g = 0;
-    while (g + 1 < t.nseg && i >= t.start[g + 1]) ++g;
-    return g;
+    int g = (int)__umulhi((uint32_t)i, t.inv_w);
+    if (g > t.nseg - 1) g = t.nseg - 1;
+    SegHit h = {t.p[g], t.start[g], t.start[g + 1]};
+    while (i >= h.s1 && g + 1 < t.nseg) { ++g; h.p = t.p[g]; h.s0 = h.s1; h.s1 = t.start[g + 1]; }
+    while (i < h.s0 && g > 0) { --g; h.p = t.p[g]; h.s1 = h.s0; h.s0 = t.start[g]; }
+    return h;
 }
 
 // element i of row q
 __device__ __forceinline__ const float *seg_elem(const SegTable &t, int64_t q, int64_t i)
 {
-    const int g = seg_of(t, i);
-    return t.p[g] + q * (t.start[g + 1] - t.start[g]) + (i - t.start[g]);
+    const SegHit h = seg_find(t, i);
+    return h.p + q * (h.s1 - h.s0) + (i - h.s0);
 }
 
 // per-tile digit histogram -> block_hist[q][b][digit].  A histogram does not care which lane counts which
@@ -92,11 +108,11 @@ __device__ __forceinline__ const float *seg_elem(const SegTable &t, int64_t q, i
 // one ds_add hit the same address.  Row stride RADIX+1 keeps the copies in different banks.
 constexpr int HIST_COPIES = 8;
 
-template <int SRC>
+template <int SRC, typename SEGT = NoSeg>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__restrict__ scores,
                                                                  const void *__restrict__ src, int64_t n,
                                                                  int64_t stride, int nblk, int shift,
-                                                                 uint32_t *__restrict__ block_hist, SegTable seg)
+                                                                 uint32_t *__restrict__ block_hist, SEGT seg)
 {
     static_assert(SORT_ITEMS == 8, "a lane takes 8 elements of a tile");
     constexpr bool FIRST = SRC == FMT_SCORES;
@@ -136,18 +152,20 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__
             w[v] = u32x4u{0u, 0u, 0u, 0u};
         }
         bool straddles = false;                 // (uniform) the tile lies in two column blocks: element-wise below
-        if (FIRST && seg.nseg > 0) {
-            const int g = seg_of(seg, b0 * SORT_TILE);
+        if constexpr (FIRST && SEGT::HAS) {
+            const SegHit h = seg_find(seg, b0 * SORT_TILE);
             const int64_t tile_end = (b0 + 1) * SORT_TILE < n ? (b0 + 1) * SORT_TILE : n;
-            straddles = tile_end > seg.start[g + 1];
-            p = (const uint32_t *)(seg.p[g] + q * (seg.start[g + 1] - seg.start[g]) - seg.start[g]);
+            straddles = tile_end > h.s1;
+            p = (const uint32_t *)(h.p + q * (h.s1 - h.s0) - h.s0);
         }
         if (straddles) {
+            if constexpr (SEGT::HAS) {
 #pragma unroll
-            for (int v = 0; v < 2; ++v)
+                for (int v = 0; v < 2; ++v)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (first[v] + j < n) w[v][j] = *(const uint32_t *)seg_elem(seg, q, first[v] + j);
+                    for (int j = 0; j < 4; ++j)
+                        if (first[v] + j < n) w[v][j] = *(const uint32_t *)seg_elem(seg, q, first[v] + j);
+            }
         } else if ((b0 + 1) * SORT_TILE <= n) {        // whole tile (uniform branch): both loads in flight together
 #pragma unroll
             for (int v = 0; v < 2; ++v) w[v] = *(const u32x4u *)(p + first[v]);
@@ -196,12 +214,34 @@ __global__ __launch_bounds__(SCAN_GROUPS * SCAN_DIGITS) void sort_scan_kernel(ui
     const int b0 = g * per < nblk ? g * per : nblk, b1 = (b0 + per) < nblk ? (b0 + per) : nblk;
     uint32_t *p = block_hist + q * nblk * RADIX + d;
     uint32_t sum = 0;
-    for (int b = b0; b < b1; ++b) sum += p[(int64_t)b * RADIX];
+    // a chain of at most 8 tiles (n <= 1 M: 246 tiles / 32 groups) stays in registers between the two passes: one round trip to
+    // the table instead of two in a kernel that is nothing but latency
+    constexpr int KEEP = 8;
+    uint32_t kept[KEEP];
+    const bool keep = per <= KEEP;          // uniform
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            kept[u] = (b0 + u) < b1 ? p[(int64_t)(b0 + u) * RADIX] : 0u;
+            sum += kept[u];
+        }
+    } else {
+        for (int b = b0; b < b1; ++b) sum += p[(int64_t)b * RADIX];
+    }
     part[g][dl] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (int k = 0; k < g; ++k) run += part[k][dl];
     if (g == SCAN_GROUPS - 1) digit_tot[q * RADIX + d] = run + sum;
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u)
+            if ((b0 + u) < b1) {
+                p[(int64_t)(b0 + u) * RADIX] = run;
+                run += kept[u];
+            }
+        return;
+    }
     int b = b0;
     for (; b + 8 <= b1; b += 8) {
         uint32_t c[8];
@@ -233,13 +273,13 @@ __global__ __launch_bounds__(SCAN_GROUPS * SCAN_DIGITS) void sort_scan_kernel(ui
 // library asks the device once (lds_order_probe_kernel below) and otherwise ranks with the eight ballots of the
 // match-any form: ~45 vector instructions per round of 64 elements instead of one LDS instruction, and the
 // scatter is bound by exactly that instruction count.
-template <int IN, int OUT, bool ARANK>
+template <int IN, int OUT, bool ARANK, typename SEGT = NoSeg>
 __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAVES) / 4)) void sort_scatter_kernel(
     const float *__restrict__ scores, const uint32_t *__restrict__ w_in, const void *__restrict__ h_in,
     uint32_t *__restrict__ w_out, void *__restrict__ h_out, int64_t *__restrict__ ranks,
     float *__restrict__ top_scores, int64_t n, int64_t stride, int nblk, int shift,
     const uint32_t *__restrict__ block_hist, const uint32_t *__restrict__ digit_tot, int64_t id_offset,
-    int64_t klimit, SegTable seg)
+    int64_t klimit, SEGT seg)
 {
     constexpr bool FIRST = IN == FMT_SCORES, LAST = OUT == FMT_RANKS;
     constexpr bool VAL_IN_KEY = IN == FMT_C;        // the id is the low 24 bits of the word the digit comes from
@@ -288,13 +328,14 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
         const uint32_t *src = (const uint32_t *)scores + base + tile0;
         bool straddles = false;         // (uniform) the tile lies in two column blocks of segmented scores
-        if (seg.nseg > 0) {
-            const int g = seg_of(seg, tile0);
-            straddles = tile0 + tile_n > seg.start[g + 1];
-            src = (const uint32_t *)(seg.p[g] + q * (seg.start[g + 1] - seg.start[g]) + (tile0 - seg.start[g]));
+        if constexpr (SEGT::HAS) {
+            const SegHit h = seg_find(seg, tile0);
+            straddles = tile0 + tile_n > h.s1;
+            src = (const uint32_t *)(h.p + q * (h.s1 - h.s0) + (tile0 - h.s0));
         }
         if (straddles) {
-            for (int e = tid; e < tile_n; e += SORT_THREADS) skey[e] = desc_key(*seg_elem(seg, q, tile0 + e));
+            if constexpr (SEGT::HAS)
+                for (int e = tid; e < tile_n; e += SORT_THREADS) skey[e] = desc_key(*seg_elem(seg, q, tile0 + e));
         } else if (tile_n == SORT_TILE) {      // whole tile (uniform branch): both loads in flight together
             u32x4u w[SORT_ITEMS / 4];
 #pragma unroll
@@ -853,9 +894,9 @@ static bool atomic_rank_ok(hipStream_t s)
     return probe_lds_order(s) == 2;
 }
 
-template <int IN, int OUT>
-static void sort_pass(const RankWs &ws, const float *scores, int64_t n, int64_t nq, int pass, int64_t id_offset,
-                      int64_t *ranks, float *top_scores, int64_t klimit, bool arank, const SegTable &seg, hipStream_t s)
+template <int IN, int OUT, typename SEGT>
+static void sort_pass_on(const RankWs &ws, const float *scores, int64_t n, int64_t nq, int pass, int64_t id_offset,
+                         int64_t *ranks, float *top_scores, int64_t klimit, bool arank, const SEGT &seg, hipStream_t s)
 {
     const int shift = 8 * pass;
     const uint32_t *w_in = pass == 0 ? nullptr : ws.w[(pass - 1) & 1];
@@ -863,18 +904,29 @@ static void sort_pass(const RankWs &ws, const float *scores, int64_t n, int64_t 
     const dim3 grid((unsigned)ws.nblk, (unsigned)nq), blk(SORT_THREADS);
     // the histogram reads only the array the digit of this pass lives in
     const void *digits = (IN == FMT_A || IN == FMT_B) ? h_in : (const void *)w_in;
-    hipLaunchKernelGGL(sort_hist_kernel<IN>, grid, blk, 0, s, scores, digits, n, ws.stride, ws.nblk, shift,
+    hipLaunchKernelGGL((sort_hist_kernel<IN, SEGT>), grid, blk, 0, s, scores, digits, n, ws.stride, ws.nblk, shift,
                        ws.block_hist, seg);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RADIX / SCAN_DIGITS, (unsigned)nq), dim3(SCAN_GROUPS * SCAN_DIGITS), 0, s,
                        ws.block_hist, ws.nblk, ws.digit_tot);
     if (arank)
-        hipLaunchKernelGGL((sort_scatter_kernel<IN, OUT, true>), grid, blk, 0, s, scores, w_in, h_in, ws.w[pass & 1],
+        hipLaunchKernelGGL((sort_scatter_kernel<IN, OUT, true, SEGT>), grid, blk, 0, s, scores, w_in, h_in, ws.w[pass & 1],
                            ws.h[pass & 1], ranks, top_scores, n, ws.stride, ws.nblk, shift, ws.block_hist, ws.digit_tot,
                            id_offset, klimit, seg);
     else
-        hipLaunchKernelGGL((sort_scatter_kernel<IN, OUT, false>), grid, blk, 0, s, scores, w_in, h_in, ws.w[pass & 1],
+        hipLaunchKernelGGL((sort_scatter_kernel<IN, OUT, false, SEGT>), grid, blk, 0, s, scores, w_in, h_in, ws.w[pass & 1],
                            ws.h[pass & 1], ranks, top_scores, n, ws.stride, ws.nblk, shift, ws.block_hist, ws.digit_tot,
                            id_offset, klimit, seg);
+}
+
+// only pass 0 of a ranking of column blocks reads the segment table
+template <int IN, int OUT>
+static void sort_pass(const RankWs &ws, const float *scores, int64_t n, int64_t nq, int pass, int64_t id_offset,
+                      int64_t *ranks, float *top_scores, int64_t klimit, bool arank, const SegTable &seg, hipStream_t s)
+{
+    if (IN == FMT_SCORES && seg.nseg > 0)
+        sort_pass_on<IN, OUT, SegTable>(ws, scores, n, nq, pass, id_offset, ranks, top_scores, klimit, arank, seg, s);
+    else
+        sort_pass_on<IN, OUT, NoSeg>(ws, scores, n, nq, pass, id_offset, ranks, top_scores, klimit, arank, NoSeg{}, s);
 }
 
 static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offset, int64_t *ranks,
@@ -884,6 +936,10 @@ static int rank_impl(const float *scores, int64_t n, int64_t nq, int64_t id_offs
     SegTable seg;
     if (segments) seg = *segments;
     else memset(&seg, 0, sizeof seg);
+    if (seg.nseg > 0) {
+        const uint64_t w = (uint64_t)ceil_div(n, (int64_t)seg.nseg), inv = (1ull << 32) / (w ? w : 1);
+        seg.inv_w = inv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)inv;
+    }
     MDX_CHECK_ARG(scores || seg.nseg > 0, "%s: NULL scores", who);
     MDX_CHECK_ARG(n > 0 && nq > 0, "%s: n=%lld nq=%lld must be positive", who, (long long)n,
                   (long long)nq);

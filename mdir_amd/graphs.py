@@ -10,6 +10,7 @@ the first ``warmup`` (default 1) occurrences of a shape run eagerly
 (MIOpen's algorithm search happens there), the next one is captured.
 """
 import collections
+import ctypes
 import os
 import warnings
 
@@ -50,6 +51,13 @@ def parallel_map(fn, items):
     return outs
 
 
+# PyTorch cannot start another capture in a process after one that failed: CUDAGraph.capture_end() leaves through its first
+# check, before the caching allocator is told that the pool's capture is over, and the next capture_begin aborts the process
+# (measured, torch 2.10 / ROCm 7.0: tests/test_gpu_round5.py).  So a refusal switches captures off for the rest of the process;
+# graphs captured before it keep replaying, everything else runs eagerly -- slower, never different.
+_captures_off = False
+
+
 class _Entry:
     __slots__ = ("graph", "static_in", "static_out")
 
@@ -83,7 +91,7 @@ class ShapeGraphs:
         entry = self.graphs.get(key)
         if entry is None:
             self.seen[key] += 1
-            if key in self.refused or self.seen[key] <= self.warmup:
+            if _captures_off or key in self.refused or self.seen[key] <= self.warmup:
                 return self.fn(x)
             if self.upcoming is not None and self.upcoming < self.PAYOFF_IMAGES:
                 return self.fn(x)                     # too few images of this shape left for a capture to pay off
@@ -109,16 +117,42 @@ class ShapeGraphs:
         entry = _Entry()
         entry.static_in = x.clone()
         entry.graph = torch.cuda.CUDAGraph()
+        # thread_local: the loader's pin-memory thread and RCCL's watchdog thread keep making HIP
+        # calls (host allocations, event queries) while this thread captures; only calls made by
+        # the capturing thread itself may invalidate the capture
+        before = torch.cuda.current_stream()
+        ctx = torch.cuda.graph(entry.graph, pool=self.pool, capture_error_mode="thread_local")
         try:
-            # thread_local: the loader's pin-memory thread and RCCL's watchdog thread keep making HIP
-            # calls (host allocations, event queries) while this thread captures; only calls made by
-            # the capturing thread itself may invalidate the capture
-            with torch.cuda.graph(entry.graph, pool=self.pool, capture_error_mode="thread_local"):
+            with ctx:
                 entry.static_out = self.fn(entry.static_in)
         except Exception as err:                     # keep extracting eagerly; never silently change results
+            # What a failed capture leaves behind (found by tests/test_gpu_round5.py::test_graph_bookkeeping_refusal_and_eviction,
+            # round 5 -- until then the eager call that followed a refusal failed with "operation failed due to a previous error
+            # during capture"): torch.cuda.graph.__exit__ raises out of capture_end() BEFORE it restores the stream context, so
+            # this thread's current stream is still the (invalidated) capture stream; that stream may still be capturing; and
+            # HIP's per-thread last-error is set.  Put the stream back, end the capture, clear the error.
+            from . import _lib
+            if torch.cuda.current_stream() != before:
+                try:
+                    ctx.stream_ctx.__exit__(None, None, None)
+                except Exception:
+                    torch.cuda.set_stream(before)
+            for stream in {ctx.capture_stream, before}:
+                _lib.lib().mdx_capture_recover(ctypes.c_void_p(stream.cuda_stream))
             torch.cuda.synchronize()
+            # ... and PyTorch's random generator of the device was told that a capture began and never that it ended (the same
+            # early exit of capture_end): the next torch.rand would fail with "Offset increment outside graph capture".  A
+            # clone of its state is a fresh state object (same seed and offset) without the flag.
+            try:
+                gen = torch.cuda.default_generators[before.device_index]
+                gen.graphsafe_set_state(gen.clone_state())
+            except Exception:                       # older / newer PyTorch without the graph-safe state API: nothing to repair with
+                pass
             self.refused.add(key)
-            warnings.warn("hipGraph capture refused for input shape %s (%s); staying eager for it" % (key[0], err))
+            global _captures_off
+            _captures_off = True
+            warnings.warn("hipGraph capture refused for input shape %s (%s); this and every further shape of the process stay eager"
+                          % (key[0], err))
             return None
         self.graphs[key] = entry
         self.captures += 1

@@ -97,9 +97,11 @@ def query_bounds(nq, world, rank):
 def exchange_chunks(n_total, world):
     """How many row chunks every shard is cut into so that the all-to-all of chunk c runs on
     RCCL's stream while the similarity kernel of chunk c+1 runs on the compute stream.  Small
-    chunks cost kernel efficiency (measured: tools/shard_model.py), so only big shards are split
-    (three chunks at G=2, two at G=4 for 1 M rows; chunk sizes halve, see ``chunk_bounds``).  Same value on every
-    rank (derived from the largest shard)."""
+    chunks cost kernel efficiency (measured: tools/shard_model.py, tools/g8_budget.py), so only big shards are split:
+    three chunks at G=2, two at G=4 for 1 M rows (chunk sizes halve, see ``chunk_bounds``), and -- round 5 -- two EQUAL chunks
+    at G=8 (125 k-row shards: two launches of 491 workgroups, one round of the chip's 512 slots each, take the time of the one
+    launch of 982, 0.345 against 0.349 ms, and the first half's transfer then hides behind the second half's kernel;
+    profiles/r05_g8_budget.md).  Same value on every rank (derived from the largest shard)."""
     import os
     forced = os.environ.get("MDIR_AMD_EXCHANGE_CHUNKS")
     if forced:
@@ -108,7 +110,10 @@ def exchange_chunks(n_total, world):
     if world == 1:
         return 1
     biggest = shard_bounds(n_total, world, 0)[1]
-    return 3 if biggest >= 400_000 else (2 if biggest >= 200_000 else 1)
+    return 3 if biggest >= 400_000 else (2 if biggest >= 120_000 else 1)
+
+
+MIN_CHUNK_ROWS = 60_000
 
 
 def chunk_bounds(lo, hi, chunks):
@@ -118,6 +123,10 @@ def chunk_bounds(lo, hi, chunks):
     only the LAST, smallest transfer is exposed."""
     n = hi - lo
     weights = [1 << (chunks - 1 - c) for c in range(chunks)]
+    if n // sum(weights) < MIN_CHUNK_ROWS:
+        # the smallest of the halving chunks would not fill the chip once (a similarity launch has 512 workgroup slots of 128
+        # rows): equal chunks instead -- at 125 625 rows 2 x 62 812 take 0.345 ms, 83 750 + 41 875 take 0.399 (tools/g8_budget.py)
+        weights = [1] * chunks
     total, edges, acc = sum(weights), [lo], 0
     for w in weights[:-1]:
         acc += w

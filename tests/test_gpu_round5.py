@@ -179,3 +179,261 @@ def test_bench_with_eight_ranks_on_one_gpu(form, one_rank_line):
         assert sp["value"]["min"] <= sp["value"]["median"] <= sp["value"]["max"]
     assert set(one["spread_over_timed_steps"]) >= {"kernel_ms", "rank_ms", "step_ms", "value"}
     assert line["roofline"]["algorithmic_flops_per_rank"] == 2.0 * 70 * 25000 * 2048
+
+
+# ---------------------------------------------------------------- host-surface branches that need the device (profiles/r05_host_branches.md)
+
+def test_mac_spoc_functions_modules_and_their_place_in_the_network(golden):
+    """cirtorch/layers/functional.py:11-16 (mac, spoc), pooling.py:14-33 (MAC / SPoC modules and their repr), through
+    mdx_pool_l2n; golden G1 holds the reference's values.  `pool_kind` names them for the fused network tail."""
+    from mdir_amd import layers
+    from mdir_amd.networks import init_network
+    from conftest import sparse_map
+    g = golden("g1_pool.npz")
+    for c, h, w in [(2048, 17, 23), (256, 7, 5)]:
+        x = dev(sparse_map(int(g[f"seed_c{c}_h{h}_w{w}"]), (1, c, h, w)))
+        for fn, mod, key in ((layers.mac, layers.MAC(), "mac"), (layers.spoc, layers.SPoC(), "spoc")):
+            want = g[f"{key}_c{c}_h{h}_w{w}"]
+            for got in (fn(x), mod(x)):
+                assert tuple(got.shape) == (1, c, 1, 1)
+                np.testing.assert_allclose(got.cpu().numpy().reshape(-1), want.reshape(-1), rtol=5e-6, atol=1e-7)
+        np.testing.assert_allclose(layers.gem(x, p=torch.tensor([2.2]), eps=1e-6).cpu().numpy().reshape(-1),
+                                   g[f"gem_c{c}_h{h}_w{w}_p2.2"].reshape(-1), rtol=2e-5, atol=1e-7)
+    assert repr(layers.MAC()) == "MAC()" and repr(layers.SPoC()) == "SPoC()" and repr(layers.L2N()) == "L2N(eps=1e-06)"
+    assert repr(layers.GeM(p=2.5)) == "GeM(p=2.5000, eps=1e-06)"
+    assert layers.pool_kind(layers.MAC()) == ("mac", 1.0, 1e-6) and layers.pool_kind(layers.SPoC()) == ("spoc", 1.0, 1e-6)
+    assert layers.pool_kind(torch.nn.AdaptiveAvgPool2d(1)) is None
+    with pytest.raises(ValueError, match="global descriptors"):
+        layers.l2n(torch.rand(2, 3, 4, 4, device=DEV))
+    y = layers.L2N()(dev(golden("g2_l2n.npz")["x"]))
+    np.testing.assert_allclose(y.cpu().numpy(), golden("g2_l2n.npz")["y"], rtol=1e-6, atol=1e-9)
+    # a MAC network end to end == its statements: L2N(MAC(features(x)))
+    torch.manual_seed(0)
+    net = init_network({"architecture": "alexnet", "pooling": "mac", "whitening": False, "pretrained": False}).to(DEV).eval()
+    xin = torch.rand(2, 3, 97, 130, device=DEV)
+    with torch.no_grad():
+        got = net(xin)
+        feat = net.features(xin)
+        want = torch.nn.functional.normalize(feat.amax(dim=(2, 3)), dim=1, eps=0) if False else feat.amax(dim=(2, 3))
+        want = want / (want.norm(dim=1, keepdim=True) + 1e-6)
+    np.testing.assert_allclose(got.t().cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_general_multiscale_routes_when_the_tail_cannot_be_fused(monkeypatch):
+    """imageretrievalnet.py:309-324 (extract_ms) and wrapper.py:84-136 with a network whose tail is NOT pooling + L2N only (an
+    in-network whitening follows): every scale goes through the whole network, descriptors are aggregated by mdx_ms_aggregate --
+    for one image and for a batch (mdx_ms_aggregate_batch) -- and equal the statements written in torch; msp = 1 because the
+    network whitens (quirk Q3)."""
+    from mdir_amd.networks import extract_ms, init_network
+    from mdir_amd.wrapper import CirMultiscaleAggregation, Compose
+    torch.manual_seed(2)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": True, "pretrained": False}).to(DEV).eval()
+    net.meta["in_channels"], net.meta["out_channels"] = 3, net.meta["outputdim"]
+    assert net.fusable_tail() is None and net.whiten is not None
+    ms = [1, 2 ** -0.5, 0.5]
+
+    def reference(x):                                   # per image: sum of the scales' descriptors / S, renormalised (msp = 1)
+        acc = 0
+        for s in ms:
+            xs = x if s == 1 else torch.nn.functional.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False)
+            acc = acc + net(xs).t()
+        acc = acc / len(ms)
+        return acc / acc.norm(dim=1, keepdim=True)
+    with torch.no_grad():
+        one, four = torch.rand(1, 3, 160, 120, device=DEV), torch.rand(4, 3, 96, 128, device=DEV)
+        got1, got4 = extract_ms(net, one, ms, 1), extract_ms(net, four, ms, 1)
+        assert tuple(got1.shape) == (net.meta["outputdim"],) and tuple(got4.shape) == (4, net.meta["outputdim"])
+        np.testing.assert_allclose(got1.cpu().numpy(), reference(one)[0].cpu().numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(got4.cpu().numpy(), reference(four).cpu().numpy(), rtol=2e-5, atol=2e-6)
+        # the wrapper chain on the same network: fused_tail declines (None), the general route aggregates the batch in one launch
+        wrap = CirMultiscaleAggregation(True, DEV)
+        assert wrap._msp(net) == 1
+        chain = Compose([wrap], DEV)
+        pyramid, waslist = wrap.preprocess(four, net)
+        assert wrap.fused_tail(pyramid, net, net, waslist, DEV) is None
+        np.testing.assert_allclose(chain(four, net).cpu().numpy(), reference(four).cpu().numpy(), rtol=2e-5, atol=2e-6)
+        monkeypatch.setenv("MDIR_AMD_FUSED_TAIL", "0")          # the same general route on a network whose tail COULD be fused
+        plain = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False}).to(DEV).eval()
+        plain.meta["in_channels"], plain.meta["out_channels"] = 3, plain.meta["outputdim"]
+        general = extract_ms(plain, four, ms, plain.pool.p_value())
+        monkeypatch.delenv("MDIR_AMD_FUSED_TAIL")
+        fused = extract_ms(plain, four, ms, plain.pool.p_value())
+        np.testing.assert_array_equal(general.cpu().numpy(), fused.cpu().numpy())          # "bit-identical to the general route"
+
+
+def test_compute_map_on_a_non_contiguous_device_ranking(golden):
+    """evaluate.py:39-111 on a device ranking handed over as [N,Q] with its OWN memory layout (a copy, not the transposed view of
+    the [Q,N] matrix the sort writes): rows are made contiguous once; same result as the host route."""
+    from mdir_amd.evaluate import compute_map
+    rng = np.random.default_rng(4)
+    n, nq = 3000, 6
+    ranks = np.stack([rng.permutation(n) for _ in range(nq)], axis=1).astype(np.int64)          # [N,Q], C-contiguous
+    gnd = [{"ok": rng.choice(n, 7, replace=False), "junk": rng.choice(n, 3, replace=False)} for _ in range(nq)]
+    want = O.compute_map(ranks, gnd, kappas=[1, 5, 10])
+    got = compute_map(dev(ranks), gnd, kappas=[1, 5, 10])
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got[1], want[1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got[3], want[3], rtol=0, atol=1e-12)
+
+
+_REFUSAL_SCRIPT = r"""
+import sys, warnings
+import torch
+sys.path.insert(0, %(root)r)
+from mdir_amd import graphs
+from mdir_amd.graphs import ShapeGraphs
+dev = "cuda:0"
+ok = ShapeGraphs(lambda t: t * 2 + 1, warmup=0)
+a = torch.rand(3, 5, device=dev)
+assert torch.equal(ok(a), a * 2 + 1) and ok.captures == 1
+
+def syncing(x):
+    return x * float(x.sum().item() > -1e30)               # .item(): a host read inside the function
+sg = ShapeGraphs(syncing, warmup=0)
+x = torch.rand(4, 8, device=dev)
+with warnings.catch_warnings(record=True) as seen:
+    warnings.simplefilter("always")
+    y = sg(x)                                               # the capture is refused, the SAME call answers eagerly
+assert any("capture refused" in str(w.message) for w in seen), [str(w.message) for w in seen]
+assert torch.equal(y, x) and len(sg.refused) == 1 and sg.captures == 0 and graphs._captures_off
+assert torch.equal(sg(x), x) and sg.replays == 0            # stays eager, silently
+z = torch.rand(4, 8, device=dev)                            # PyTorch's generator works again (its capture flag was left set)
+assert torch.equal(sg(z), z)
+b = torch.rand(3, 5, device=dev)
+assert torch.equal(ok(b), b * 2 + 1) and ok.replays == 2    # a graph captured BEFORE the refusal keeps replaying
+later = ShapeGraphs(lambda t: t - 1, warmup=0)
+c = torch.rand(6, 7, device=dev)
+assert torch.equal(later(c), c - 1) and later.captures == 0  # no further capture is attempted in this process
+torch.cuda.synchronize()
+print("REFUSAL_OK")
+"""
+
+
+def test_graph_bookkeeping_refusal_and_eviction():
+    """mdir_amd/graphs.py: beyond `max_graphs` shapes the least recently used graph goes; few images left of a shape
+    (`upcoming` < PAYOFF_IMAGES) are not worth a capture; a function that cannot be captured (it synchronises with the host) is
+    refused with a warning, the same call and all later ones answer eagerly with the eager result, earlier graphs keep
+    replaying and no further capture is attempted (own process: PyTorch cannot capture again after a failed capture)."""
+    from mdir_amd.graphs import ShapeGraphs
+    small = ShapeGraphs(lambda t: t * 2 + 1, warmup=0, max_graphs=2)
+    shapes = [(2, 3), (4, 5), (6, 7)]
+    for s in shapes:
+        t = torch.rand(s, device=DEV)
+        assert torch.equal(small(t), t * 2 + 1)
+    assert small.captures == 3 and len(small.graphs) == 2 and (tuple(shapes[0]), torch.float32, 0) not in small.graphs
+    t = torch.rand(shapes[0], device=DEV)
+    assert torch.equal(small(t), t * 2 + 1) and small.captures == 4           # captured again after its eviction
+    few = ShapeGraphs(lambda t: t + 1, warmup=0)
+    few.upcoming = 3
+    assert torch.equal(few(t), t + 1) and few.captures == 0                  # too few images left: eager
+    proc = subprocess.run([sys.executable, "-c", _REFUSAL_SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "REFUSAL_OK" in proc.stdout, (proc.stdout[-2000:], proc.stderr[-4000:])
+
+
+def test_loader_routes_what_the_device_decoder_does_not_take(tmp_path, monkeypatch):
+    """genericdataset.py:44-70 with the device JPEG route on: a PNG, a CMYK JPEG and a progressive JPEG are not
+    candidates for mdx_jpeg_* (`_coefficients` answers None, nothing is raised) and come out of the loader exactly as Pillow
+    decodes them; a baseline JPEG goes through the device and equals Pillow too.  jpeg.box_on_device / resample.on_device:
+    the cases the device declines."""
+    from PIL import Image
+    from mdir_amd import jpeg, resample
+    from mdir_amd.datasets import ImagesFromList, ToUint8HWC
+    rng = np.random.default_rng(7)
+    arr = rng.integers(0, 255, (90, 130, 3), dtype=np.uint8)
+    Image.fromarray(arr).save(str(tmp_path / "a.png"))
+    Image.fromarray(arr).save(str(tmp_path / "b.jpg"), quality=92)
+    Image.fromarray(arr).save(str(tmp_path / "c.jpg"), quality=92, progressive=True)
+    Image.fromarray(arr).convert("CMYK").save(str(tmp_path / "d.jpg"), quality=92)
+    (tmp_path / "e.jpg").write_bytes(b"")
+    names = [str(tmp_path / n) for n in ("a.png", "b.jpg", "c.jpg", "d.jpg")]
+    ds = ImagesFromList("", names + [str(tmp_path / "e.jpg")], imsize=64, transform=ToUint8HWC())
+    took = [ds._coefficients(i) for i in range(5)]
+    assert took[0] is None and took[1] is not None and took[3] is None and took[4] is None
+    assert jpeg.entropy_decode(b"") is None
+    assert jpeg.box_on_device(None, 10, 10) and jpeg.box_on_device((0, 0, 10, 10), 10, 10)
+    assert not jpeg.box_on_device((0, 0, 11, 10), 10, 10) and not jpeg.box_on_device((5, 5, 5, 9), 10, 10) and not jpeg.box_on_device((-1, 0, 4, 4), 10, 10)
+    assert resample.on_device(100, 80, 200) is None and resample.on_device(100, 80, 100) is None      # nothing to shrink
+    assert resample.on_device(4000, 3000, 64) is None                                                 # Pillow reduces by an integer factor first
+    assert resample.on_device(100, 80, 50) == (50, 40)
+    assert resample.on_device(3, 1000, 200) is None or isinstance(resample.on_device(3, 1000, 200), tuple)
+    img = rng.integers(0, 256, (47, 61, 3), dtype=np.uint8)
+    assert np.array_equal(resample._host_resample(img, (61, 47)), img)                               # both axes already at size
+    for i, name in enumerate(names):
+        with Image.open(name) as im:
+            want = im.convert("RGB")
+            want.thumbnail((64, 64), Image.LANCZOS)
+            want = np.asarray(want)
+        got = ds[i]
+        got = got.numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+        assert got.shape == want.shape, name
+        np.testing.assert_array_equal(got, want, err_msg=name)
+
+
+def test_argument_checks_of_the_python_shim():
+    """SURVEY section 8(b) "Errors": the C ABI returns a status, the Python shim raises the matching exception BEFORE any launch --
+    RuntimeError for host tensors (no CPU fallback), TypeError for a wrong dtype, ValueError for shapes the kernels do not take."""
+    from mdir_amd import ops
+    f = lambda *s: torch.rand(*s, device=DEV)
+    u8 = torch.zeros((1, 8, 8, 3), dtype=torch.uint8, device=DEV)
+    ix = ops.DescriptorIndex(f(32, 16), "ND")
+    closed = ops.DescriptorIndex(f(32, 16), "ND")
+    closed.close()
+    i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=DEV)
+    cases = [
+        (RuntimeError, lambda: ops.pool_l2n(torch.rand(1, 4, 3, 3))),
+        (TypeError, lambda: ops.pool_l2n(f(1, 4, 3, 3).double())),
+        (ValueError, lambda: ops.pool_l2n(f(1, 4, 3, 6)[:, :, :, ::2])),
+        (ValueError, lambda: ops.pool_l2n(f(4, 3, 3))),
+        (ValueError, lambda: ops.l2n_rows_(f(4))),
+        (ValueError, lambda: ops.l2n_rows_(f(2, 4), bias=f(3))),
+        (ValueError, lambda: ops.ms_aggregate([])),
+        (ValueError, lambda: ops.ms_aggregate([f(4), f(5)])),
+        (ValueError, lambda: ops.ms_aggregate_batch([f(2, 4)] * 9)),
+        (ValueError, lambda: ops.ms_aggregate_batch([f(2, 4), f(3, 4)])),
+        (ValueError, lambda: ops.pool_multi([])),
+        (ValueError, lambda: ops.pool_multi([f(4, 3, 3)])),
+        (ValueError, lambda: ops.pool_multi([f(1, 4, 3, 3), f(1, 5, 2, 2)])),
+        (ValueError, lambda: ops.l2n_aggregate(f(2, 4))),
+        (ValueError, lambda: ops.u8_to_chw(u8.cpu(), [0.5] * 3, [0.2] * 3)),
+        (ValueError, lambda: ops.u8_to_chw(u8, [0.5] * 2, [0.2] * 3)),
+        (ValueError, lambda: ops.clahe_u8_to_chw(u8[..., :2].contiguous(), 4, 8, [0.5] * 3, [0.2] * 3)),
+        (ValueError, lambda: ops.clahe_u8_to_chw(u8, 4, 8, [0.5] * 2, [0.2] * 3)),
+        (ValueError, lambda: ops.bilinear_pyramid(f(3, 8, 8), [0.5])),
+        (ValueError, lambda: ops.bilinear_pyramid(f(1, 3, 8, 8), [0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2, 0.15])),
+        (ValueError, lambda: ops.resample_u8(u8.cpu(), 0, i32(4, 2), i32(4, 3))),
+        (ValueError, lambda: ops.resample_u8(u8, 2, i32(4, 2), i32(4, 3))),
+        (ValueError, lambda: ops.resample_u8(u8, 0, i32(4, 3), i32(4, 3))),
+        (ValueError, lambda: ops.bn_act_(f(4, 3, 3), f(4), f(4))),
+        (ValueError, lambda: ops.bn_act_(f(1, 4, 3, 3), f(4), None)),
+        (ValueError, lambda: ops.bn_act_(f(1, 4, 3, 3), f(4), f(4), residual=f(1, 4, 3, 2))),
+        (ValueError, lambda: ops.conv1x1_bn_act(f(4, 3, 3), f(4, 8), f(8), f(8), f(8), f(8), 1e-5, None, True)),
+        (ValueError, lambda: ops.conv1x1_bn_act(f(1, 4, 3, 3), f(5, 8), f(8), f(8), f(8), f(8), 1e-5, None, True)),
+        (ValueError, lambda: ops.conv1x1_bn_act(f(1, 4, 3, 3), f(4, 8), f(7), f(8), f(8), f(8), 1e-5, None, True)),
+        (ValueError, lambda: ops.conv1x1_bn_act(f(1, 4, 3, 3), f(4, 8), f(8), f(8), f(8), f(8), 1e-5, f(1, 8, 3, 2), True)),
+        (RuntimeError, lambda: closed.scores(f(2, 16), "ND")),
+        (ValueError, lambda: ix.scores(f(2, 16), "ND", center=f(15))),
+        (ValueError, lambda: ix.scores(f(2, 16), "ND", out=f(3, 32))),
+        (ValueError, lambda: ix.scores(f(2, 16), "sideways")),
+        (ValueError, lambda: ix.scores(f(2, 2, 16), "ND")),
+        (ValueError, lambda: ops.rank_full_segments([f(2, 5), f(3, 5)])),
+        (ValueError, lambda: ops.scores_rowmajor(f(2, 3, 16), f(2, 16), "ND")),
+        (ValueError, lambda: ops.scores_rowmajor(f(32, 16), f(2, 12), "ND")),
+        (ValueError, lambda: ops.scores_rowmajor(f(32, 16), f(2, 16), "ND", center=f(3))),
+        (ValueError, lambda: ops.scores_rowmajor(f(32, 16), f(2, 16), "ND", out=f(3, 32))),
+        (ValueError, lambda: ops.rank_positions(torch.zeros((2, 4), dtype=torch.int32, device=DEV), [[0], [1]])),
+        (ValueError, lambda: ops.rank_positions(torch.zeros((2, 4), dtype=torch.int64, device=DEV), [[0]])),
+        (ValueError, lambda: ops.gram_f64(f(4).double())),
+        (ValueError, lambda: ops.gram_f64(f(4, 9).double(), f(3).double())),
+        (ValueError, lambda: ops.project_f64(f(4, 5).double(), f(4, 9).double())),
+        (ValueError, lambda: ops.project_f64(f(4, 5).double(), f(5, 9).double(), f(4).double())),
+    ]
+    for i, (exc, call) in enumerate(cases):
+        with pytest.raises(exc):
+            call()
+        assert True, i
+    ix.close()
+    # what is legal at the edges: empty batches come back empty, a pyramid of the identity scale is the input itself
+    assert ops.u8_to_chw(u8[:0], [0.5] * 3, [0.2] * 3).shape[0] == 0
+    assert ops.bilinear_pyramid(f(1, 3, 8, 8), [1])[0].shape == (1, 3, 8, 8)
+    e = f(0, 4, 3, 3)
+    assert ops.bn_act_(e, f(4), f(4)) is e

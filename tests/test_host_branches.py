@@ -242,3 +242,59 @@ def test_images_from_list_len_and_position_lookup_of_a_set():
         labelled = set(np.concatenate([np.asarray(gnd[q][k]) for k in ("ok", "junk")]).tolist())
         want = np.array([p for p in want if ranks[p, q] in labelled], dtype=np.int64)        # the route only knows labelled ids
         np.testing.assert_array_equal(pos.of(q, ids), want)
+
+
+def test_eval_py_without_a_scenario_and_with_an_unknown_one():
+    """mdir/examples/iccv19/eval.py:33-47: no argument -> "Scenario needs to be specified" on stderr, exit status 1 (nothing
+    has touched a device by then); a scenario file that does not exist is the FileNotFoundError of `open`."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py")], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 1 and "Scenario needs to be specified" in proc.stderr
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py"), "no_such_scenario.yml"], capture_output=True, text=True, timeout=300)
+    assert proc.returncode != 0 and "FileNotFoundError" in proc.stderr and "no_such_scenario.yml" in proc.stderr
+
+
+def test_library_binding_failures_are_loud(monkeypatch, tmp_path):
+    """The product has no fallback: a library that was never built, or one built from another version of include/mdx.h, is an
+    MdxError at the first use (mdir_amd/_lib.py) -- never a silent CPU route."""
+    from mdir_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libmdx.so"))
+    with pytest.raises(_lib.MdxError, match="not built"):
+        _lib.lib()
+
+    class Stale:
+        def __getattr__(self, name):
+            fn = lambda *a: 1                 # every entry point exists; the version it reports is an old one
+            return fn
+    (tmp_path / "libmdx.so").write_bytes(b"")
+    import ctypes
+    monkeypatch.setattr(ctypes, "CDLL", lambda path: Stale())
+    monkeypatch.setattr(_lib, "_declare", lambda handle: None)
+    with pytest.raises(_lib.MdxError, match="ABI version 1"):
+        _lib.lib()
+
+
+def test_infer_stage_needs_a_device_and_roctx_ranges_are_optional(monkeypatch):
+    """stages/infer.py:18-64 runs on `device`; without one and without a GPU the stage refuses instead of running on the CPU.
+    trace.range_: no-op unless MDIR_AMD_ROCTX=1, then roctx push / pop around the block (library present in the image)."""
+    from mdir_amd import stages, trace
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="needs an MI355X"):
+            stages.infer({"data": {}, "network": {}, "output": {}}, None)
+    monkeypatch.setattr(trace, "_lib", None)
+    monkeypatch.delenv("MDIR_AMD_ROCTX", raising=False)
+    with trace.range_("off"):
+        pass
+    assert trace._lib is False
+    monkeypatch.setattr(trace, "_lib", None)
+    monkeypatch.setenv("MDIR_AMD_ROCTX", "1")
+    ran = []
+    with trace.range_("roxford5k/compute_score"):
+        ran.append(1)
+    assert ran == [1] and trace._lib is not None          # the library if the image has it, False otherwise: both are legal
+    with pytest.raises(KeyError):
+        with trace.range_("x"):
+            raise KeyError("the range is popped on the way out")

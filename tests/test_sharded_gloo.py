@@ -145,8 +145,11 @@ def test_exchange_chunk_policy():
     from mdir_amd.sharded import chunk_bounds, exchange_chunks
     assert exchange_chunks(1004993, 1) == 1
     assert exchange_chunks(1004993, 2) == 3          # 502 k-row shards: 4/7, 2/7, 1/7 -- only the last transfer is exposed
-    assert exchange_chunks(1004993, 4) == 2 and exchange_chunks(1004993, 8) == 1
+    assert exchange_chunks(1004993, 4) == 2 and exchange_chunks(1004993, 8) == 2 and exchange_chunks(1004993, 16) == 1
     assert exchange_chunks(4993, 8) == 1
+    # 125 k-row shards (G = 8): two EQUAL chunks, one round of the chip's workgroup slots each; bigger shards halve
+    assert [y - x for x, y in chunk_bounds(0, 125625, 2)] == [62812, 62813]
+    assert [y - x for x, y in chunk_bounds(0, 251249, 2)] == [167499, 83750]
     b = chunk_bounds(10, 21, 3)
     assert b[0][0] == 10 and b[-1][1] == 21 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
     sizes = [y - x for x, y in chunk_bounds(0, 700000, 3)]

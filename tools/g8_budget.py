@@ -43,10 +43,10 @@ def main():
     out = []
     # --- similarity of the shard: one launch, and the shard cut into chunks (each chunk its own index and launch, as ShardedIndex does)
     cuts = {"1 launch": [(0, n_local)],
-            "2 chunks, halving (4/6, 2/6: chunk_bounds)": [(a - lo, b - lo) for a, b in chunk_bounds(lo, hi, 2)],
-            "2 chunks, equal": [(0, n_local // 2), (n_local // 2, n_local)],
+            "2 chunks, halving (4/6, 2/6)": [(0, n_local * 2 // 3), (n_local * 2 // 3, n_local)],
+            "2 chunks, equal": [(a - lo, b - lo) for a, b in chunk_bounds(lo, hi, 2)],        # what ShardedIndex does at G = 8 (round 5)
             "2 chunks, first = one full round of 512 workgroups (65 536 rows)": [(0, 65536), (65536, n_local)],
-            "3 chunks, halving (4/7, 2/7, 1/7)": [(a - lo, b - lo) for a, b in chunk_bounds(lo, hi, 3)]}
+            "3 chunks, halving (4/7, 2/7, 1/7)": [(0, n_local * 4 // 7), (n_local * 4 // 7, n_local * 6 // 7), (n_local * 6 // 7, n_local)]}
     sims = {}
     for name, pieces in cuts.items():
         ixs = [ops.DescriptorIndex(rows[a:b].contiguous(), "ND") for a, b in pieces]
@@ -78,7 +78,7 @@ def main():
     model = {"optimistic (0.7 of the 7 links, 30 us)": 0.03 + sent / (7 * 153e9 * 0.7) * 1e3,
              "honest (uneven pieces, half the link rate, 80 us of RCCL launch + sync)": 0.08 + sent / (7 * 153e9 * 0.5) * 1e3,
              "pessimistic (a quarter of the link rate, 100 us)": 0.10 + sent / (7 * 153e9 * 0.25) * 1e3}
-    one = 3.47          # the single-GPU step of this round's bench line (similarity 2.63 + ranking 0.84 ms)
+    one = 3.44          # the single-GPU step of this round's bench line (similarity 2.62 + ranking 0.82 ms)
     lines = ["# r05: the G = 8 budget of one rank (VERDICT round 4, item 2c)", "",
              "`tools/g8_budget.py` on one MI355X: rank 0's work of a step of `bench.py --gpus 8` -- the similarity of 70 queries against its "
              "%d-row shard and the exact sort of its %d queries over all %d rows -- with the real kernels; the exchange "
@@ -88,12 +88,12 @@ def main():
     for name, (tot, per, sizes) in sims.items():
         lines.append("| %s | %s | %s | %s | **%.3f** |" % (name, " / ".join(str(s) for s in sizes), " / ".join(str(-(-s // 128)) for s in sizes),
                                                          " / ".join("%.3f" % p for p in per), tot))
-    lines += ["", "Ideal = the single-GPU launch / 8 = %.3f ms." % (2.63 / 8), "",
+    lines += ["", "Ideal = the single-GPU launch / 8 = %.3f ms." % (2.62 / 8), "",
               "## Sort of %d queries x %d rows (`mdx_rank_full_segments` on the peer blocks), ms" % (nq_mine, N), "",
               "| input | ms |", "|---|---|", "| dense [9, N] (`mdx_rank_full`) | %.3f |" % dense]
     for chunks, t in sorts.items():
         lines.append("| %d segments (8 peers x %d chunk%s) | %.3f |" % (8 * chunks, chunks, "" if chunks == 1 else "s", t))
-    lines += ["", "Ideal = the single-GPU ranking x 9 / 70 = %.3f ms." % (0.84 * 9 / 70), "",
+    lines += ["", "Ideal = the single-GPU ranking x 9 / 70 = %.3f ms." % (0.82 * 9 / 70), "",
               "## Step of the slowest rank and speed-up over the single-GPU step (%.2f ms), by exchange model" % one, "",
               "One launch: step = similarity + exchange + sort (nothing overlaps).  Chunks: the transfer of chunk c runs while chunk c+1 "
               "multiplies; exposed = what is left of the earlier transfers when the last kernel ends + the last chunk's transfer.", "",
@@ -104,6 +104,7 @@ def main():
         for key, chunks in (("1 launch", 1), ("2 chunks, first = one full round of 512 workgroups (65 536 rows)", 2), ("2 chunks, equal", 2),
                             ("3 chunks, halving (4/7, 2/7, 1/7)", 3)):
             tot, per, sizes = sims[key]
+            per = [p * tot / sum(per) for p in per]       # the launches' shares of the back-to-back time (the figure that counts)
             xfer = [lat + (t_x - lat) * s / n_local for s in sizes]          # every chunk pays the latency
             busy = 0.0          # when the link is free again, relative to the start of the first kernel
             t = 0.0
