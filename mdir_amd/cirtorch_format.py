@@ -43,7 +43,9 @@ def embed(params, data, device=None):
 
     net = load_upstream(checkpoint).eval()
     if device is None:
-        net.cuda()
+        net.cuda()                      # cirtorch_format/test.py:55
+    else:
+        net.to(device)                  # `device` is this build's extension (CPU tests, cuda:N): the network follows it
     scales = (MS_SCALES if multiscale else [1]) if isinstance(multiscale, bool) else multiscale
     # GeM exponent as the power of the multi-scale mean only when nothing follows the pooling in the network
     msp = float(net.pool.p) if net.meta["pooling"] == "gem" and net.whiten is None and len(scales) > 1 else 1

@@ -437,3 +437,62 @@ def test_argument_checks_of_the_python_shim():
     assert ops.bilinear_pyramid(f(1, 3, 8, 8), [1])[0].shape == (1, 3, 8, 8)
     e = f(0, 4, 3, 3)
     assert ops.bn_act_(e, f(4), f(4)) is e
+
+
+def test_remaining_device_branches(tmp_path, monkeypatch):
+    """What was left of profiles/r05_host_branches.md on the device side: the GeM MODULE called on its own (pooling.py:36-47),
+    `embed` without a device argument (cirtorch_format/test.py:40-41: `net.cuda()`), more than 32 peer blocks into the ranking
+    (concatenated, same result), an architecture the backbones do not know, the communicator's argument checks."""
+    from PIL import Image
+    from mdir_amd import cirtorch_format as C
+    from mdir_amd import layers, ops
+    from mdir_amd.backbones import build_features
+    from mdir_amd.networks import init_network
+    from mdir_amd.sharded import HipBackend
+    x = torch.rand(2, 16, 5, 7, device=DEV) + 0.1
+    gem = layers.GeM(p=2.5).to(DEV)
+    want = x.clamp(min=1e-6).pow(2.5).mean(dim=(2, 3)).pow(1 / 2.5)
+    np.testing.assert_allclose(gem(x).cpu().numpy().reshape(2, 16), want.cpu().numpy(), rtol=2e-5)
+    # embed(device=None) moves the network to the GPU itself
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    rng = np.random.default_rng(5)
+    (tmp_path / "ims").mkdir()
+    imgs = ["a%d.jpg" % i for i in range(3)]
+    for name in imgs:
+        Image.fromarray(rng.integers(0, 255, (120, 160, 3), dtype=np.uint8)).save(tmp_path / "ims" / name, format="JPEG")
+    torch.manual_seed(2)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False})
+    meta = {"architecture": "alexnet", "pooling": "gem", "whitening": False, "mean": net.meta["mean"], "std": net.meta["std"],
+            "outputdim": 256, "local_whitening": False, "regional": False}
+    torch.save({"meta": meta, "state_dict": net.state_dict()}, str(tmp_path / "up.pth"))
+    res = C.embed({"net": str(tmp_path / "up.pth"), "imgdir": str(tmp_path / "ims"), "image_size": 128, "multiscale": True}, (imgs,))
+    on_dev = C.embed({"net": str(tmp_path / "up.pth"), "imgdir": str(tmp_path / "ims"), "image_size": 128, "multiscale": True}, (imgs,), device=DEV)
+    assert res[1] == imgs and res[2].shape == (3, 256)
+    np.testing.assert_allclose(res[2], on_dev[2], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(res[2], axis=1), 1.0, atol=1e-4)
+    # 40 peer blocks: beyond the segment table (32) the blocks are concatenated; same ranking as the dense call
+    sc = (rng.standard_normal((3, 4000)) * 0.03).astype(np.float32)
+    sc[:, 100] = sc[:, 7]
+    blocks = [dev(sc[:, 100 * g:100 * (g + 1)]) for g in range(40)]
+    np.testing.assert_array_equal(HipBackend().rank_full_segments(blocks, 5).cpu().numpy(), OC.rank_full(sc) + 5)
+    np.testing.assert_array_equal(HipBackend().rank_full_segments(blocks[:32], 0).cpu().numpy(), OC.rank_full(sc[:, :3200]))
+    with pytest.raises(ValueError, match="1..32 blocks"):
+        ops.rank_full_segments(blocks)
+    with pytest.raises(ValueError, match="Unsupported or unknown architecture"):
+        build_features("resnet7")
+    with pytest.raises(ValueError, match="need one id list per query"):
+        ops.rank_of(dev(sc), [[1], [2]])
+    # the communicator (one rank: all a one-GPU box can hold)
+    with pytest.raises(ValueError, match="128 bytes"):
+        ops.Comm(b"short", 1, 0, DEV)
+    comm = ops.Comm(ops.Comm.unique_id(), 1, 0, DEV)
+    with pytest.raises(ValueError, match="one width per rank"):
+        comm.allgather_scores(dev(sc), [4000, 10])
+    with pytest.raises(ValueError, match="local block is"):
+        comm.allgather_scores(dev(sc), [3999])
+    with pytest.raises(ValueError, match="local block is"):
+        comm.exchange_scores(dev(sc), [3999])
+    comm.close()
+    comm.close()                                            # closing twice is harmless
+    assert ops.conv1x1_bn_act(torch.rand(0, 16, 3, 3, device=DEV), torch.rand(16, 32, device=DEV), torch.rand(32, device=DEV),
+                              torch.rand(32, device=DEV)).shape == (0, 32, 3, 3)

@@ -97,6 +97,20 @@ def _worker(rank, world, port, n, nq, d, out_dir, chunks, exchange=None):
     pos, off = sh.positions(sh.local_scores(torch.from_numpy(qvecs), "DN"), lists)
     assert np.array_equal(sh.all_scores(torch.from_numpy(qvecs), "DN").numpy(),
                           __import__("oracle.chain", fromlist=["x"]).scores_chain(vecs, qvecs))      # all-gather form
+    # the exchange as its own steps (sharded.py `exchange`, `exchanged_scores`): [Q, n_local] on every rank -> [Q_mine, N]; the
+    # BlockScores container answers like the dense matrix
+    want_all = __import__("oracle.chain", fromlist=["x"]).scores_chain(vecs, qvecs)
+    dense, (elo, ehi) = sh.exchange(sh.local_scores(torch.from_numpy(qvecs), "DN"))
+    assert (elo, ehi) == (qlo, qhi) and np.array_equal(dense.numpy(), want_all[qlo:qhi])
+    again, bounds = sh.exchanged_scores(torch.from_numpy(qvecs), "DN")
+    assert bounds == (qlo, qhi) and np.array_equal(again.numpy(), want_all[qlo:qhi])
+    assert len(sc) == qhi - qlo and sc.shape == (qhi - qlo, n) and np.array_equal(sc.cpu().numpy(), want_all[qlo:qhi])
+    if qhi > qlo:
+        assert np.array_equal(sc[0].numpy(), want_all[qlo])
+    from mdir_amd.sharded import gather_query_vectors
+    qrows = torch.from_numpy(np.ascontiguousarray(qvecs.T))
+    a_lo, a_hi = shard_bounds(nq, world, rank)
+    assert np.array_equal(gather_query_vectors(qrows[a_lo:a_hi], nq).numpy(), qrows.numpy())          # even and uneven slices
     tk_ids, tk_vals = sh.topk_queries(torch.from_numpy(qvecs), 9, "DN")
     big_ids, _ = sh.topk_queries(torch.from_numpy(qvecs), n + 5, "DN")          # k beyond every shard and beyond N
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), ranks=rk.numpy(), scores=sc.dense().numpy(), q=np.array([qlo, qhi]),
@@ -109,7 +123,8 @@ def _worker(rank, world, port, n, nq, d, out_dir, chunks, exchange=None):
                                                         # the node's shapes: 70 queries over 4 and 8 ranks (uneven: 8.75 per rank),
                                                         # shards of 8-9 rows against k = 9, fewer queries than ranks (idle sorters)
                                                         (4, 203, 70, 0, None), (8, 71, 70, 0, None), (8, 203, 70, 2, None),
-                                                        (4, 101, 3, 0, "allgather")])
+                                                        (4, 101, 3, 0, "allgather"),
+                                                        (2, 100, 4, 0, None)])           # queries divide evenly (plain all_gather of the query slices)
 def test_sharded_equals_single_process(tmp_path, world, n, nq, chunks, exchange):
     """chunks > 0: every shard is cut into row chunks whose all-to-alls are in flight together
     (the overlap pipeline used for big shards); exchange="allgather": the fallback taken when the
@@ -241,3 +256,31 @@ def test_sharded_extraction_and_map_equal_single_process(tmp_path, monkeypatch):
             for k in want_per:
                 np.testing.assert_allclose(per[k], want_per[k], rtol=0, atol=1e-12, equal_nan=True)
         assert got[0][ds][0] == got[1][ds][0]
+
+
+def test_single_process_forms_and_argument_errors():
+    """world == 1 (no process group): the sharded calls answer without any collective -- `exchange` hands the scores back,
+    `all_scores` are the local ones, `gather_query_vectors` the slice itself, `phase_ms` has nothing to report; wrong shard
+    sizes and compute modes are refused."""
+    from mdir_amd.sharded import ShardedIndex, gather_query_vectors
+    from oracle import chain as OC
+    from oracle import oracle as O
+    vecs, qvecs, _ = O.synth_ranking_problem(50, 4, 16, seed=2)
+    sh = ShardedIndex(torch.from_numpy(vecs), "DN", 50, backend=OracleBackend())
+    want = OC.scores_chain(vecs, qvecs)
+    local = sh.local_scores(torch.from_numpy(qvecs), "DN")
+    same, bounds = sh.exchange(local)
+    assert same is local and bounds == (0, 4)
+    assert np.array_equal(sh.all_scores(torch.from_numpy(qvecs), "DN").numpy(), want)
+    rk, sc, (qlo, qhi) = sh.rank_queries(torch.from_numpy(qvecs), "DN")
+    assert (qlo, qhi) == (0, 4) and np.array_equal(rk.numpy(), OC.rank_full(want)) and sh.phase_ms() is None
+    ids, vals = sh.topk_queries(torch.from_numpy(qvecs), 5, "DN")
+    assert np.array_equal(ids.numpy(), OC.rank_full(want)[:, :5])
+    q = torch.rand(3, 16)
+    assert gather_query_vectors(q, 3) is q
+    with pytest.raises(ValueError, match="holds 50 rows, expected 49"):
+        ShardedIndex(torch.from_numpy(vecs), "DN", 49, backend=OracleBackend())
+    with pytest.raises(ValueError, match="compute"):
+        ShardedIndex(torch.from_numpy(vecs), "DN", 50, backend=OracleBackend(), compute="bf16x9")
+    with pytest.raises(ValueError, match="multiplies an fp32 shard"):
+        ShardedIndex(torch.from_numpy(vecs), "DN", 50, backend=OracleBackend(), storage="f16", compute="split3")

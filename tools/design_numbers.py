@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 b = json.load(open(os.path.join(root, "profiles", tag + "_bench_line.json")))
 t = json.load(open(os.path.join(root, "profiles", tag + "_traffic.json")))
@@ -49,7 +49,9 @@ rows = [
     ("CPU reference beside it (np.dot + np.argsort, %s host cores)" % cpu.get("cores"), "%s queries/s (%s with the BLAS pool at 3 threads)"
      % (f(cpu.get("value"), "%.1f"), f(cpu.get("value_blas_3_threads"), "%.1f")), "`cpu_baseline`"),
     ("sort-free evaluation route (similarity + rank counting, same mAP)", "%s queries/s" % f(g(b, "sort_free_map_route", "value"), "%.0f"), "`sort_free_map_route`"),
-    ("two-stream throughput form", "%s queries/s" % f(g(b, "pipelined_two_streams", "value"), "%.0f"), "`pipelined_two_streams`"),
+    ("spread over the timed steps of this run (min / median / max): similarity ms; ranking ms; queries/s",
+     "%s / %s / %s; %s / %s / %s; %s / %s / %s" % tuple(f(g(b, "spread_over_timed_steps", k, m), fmt) for k, fmt in (("kernel_ms", "%.3f"), ("rank_ms", "%.3f"), ("value", "%.0f"))
+                                                      for m in ("min", "median", "max")), "`spread_over_timed_steps`"),
     ("LABELLED split-precision mode `MDX_F32_SPLIT3` on the same shard", "%s ms (exact chain %s) = %s GB/s of algorithmic bytes = %s of 8 TB/s; max abs(diff) %s; top-100 slot agreement %s; with the fp32 ranking %s queries/s"
      % (f(g(sec, "split3", "scores_ms")), f(g(sec, "split3", "exact_chain_scores_ms")), f(g(sec, "split3", "roofline", "achieved"), "%.0f"),
         f(g(sec, "split3", "roofline", "frac")), f(g(sec, "split3", "max_abs_diff_vs_exact_chain"), "%.1e"),
