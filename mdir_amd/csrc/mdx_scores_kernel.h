@@ -222,7 +222,9 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
             else if (younger == 1 && NSTAGE > 3)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_LOADER) : "memory");
             else                                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                   // B_c
+#ifndef MDX_ABL_NOLOAD              // timing only (tools/scores_where.sh): the ring is filled once and never again -- no LDS-DMA beside the MFMAs
             if (c + NSTAGE - 1 < nchunks) issue(c + NSTAGE - 1);            // refill the slot of stage c-1
+#endif
         }
         return;
     }
@@ -253,13 +255,20 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
         f32x4 a[QT > 0 ? QT : 1], b[R], bn[R], an0;
         f32x4 al[4], bl[4];
         constexpr int PIN = 0x0002 | 0x0004 | 0x0070 | 0x0380 | 0x0400;
+#ifdef MDX_ABL_NOLDSREAD             // timing only: operands are read for the first chunk and reused -- no ds_read beside the MFMAs
+        bool abl_read = true;
+#else
+        constexpr bool abl_read = true;
+#endif
         auto read_first = [&](const f32x4 *slot, int kb) __attribute__((always_inline)) {
+            if (!abl_read) return;
             const f32x4 *bs = slot + (QTILES + wave * R * KC) * 64 + lane;
 #pragma unroll
             for (int r = 0; r < R; ++r) bn[r] = bs[(r * KC + kb) * 64];
             an0 = slot[kb * 64 + lane];
         };
         auto read_left = [&](const f32x4 *slot, int kb) __attribute__((always_inline)) {
+            if (!abl_read) return;
             if constexpr (QR != 0) {
                 const f32x4 *ql = slot + (QT * KC + kb) * 64 + l_q;
                 const f32x4 *bw = slot + (QTILES + wave * R * KC + kb) * 64 + l_boff;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                             }
                         }
                     }
-                    if (t == 3 && q != 0 && nslot) {                    // a[q] is dead: the next block's tile q
+                    if (t == 3 && q != 0 && nslot && abl_read) {        // a[q] is dead: the next block's tile q
                         __builtin_amdgcn_sched_barrier(0);
                         a[q] = nslot[(q * KC + nkb) * 64 + lane];
                         __builtin_amdgcn_sched_barrier(0);
@@ -317,6 +326,9 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
             read_left(slot, 0);
             block(slot, 1, true, []() {});
             read_left(slot, 1);
+#ifdef MDX_ABL_NOLDSREAD
+            if (c >= 1) abl_read = false;
+#endif
             block(more ? next : nullptr, 0, false, [&]() __attribute__((always_inline)) {
                 if (more) {
                     __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): every read of this stage is back
