@@ -246,7 +246,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     unsigned long long tr0 = 0, tc0 = 0;
     if (STAMPS) { tr0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory"); tc0 = ts0; }
     if constexpr (PIPE) {
-        static_assert(MM::STEPS == 4 && KC == 2 && !RM && !STAMPS, "pipelined consumer: fp32 tiles, two k-blocks per stage");
+        static_assert(MM::STEPS == 4 && (KC == 2 || KC == 1) && !RM && !STAMPS, "pipelined consumer: fp32 tiles, one or two k-blocks per stage");
         // Registers: a full second operand set does not fit beside the accumulators and the leftover operands (128 registers per
         // wave at two workgroups per CU), so only what a block's FIRST MFMAs need is read ahead -- its database operands bn[] and
         // query tile 0 (an0); query tiles 1.. are read into a[1..] during the previous block's last step, each right after the
@@ -323,9 +323,11 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
             const f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
             const f32x4 *next = ring + ((c + 1) % NSTAGE) * (STAGE_TILES * 64);
             const bool more = c + 1 < nchunks;
-            read_left(slot, 0);
-            block(slot, 1, true, []() {});
-            read_left(slot, 1);
+            if constexpr (KC == 2) {
+                read_left(slot, 0);
+                block(slot, 1, true, []() {});
+            }
+            read_left(slot, KC - 1);
 #ifdef MDX_ABL_NOLDSREAD
             if (c >= 1) abl_read = false;
 #endif
