@@ -599,16 +599,15 @@ def main():
                               "cores) + np.argsort %.2f s (1 thread), N=%d Q=%d D=%d fp32" % (world - 1, t_dot, t_sort, n_total, NQ, DIM)}
                 extra["map_medium_cpu"] = avg_cpu["map_medium"]
                 # same statement as the single-GPU line: BLAS order vs the k-ordered chain may swap rows inside near-ties only
-                assert abs(avg_cpu["map_medium"] - extra["map_medium"]) <= 1e-5, (avg_cpu["map_medium"], extra["map_medium"])
+                # (recorded, not asserted: an exception on rank 0 alone would leave the other ranks in the barrier below)
                 extra["map_equals_cpu_path"] = bool(avg_cpu["map_medium"] == extra["map_medium"])
+                extra["map_within_1e-5_of_cpu_path"] = bool(abs(avg_cpu["map_medium"] - extra["map_medium"]) <= 1e-5)
                 # rank 0's queries: the head of its rows of the sharded ranking against the CPU ranking's columns
                 rk0, (q0lo, q0hi) = keep["rk"], keep["q"]
                 if q0hi > q0lo:
                     head = rk0[:, :100].t().cpu().numpy()
                     extra["cpu_top100_id_agreement"] = round(float((rk_cpu[:100, q0lo:q0hi] == head).mean()), 6)
                 del vecs_host, rk_cpu
-            except AssertionError:
-                raise
             except Exception as exc:          # the reported baseline must not cost the measured line
                 extra["cpu_baseline"] = {"value": None, "unit": "queries/s", "error": "%s: %s" % (type(exc).__name__, exc)}
         dist.barrier()

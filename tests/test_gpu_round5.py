@@ -173,7 +173,7 @@ def test_bench_with_eight_ranks_on_one_gpu(form, one_rank_line):
     for ln in (line, one):
         assert ln["roofline"]["bound"] == "mfma" and ln["roofline"]["frac"] > 0 and "traffic" in ln["roofline"]
         assert ln["cpu_baseline"]["value"] > 0 and ln["cpu_baseline"]["kind"] == "port" and ln["cpu_baseline"]["cores"] >= 1
-        assert abs(ln["map_medium_cpu"] - ln["map_medium"]) <= 1e-5
+        assert abs(ln["map_medium_cpu"] - ln["map_medium"]) <= 1e-5 and ln.get("map_within_1e-5_of_cpu_path", True)
         sp = ln["spread_over_timed_steps"]
         assert sp["steps"] == 3 and sp["step_ms"]["min"] <= sp["step_ms"]["median"] <= sp["step_ms"]["max"]
         assert sp["value"]["min"] <= sp["value"]["median"] <= sp["value"]["max"]
