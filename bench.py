@@ -290,6 +290,8 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from mdir_amd.sharded import private_miopen_caches
+        private_miopen_caches(os.environ.get("LOCAL_RANK", "0"))      # before this process's first convolution (the extraction leg)
         import datetime
         limit = datetime.timedelta(seconds=900)       # a collective that cannot complete ends the run instead of hanging it
         if dryrun:

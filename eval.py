@@ -57,6 +57,8 @@ def init_distributed():
     import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from mdir_amd.sharded import private_miopen_caches
+    private_miopen_caches(local)
     import datetime
     limit = datetime.timedelta(minutes=30)            # extraction of a rank's slice happens between collectives
     if os.environ.get("MDIR_AMD_DRYRUN_ONE_GPU") == "1":

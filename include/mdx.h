@@ -85,6 +85,17 @@ int mdx_capture_recover(void *stream);
 int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float p,
                  float pool_eps, float l2n_eps, float *out, void *stream);
 
+/* R-MAC pooling: feat [B,C,H,W] row-major  ->  out [B,C] (NOT yet L2-normalised as a whole: the network's `self.norm` follows).
+ * Replaces `LF.rmac(x, L, eps)` (cirtorch/layers/functional.py:26-72; module RMAC, layers/pooling.py:50-60):
+ *     v = l2n(max over the map);  for every region of the grid: v += l2n(max over the region)      (l2n: eps added to the norm)
+ *   regions : HOST array [nregions][4] int32 = (row0, col0, height, width), the whole map first, then the grid in the
+ *             reference's order (levels 1..L, rows of centres outer, columns inner); the host restates the reference's float32
+ *             grid arithmetic (mdir_amd/layers.py: rmac_regions).  At most 64 regions (L = 3 gives 15-51).
+ *   workspace: mdx_rmac_workspace(B, C, nregions) bytes of device memory (the regions' maxima). */
+int64_t mdx_rmac_workspace(int B, int C, int nregions);
+int mdx_rmac(const float *feat, int B, int C, int H, int W, const int32_t *regions, int nregions, float eps,
+             void *workspace, int64_t workspace_bytes, float *out, void *stream);
+
 /* The S feature maps of one image pyramid (or of a batch of B equal-sized images), pooled by ONE launch:
  *   feats[s] [B,C,H[s],W[s]] row-major  ->  pooled [S,B,C]   (no normalisation)
  * Replaces the S calls of `self.pool(o)` (imageretrievalnet.py:108; LF.gem / LF.mac / LF.spoc,

@@ -304,6 +304,88 @@ int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float 
     return MDX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// R-MAC (cirtorch/layers/functional.py:26-72): maxima over the whole map and over a grid of square regions, each
+// L2-normalised over the channels (eps added to the norm), summed in region order.  The grid is the caller's (the reference
+// computes it in float32 tensor arithmetic; the host restates that, mdir_amd/layers.py).
+// Launch 1: one wave per (image, channel) plane -- the plane is read ONCE into registers (lane = column block), every region's
+// maximum is a masked wave reduction: regmax[b][r][c].  Launch 2: one workgroup per image walks the regions in order: norm over
+// the channels (workgroup reduction), v += max / (norm + eps).
+// ---------------------------------------------------------------------------
+constexpr int RMAC_MAX_REGIONS = 64;
+struct RmacGrid { int i0[RMAC_MAX_REGIONS], j0[RMAC_MAX_REGIONS], h[RMAC_MAX_REGIONS], w[RMAC_MAX_REGIONS]; int n; };
+
+__global__ __launch_bounds__(256) void rmac_max_kernel(const float *__restrict__ feat, int64_t planes, int C, int H, int W, RmacGrid grid,
+                                                       float *__restrict__ regmax)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const float *p = feat + plane * (int64_t)H * W;
+    const int64_t b = plane / C, c = plane % C;
+    for (int r = 0; r < grid.n; ++r) {
+        const int i0 = grid.i0[r], j0 = grid.j0[r], rh = grid.h[r], rw = grid.w[r];
+        float m = -INFINITY;
+        for (int e = lane; e < rh * rw; e += 64) m = fmaxf(m, p[(i0 + e / rw) * W + j0 + e % rw]);   // (the map is L2-resident after region 0)
+        m = wave_max(m);
+        if (lane == 0) regmax[(b * grid.n + r) * C + c] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void rmac_sum_kernel(const float *__restrict__ regmax, int C, int nreg, float eps, float *__restrict__ out)
+{
+    __shared__ float part[4];
+    const int tid = threadIdx.x;
+    const float *m = regmax + (int64_t)blockIdx.x * nreg * C;
+    float *o = out + (int64_t)blockIdx.x * C;
+    for (int r = 0; r < nreg; ++r) {
+        float ss = 0.0f;
+        for (int k = tid; k < C; k += 256) ss += m[r * (int64_t)C + k] * m[r * (int64_t)C + k];
+        ss = wave_sum(ss);
+        __syncthreads();                       // `part` of the previous region has been read by everybody
+        if ((tid & 63) == 0) part[tid >> 6] = ss;
+        __syncthreads();
+        const float den = sqrtf((part[0] + part[1]) + (part[2] + part[3])) + eps;
+        for (int k = tid; k < C; k += 256) {
+            const float v = m[r * (int64_t)C + k] / den;
+            o[k] = r == 0 ? v : o[k] + v;       // a thread owns its channels: no hazard between regions
+        }
+    }
+}
+
+int64_t mdx_rmac_workspace(int B, int C, int nregions)
+{
+    if (B <= 0 || C <= 0 || nregions <= 0) return 0;
+    return (int64_t)B * nregions * C * 4;
+}
+
+int mdx_rmac(const float *feat, int B, int C, int H, int W, const int32_t *regions, int nregions, float eps, void *workspace,
+             int64_t workspace_bytes, float *out, void *stream)
+{
+    MDX_CHECK_ARG(feat && regions && out, "mdx_rmac: NULL pointer");
+    MDX_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "mdx_rmac: bad shape [%d,%d,%d,%d]", B, C, H, W);
+    MDX_CHECK_ARG(nregions >= 1 && nregions <= RMAC_MAX_REGIONS, "mdx_rmac: %d regions, 1..%d supported", nregions, RMAC_MAX_REGIONS);
+    MDX_CHECK_ARG(eps >= 0.0f, "mdx_rmac: eps=%g", (double)eps);
+    const int64_t need = mdx_rmac_workspace(B, C, nregions);
+    if (!workspace || workspace_bytes < need) {
+        set_error("mdx_rmac: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+        return MDX_ERR_WORKSPACE;
+    }
+    RmacGrid grid;
+    grid.n = nregions;
+    for (int r = 0; r < nregions; ++r) {
+        grid.i0[r] = regions[4 * r]; grid.j0[r] = regions[4 * r + 1]; grid.h[r] = regions[4 * r + 2]; grid.w[r] = regions[4 * r + 3];
+        MDX_CHECK_ARG(grid.i0[r] >= 0 && grid.j0[r] >= 0 && grid.h[r] > 0 && grid.w[r] > 0 && grid.i0[r] + grid.h[r] <= H && grid.j0[r] + grid.w[r] <= W,
+                      "mdx_rmac: region %d = (%d, %d, %d, %d) outside the %d x %d map", r, grid.i0[r], grid.j0[r], grid.h[r], grid.w[r], H, W);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t planes = (int64_t)B * C;
+    hipLaunchKernelGGL(rmac_max_kernel, dim3((unsigned)ceil_div(planes, (int64_t)4)), dim3(256), 0, s, feat, planes, C, H, W, grid, (float *)workspace);
+    hipLaunchKernelGGL(rmac_sum_kernel, dim3((unsigned)B), dim3(256), 0, s, (const float *)workspace, C, nregions, eps, out);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
 int mdx_pool_multi(const float *const *feats, int S, int B, int C, const int *H, const int *W, int kind, float p,
                    float pool_eps, float *pooled, void *stream)
 {

@@ -4,9 +4,13 @@ Drop-in for ``mdir/external/cirtorch/layers/{functional,pooling,normalization}.p
 (the global poolings ``mac``/``spoc``/``gem`` :11-22, ``l2n`` :130-131; modules
 ``MAC``/``SPoC``/``GeM`` pooling.py:14-47, ``L2N`` normalization.py:10-20).  The
 arithmetic runs in the HIP library (``mdx_pool_l2n`` / ``mdx_l2n_rows``); there is
-no torch-op or CPU fallback.  ``rmac`` / ``Rpool`` / losses are out of scope
-(SURVEY.md section 2 row 4).
+no torch-op or CPU fallback.  ``rmac`` / ``RMAC`` (functional.py:26-72, pooling.py:50-60; round 5) complete the
+``POOLING`` registry of imageretrievalnet.py:32-37; ``Rpool`` (regional pooling with a whitening per region) and the losses are
+out of scope.
 """
+import functools
+import math
+
 import torch
 import torch.nn as nn
 from torch.nn.parameter import Parameter
@@ -33,6 +37,39 @@ def spoc(x):
 
 def gem(x, p=3, eps=1e-6):
     return _pool(x, "gem", _as_scalar(p), eps)
+
+
+@functools.lru_cache(maxsize=256)
+def rmac_regions(H, W, L=3):
+    """``[(row0, col0, height, width), ...]`` of R-MAC on an ``H x W`` map: the whole map, then the grid of
+    functional.py:26-72 in its order.  The reference computes the grid with float32 TENSORS (``torch.Tensor([2..7])``,
+    ``torch.floor(wl2 + torch.Tensor(range(n)) * b)``); the same tensor arithmetic here, on the host, so that every window
+    starts where the reference's does: along the longer side the number of extra windows is the one of 1..6 whose overlap
+    ``(w^2 - w b) / w^2`` is closest to 0.4; level l = 1..L has windows of ``floor(2 w / (l + 1))`` (skipped when 0)."""
+    steps = torch.tensor([2, 3, 4, 5, 6, 7], dtype=torch.float32)
+    w = min(W, H)
+    b = (max(H, W) - w) / (steps - 1)
+    idx = int(torch.min(torch.abs(((w ** 2 - w * b) / w ** 2) - 0.4), 0)[1])
+    extra_w, extra_h = (idx + 1 if H < W else 0), (idx + 1 if H > W else 0)
+    regions = [(0, 0, H, W)]
+    for l in range(1, L + 1):
+        wl = math.floor(2 * w / (l + 1))
+        if wl == 0:
+            continue
+        wl2 = math.floor(wl / 2 - 1)
+
+        def starts(size, count):
+            step = 0 if count == 1 else (size - wl) / (count - 1)
+            return (torch.floor(wl2 + torch.arange(count, dtype=torch.float32) * step) - wl2).tolist()
+        for i0 in starts(H, l + extra_h):
+            for j0 in starts(W, l + extra_w):
+                regions.append((int(i0), int(j0), wl, wl))
+    return tuple(regions)
+
+
+def rmac(x, L=3, eps=1e-6):
+    """R-MAC (functional.py:26-72): ``[B,C,H,W] -> [B,C,1,1]``, NOT normalised as a whole (``self.norm`` follows in the network)."""
+    return ops.rmac(x.contiguous(), rmac_regions(int(x.shape[2]), int(x.shape[3]), int(L)), eps).reshape(x.shape[0], x.shape[1], 1, 1)
 
 
 def l2n(x, eps=1e-6):
@@ -84,6 +121,21 @@ class GeM(nn.Module):
         return self.__class__.__name__ + "(p={:.4f}, eps={})".format(self.p.data.tolist()[0], self.eps)
 
 
+class RMAC(nn.Module):
+    """pooling.py:50-60."""
+
+    def __init__(self, L=3, eps=1e-6):
+        super().__init__()
+        self.L = L
+        self.eps = eps
+
+    def forward(self, x):
+        return rmac(x, L=self.L, eps=self.eps)
+
+    def __repr__(self):
+        return self.__class__.__name__ + "(L={})".format(self.L)
+
+
 class L2N(nn.Module):
     def __init__(self, eps=1e-6):
         super().__init__()
@@ -96,7 +148,7 @@ class L2N(nn.Module):
         return self.__class__.__name__ + "(eps=" + str(self.eps) + ")"
 
 
-POOLING = {"mac": MAC, "spoc": SPoC, "gem": GeM}   # networks/imageretrievalnet.py:32-37 minus rmac
+POOLING = {"mac": MAC, "spoc": SPoC, "gem": GeM, "rmac": RMAC}   # networks/imageretrievalnet.py:32-37
 
 
 def pool_kind(pool):

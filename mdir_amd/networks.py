@@ -120,7 +120,7 @@ def init_network(params):
     if regional:
         raise NotImplementedError("regional pooling (Rpool) is outside the MI355X hot path")
     if pooling not in POOLING:
-        raise KeyError("pooling '%s' is outside the MI355X hot path (%s)" % (pooling, sorted(POOLING)))
+        raise KeyError("pooling '%s' is not one of %s" % (pooling, sorted(POOLING)))
     dim = OUTPUT_DIM[architecture]
     features = build_features(architecture)
     lwhiten = nn.Linear(dim, dim, bias=True) if local_whitening else None

@@ -90,6 +90,25 @@ def pool_l2n(feat, kind="gem", p=3.0, pool_eps=1e-6, l2n_eps=1e-6):
     return out
 
 
+def rmac(feat, regions, eps=1e-6):
+    """R-MAC pooling ``[B,C,H,W] -> [B,C]`` over the given regions (``[(row0, col0, height, width), ...]``, the whole map
+    first): ``sum_r l2n(max over region r)`` -- ``LF.rmac`` (functional.py:26-72) through ``mdx_rmac``."""
+    fp = _dev(feat, torch.float32, "feature map")
+    if feat.dim() != 4:
+        raise ValueError("feature map must be [B,C,H,W]")
+    B, C, H, W = feat.shape
+    n = len(regions)
+    if not 1 <= n <= 64:
+        raise ValueError("1..64 regions supported, got %d" % n)
+    flat = (ctypes.c_int32 * (4 * n))(*[int(v) for reg in regions for v in reg])
+    out = torch.empty((B, C), dtype=torch.float32, device=feat.device)
+    ws = _workspace(_lib.lib().mdx_rmac_workspace(B, C, n), feat.device)
+    with _on(feat):
+        check(_lib.lib().mdx_rmac(fp, B, C, H, W, flat, n, float(eps), _vp(ws.data_ptr()), ws.numel(), _vp(out.data_ptr()), _stream()),
+              "mdx_rmac")
+    return out
+
+
 def l2n_rows_(x, bias=None, eps=1e-6):
     """In place ``(x + bias) / (||x + bias|| + eps)`` per row of a [R,D] matrix."""
     xp = _dev(x, torch.float32, "x")

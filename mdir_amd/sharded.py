@@ -83,6 +83,19 @@ class BlockScores:
         return self.blocks[0] if len(self.blocks) == 1 else torch.cat(self.blocks, dim=1)
 
 
+def private_miopen_caches(local_rank):
+    """One process per GPU: give every rank its OWN MIOpen user database and kernel cache directory (unless the user has set
+    them).  MIOpen keeps both in sqlite files under ~/.config/miopen and ~/.cache/miopen; eight ranks that meet the same new
+    convolution shapes at the same moment would all write them at once.  Must run before the process's first convolution."""
+    import os
+    import tempfile
+    base = os.path.join(tempfile.gettempdir(), "mdir_amd_miopen_%d_rank%d" % (os.getuid(), int(local_rank)))
+    for var, sub_dir in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+        if var not in os.environ:
+            os.makedirs(os.path.join(base, sub_dir), exist_ok=True)
+            os.environ[var] = os.path.join(base, sub_dir)
+
+
 def shard_bounds(n_total, world, rank):
     """Rows ``[lo, hi)`` of shard ``rank``: contiguous, sizes differ by at most one."""
     base, rem = divmod(n_total, world)

@@ -17,6 +17,8 @@ every function below against them.
 All arithmetic is float32 unless stated (the reference computes in fp32 on the
 device and in float64 only inside compute_map / whitenapply-with-f64-P).
 """
+import math
+
 import numpy as np
 
 F32 = np.float32
@@ -51,6 +53,48 @@ def spoc(x):
     """Global average pooling ``[B,C,H,W] -> [B,C]`` (``layers/functional.py:16-17``)."""
     x = np.asarray(x, dtype=F32)
     return x.reshape(x.shape[0], x.shape[1], -1).mean(axis=2, dtype=F32)
+
+
+def rmac_regions(H, W, L=3):
+    """The square regions of R-MAC on an ``H x W`` map as ``(i0, j0, size)`` rows, whole-map term NOT included.
+
+    Reference: ``layers/functional.py:26-72`` (the same grid in ``roipool`` :75-121).  The reference computes the grid in
+    float32 tensors (``torch.Tensor([...])``, ``torch.floor``); so does this, with numpy float32: the number of regions along
+    the longer side is the one of 2..7 whose overlap is closest to 0.4, level ``l`` has windows of ``floor(2 w / (l + 1))``
+    spaced evenly with float32 steps.
+    """
+    ovr = 0.4
+    steps = np.array([2, 3, 4, 5, 6, 7], dtype=F32)
+    w = min(W, H)
+    b = (F32(max(H, W) - w) / (steps - F32(1))).astype(F32)
+    idx = int(np.argmin(np.abs(((F32(w * w) - F32(w) * b) / F32(w * w)) - F32(ovr))))        # first minimum, as torch.min
+    Wd = idx + 1 if H < W else 0
+    Hd = idx + 1 if H > W else 0
+    out = []
+    for l in range(1, L + 1):
+        wl = math.floor(2 * w / (l + 1))
+        wl2 = math.floor(wl / 2 - 1)
+        bw = 0 if l + Wd == 1 else (W - wl) / (l + Wd - 1)
+        cen_w = np.floor(F32(wl2) + np.arange(l - 1 + Wd + 1, dtype=F32) * F32(bw)) - F32(wl2)
+        bh = 0 if l + Hd == 1 else (H - wl) / (l + Hd - 1)
+        cen_h = np.floor(F32(wl2) + np.arange(l - 1 + Hd + 1, dtype=F32) * F32(bh)) - F32(wl2)
+        for i_ in cen_h.tolist():
+            for j_ in cen_w.tolist():
+                if wl == 0:
+                    continue
+                out.append((int(i_), int(j_), wl))
+    return out
+
+
+def rmac(x, L=3, eps=1e-6):
+    """R-MAC pooling ``[B,C,H,W] -> [B,C]``: the L2-normalised (eps added to the norm) global maximum plus the
+    L2-normalised maxima of every region, summed in region order (``layers/functional.py:26-72``)."""
+    x = np.asarray(x, dtype=F32)
+    B, C, H, W = x.shape
+    v = l2n(x.reshape(B, C, -1).max(axis=2), eps)
+    for i0, j0, wl in rmac_regions(H, W, L):
+        v = (v + l2n(x[:, :, i0:i0 + wl, j0:j0 + wl].reshape(B, C, -1).max(axis=2), eps)).astype(F32)
+    return v
 
 
 def l2n(x, eps=1e-6):

@@ -20,6 +20,16 @@ def pool_l2n(feat, kind="gem", p=3.0, pool_eps=1e-6, l2n_eps=1e-6):
     return torch.from_numpy(np.ascontiguousarray(pooled))
 
 
+def rmac(feat, regions, eps=1e-6):
+    """The product's region list (whole map first) through the oracle's arithmetic: sum of the L2-normalised region maxima."""
+    x = feat.detach().numpy()
+    v = None
+    for i0, j0, h, w in regions:
+        t = O.l2n(x[:, :, i0:i0 + h, j0:j0 + w].reshape(x.shape[0], x.shape[1], -1).max(axis=2), eps)
+        v = t if v is None else (v + t).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(v))
+
+
 def l2n_rows_(x, bias=None, eps=1e-6):
     v = x.detach().numpy()
     if bias is not None:
@@ -162,7 +172,7 @@ def project_f64(p, x, center=None):
     return torch.from_numpy(p.detach().numpy() @ xv)
 
 
-NAMES = ("clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "scores_rowmajor", "rank_full", "topk", "rank_of",
+NAMES = ("rmac", "clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "scores_rowmajor", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 

@@ -336,6 +336,7 @@ def main():
                    "list_merge_raises": list_err, "three_way": three, "metadata": meta_out}, f, indent=1)
     make_next_rows()
     make_tables()
+    make_rmac()
     print("golden fixtures written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-28s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))
@@ -517,6 +518,20 @@ def make_tables():
                                     "gnd": score.gnd})
     with open(os.path.join(HERE, "g16_tables.json"), "w") as f:
         json.dump(g16, f, indent=1)
+
+
+def make_rmac():
+    """G17: R-MAC pooling (cirtorch/layers/functional.py:26-72, pooling.py:50-60) on ReLU-like maps regenerated from seeds;
+    only the reference's outputs are stored."""
+    import cirtorch.layers.functional as LF
+    g17 = {}
+    for c, h, w, b in [(2048, 24, 32, 1), (512, 48, 64, 1), (64, 17, 23, 2), (256, 7, 5, 1), (16, 3, 40, 2), (8, 12, 12, 1), (4, 2, 2, 1)]:
+        seed = 1700 + h * 100 + w
+        x = torch.from_numpy(sparse_map(seed, (b, c, h, w)))
+        g17["seed_c%d_h%d_w%d_b%d" % (c, h, w, b)] = seed
+        for L in (3, 2):
+            g17["rmac_c%d_h%d_w%d_b%d_L%d" % (c, h, w, b, L)] = LF.rmac(x.clone(), L=L, eps=1e-6).numpy().reshape(b, c)
+    np.savez_compressed(os.path.join(HERE, "g17_rmac.npz"), **g17)
 
 
 def _jsonable(o):

@@ -496,3 +496,34 @@ def test_remaining_device_branches(tmp_path, monkeypatch):
     comm.close()                                            # closing twice is harmless
     assert ops.conv1x1_bn_act(torch.rand(0, 16, 3, 3, device=DEV), torch.rand(16, 32, device=DEV), torch.rand(32, device=DEV),
                               torch.rand(32, device=DEV)).shape == (0, 32, 3, 3)
+
+
+def test_rmac_on_the_device(golden):
+    """mdx_rmac (LF.rmac, functional.py:26-72) against golden G17 at the path's map sizes, against the oracle on odd shapes, and
+    inside a network: `pooling: rmac` end to end == l2n(rmac(features))."""
+    from conftest import sparse_map
+    from mdir_amd import layers, ops
+    from mdir_amd.networks import init_network
+    g = golden("g17_rmac.npz")
+    for c, h, w, b in [(2048, 24, 32, 1), (512, 48, 64, 1), (64, 17, 23, 2), (256, 7, 5, 1), (16, 3, 40, 2), (8, 12, 12, 1), (4, 2, 2, 1)]:
+        x = sparse_map(int(g["seed_c%d_h%d_w%d_b%d" % (c, h, w, b)]), (b, c, h, w))
+        for L in (3, 2):
+            got = layers.rmac(dev(x), L=L).cpu().numpy().reshape(b, c)
+            np.testing.assert_allclose(got, g["rmac_c%d_h%d_w%d_b%d_L%d" % (c, h, w, b, L)], rtol=2e-6, atol=2e-6)
+    rng = np.random.default_rng(0)
+    for b, c, h, w in [(3, 70, 33, 9), (1, 1, 1, 1), (2, 300, 5, 64), (1, 2048, 12, 16)]:
+        x = (rng.standard_normal((b, c, h, w)) * (rng.random((b, c, h, w)) > 0.5)).astype(np.float32)      # negative values too
+        np.testing.assert_allclose(layers.RMAC()(dev(x)).cpu().numpy().reshape(b, c), O.rmac(x, 3, 1e-6), rtol=2e-6, atol=2e-6)
+    zero = layers.rmac(torch.zeros(1, 8, 6, 6, device=DEV))
+    assert not torch.isnan(zero).any() and float(zero.abs().max()) == 0.0        # eps is added to every norm
+    with pytest.raises(ValueError, match="regions"):
+        ops.rmac(torch.rand(1, 4, 3, 3, device=DEV), [])
+    with pytest.raises(Exception, match="outside"):
+        ops.rmac(torch.rand(1, 4, 3, 3, device=DEV), [(0, 0, 3, 3), (1, 1, 3, 3)])
+    torch.manual_seed(0)
+    net = init_network({"architecture": "resnet18", "pooling": "rmac", "whitening": False, "pretrained": False}).to(DEV).eval()
+    x = torch.rand(2, 3, 224, 160, device=DEV)
+    with torch.no_grad():
+        got = net(x)
+        want = O.l2n(O.rmac(net.features(x).cpu().numpy(), 3, 1e-6), 1e-6)
+    np.testing.assert_allclose(got.t().cpu().numpy(), want, rtol=1e-5, atol=1e-6)

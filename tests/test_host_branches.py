@@ -41,8 +41,8 @@ def test_normalize_strict_shape_argument():
 
 
 def test_init_cirnet_requires_its_keys_and_init_network_refuses_what_is_out_of_scope():
-    """cirnet.py:10-13 (every key of the list must be given); imageretrievalnet.py:155-164 architectures; regional pooling and
-    'rmac' are named as outside the path instead of silently building something else."""
+    """cirnet.py:10-13 (every key of the list must be given); imageretrievalnet.py:155-164 architectures; regional pooling (Rpool) is
+    named as outside the path instead of silently building something else; an unknown pooling is a KeyError as in the reference."""
     from mdir_amd.network import init_cirnet
     from mdir_amd.networks import init_network
     full = {"cir_architecture": "alexnet", "local_whitening": False, "pooling": "gem", "regional": False, "whitening": False, "pretrained": False}
@@ -58,8 +58,8 @@ def test_init_cirnet_requires_its_keys_and_init_network_refuses_what_is_out_of_s
         init_network({"architecture": "resnet7", "pretrained": False})
     with pytest.raises(NotImplementedError, match="regional"):
         init_network({"architecture": "alexnet", "regional": True, "pretrained": False})
-    with pytest.raises(KeyError, match="rmac"):
-        init_network({"architecture": "alexnet", "pooling": "rmac", "pretrained": False})
+    with pytest.raises(KeyError, match="not one of"):
+        init_network({"architecture": "alexnet", "pooling": "rpool", "pretrained": False})
 
 
 def test_network_repr_out_dim_and_local_feature_file(tmp_path, capsys):
@@ -298,3 +298,47 @@ def test_infer_stage_needs_a_device_and_roctx_ranges_are_optional(monkeypatch):
     with pytest.raises(KeyError):
         with trace.range_("x"):
             raise KeyError("the range is popped on the way out")
+
+
+def test_rmac_region_grid_module_and_network(fops, golden):
+    """The product's R-MAC region grid (float32 tensor arithmetic of functional.py:26-72 restated in mdir_amd/layers.py) equals
+    the oracle's for every map size of the path; `RMAC` module / `POOLING["rmac"]` / `init_network(pooling="rmac")`
+    (pooling.py:50-60, imageretrievalnet.py:32-37,200): golden G17 through the host layer (oracle arithmetic on the product's grid)."""
+    from conftest import sparse_map
+    from mdir_amd import layers
+    from mdir_amd.networks import init_network
+    from oracle import oracle as O
+    for h in list(range(1, 41)) + [48, 64, 100]:
+        for w in (1, 2, 3, 5, 7, 12, 17, 23, 24, 32, 33, 45, 48, 64, 100):
+            for L in (1, 2, 3):
+                got = layers.rmac_regions(h, w, L)
+                assert got[0] == (0, 0, h, w)
+                assert [(i, j, s) for i, j, s, _ in got[1:]] == O.rmac_regions(h, w, L), (h, w, L)
+                assert all(s == t and i + s <= h and j + t <= w for i, j, s, t in got[1:])
+    g = golden("g17_rmac.npz")
+    for c, h, w, b in [(64, 17, 23, 2), (256, 7, 5, 1), (16, 3, 40, 2), (8, 12, 12, 1), (4, 2, 2, 1)]:
+        x = torch.from_numpy(sparse_map(int(g["seed_c%d_h%d_w%d_b%d" % (c, h, w, b)]), (b, c, h, w)))
+        for L in (3, 2):
+            out = layers.RMAC(L=L)(x)
+            assert tuple(out.shape) == (b, c, 1, 1)
+            np.testing.assert_allclose(out.numpy().reshape(b, c), g["rmac_c%d_h%d_w%d_b%d_L%d" % (c, h, w, b, L)], rtol=2e-6, atol=2e-6)
+    assert repr(layers.RMAC()) == "RMAC(L=3)" and set(layers.POOLING) == {"mac", "spoc", "gem", "rmac"}
+    assert layers.pool_kind(layers.RMAC()) is None
+    torch.manual_seed(0)
+    net = init_network({"architecture": "alexnet", "pooling": "rmac", "whitening": False, "pretrained": False}).eval()
+    assert isinstance(net.pool, layers.RMAC) and net.meta["pooling"] == "rmac" and net.fusable_tail() is None
+    x = torch.rand(2, 3, 130, 97)
+    with torch.no_grad():
+        got = net(x)                                   # [D, B]: l2n(rmac(features(x)))
+        want = O.l2n(O.rmac(net.features(x).numpy(), 3, 1e-6), 1e-6)
+    np.testing.assert_allclose(got.t().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_ranks_get_private_miopen_caches(monkeypatch):
+    """One process per GPU: every rank writes its own MIOpen user db / kernel cache (sqlite files); what the user has set stays."""
+    from mdir_amd.sharded import private_miopen_caches
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.setenv("MIOPEN_CUSTOM_CACHE_DIR", "/somewhere/else")
+    private_miopen_caches(3)
+    assert os.environ["MIOPEN_USER_DB_PATH"].endswith("rank3/db") and os.path.isdir(os.environ["MIOPEN_USER_DB_PATH"])
+    assert os.environ["MIOPEN_CUSTOM_CACHE_DIR"] == "/somewhere/else"

@@ -520,3 +520,14 @@ def test_split_precision_restatements():
     # block exponents are exact: other powers of two in, the same scores times that power out
     np.testing.assert_array_equal(O.scores_split2(vecs * np.float32(2.0 ** 9), qvecs * np.float32(2.0 ** -20)),
                                   O.scores_split2(vecs, qvecs) * np.float32(2.0 ** -11))
+
+
+def test_g17_rmac(golden):
+    """R-MAC (functional.py:26-72): the oracle's float32 region grid and region-ordered sum against the reference's outputs."""
+    g = golden("g17_rmac.npz")
+    for c, h, w, b in [(2048, 24, 32, 1), (512, 48, 64, 1), (64, 17, 23, 2), (256, 7, 5, 1), (16, 3, 40, 2), (8, 12, 12, 1), (4, 2, 2, 1)]:
+        x = sparse_map(int(g["seed_c%d_h%d_w%d_b%d" % (c, h, w, b)]), (b, c, h, w))
+        for L in (3, 2):
+            np.testing.assert_allclose(O.rmac(x, L=L), g["rmac_c%d_h%d_w%d_b%d_L%d" % (c, h, w, b, L)], rtol=2e-6, atol=2e-6)
+    assert len(O.rmac_regions(24, 32, 3)) == 20 and len(O.rmac_regions(12, 12, 3)) == 14 and len(O.rmac_regions(3, 40, 3)) == 50
+    assert O.rmac_regions(1, 5, 3) == O.rmac_regions(1, 5, 1)                  # windows of size 0 (levels 2, 3 of a 1-pixel side) are skipped
