@@ -96,6 +96,17 @@ int64_t mdx_rmac_workspace(int B, int C, int nregions);
 int mdx_rmac(const float *feat, int B, int C, int H, int W, const int32_t *regions, int nregions, float eps,
              void *workspace, int64_t workspace_bytes, float *out, void *stream);
 
+/* Regional pooling: feat [B,C,H,W]  ->  out [B, nregions, C]: the pooling `kind` (p, pool_eps as in mdx_pool_l2n) of every
+ * region, no normalisation.  Replaces `LF.roipool(x, rpool, L, eps)` (cirtorch/layers/functional.py:75-121) inside `Rpool.forward`
+ * (layers/pooling.py:62-95: `regional: True`); regions as in mdx_rmac. */
+int mdx_roipool(const float *feat, int B, int C, int H, int W, const int32_t *regions, int nregions, int kind, float p,
+                float pool_eps, float *out, void *stream);
+
+/* vecs [B, nregions, C]  ->  out [B, C] = the sum over the regions in order; l2n_eps >= 0: every region vector is L2-normalised
+ * (eps added to the norm) before it is added (R-MAC, functional.py:62-70); l2n_eps < 0: summed as they are (`o.sum(1)`,
+ * layers/pooling.py:91). */
+int mdx_region_sum(const float *vecs, int B, int nregions, int C, float l2n_eps, float *out, void *stream);
+
 /* The S feature maps of one image pyramid (or of a batch of B equal-sized images), pooled by ONE launch:
  *   feats[s] [B,C,H[s],W[s]] row-major  ->  pooled [S,B,C]   (no normalisation)
  * Replaces the S calls of `self.pool(o)` (imageretrievalnet.py:108; LF.gem / LF.mac / LF.spoc,

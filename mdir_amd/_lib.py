@@ -60,6 +60,8 @@ def _declare(lib):
         "mdx_capture_recover": (i32, [p]),
         "mdx_rmac_workspace": (i64, [i32, i32, i32]),
         "mdx_rmac": (i32, [p, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), i32, f32, p, i64, p, p]),
+        "mdx_roipool": (i32, [p, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), i32, i32, f32, f32, p, p]),
+        "mdx_region_sum": (i32, [p, i32, i32, i32, f32, p, p]),
         "mdx_pool_l2n": (i32, [p, i32, i32, i32, i32, i32, f32, f32, f32, p, p]),
         "mdx_l2n_rows": (i32, [p, i64, i64, p, f32, p]),
         "mdx_ms_aggregate": (i32, [pp, i32, i64, f32, p, p]),
@@ -114,7 +116,7 @@ def _declare(lib):
     return sig
 
 
-EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_capture_recover", "mdx_rmac_workspace", "mdx_rmac", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
+EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_capture_recover", "mdx_rmac_workspace", "mdx_rmac", "mdx_roipool", "mdx_region_sum", "mdx_pool_l2n", "mdx_l2n_rows", "mdx_ms_aggregate",
            "mdx_ms_aggregate_batch", "mdx_pool_multi", "mdx_l2n_aggregate", "mdx_bn_act", "mdx_u8_to_chw", "mdx_resample_u8", "mdx_bilinear_pyramid", "mdx_jpeg_probe", "mdx_jpeg_coefficients", "mdx_jpeg_pixels",
            "mdx_index_create", "mdx_index_create_ex", "mdx_index_bytes", "mdx_index_create_in", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
            "mdx_scores", "mdx_scores_rowmajor", "mdx_scores_workspace_ex", "mdx_scores_ex", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of", "mdx_rank_positions",

@@ -315,8 +315,11 @@ int mdx_pool_l2n(const float *feat, int B, int C, int H, int W, int kind, float 
 constexpr int RMAC_MAX_REGIONS = 64;
 struct RmacGrid { int i0[RMAC_MAX_REGIONS], j0[RMAC_MAX_REGIONS], h[RMAC_MAX_REGIONS], w[RMAC_MAX_REGIONS]; int n; };
 
-__global__ __launch_bounds__(256) void rmac_max_kernel(const float *__restrict__ feat, int64_t planes, int C, int H, int W, RmacGrid grid,
-                                                       float *__restrict__ regmax)
+// (also `roipool` of functional.py:75-121: KIND = the regional pooling -- max, mean or GeM over every region)
+extern "C++" {
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256) void roi_pool_kernel(const float *__restrict__ feat, int64_t planes, int C, int H, int W, RmacGrid grid,
+                                                       float pw, float inv_p, float eps, float *__restrict__ regions_out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -325,13 +328,70 @@ __global__ __launch_bounds__(256) void rmac_max_kernel(const float *__restrict__
     const int64_t b = plane / C, c = plane % C;
     for (int r = 0; r < grid.n; ++r) {
         const int i0 = grid.i0[r], j0 = grid.j0[r], rh = grid.h[r], rw = grid.w[r];
-        float m = -INFINITY;
-        for (int e = lane; e < rh * rw; e += 64) m = fmaxf(m, p[(i0 + e / rw) * W + j0 + e % rw]);   // (the map is L2-resident after region 0)
-        m = wave_max(m);
-        if (lane == 0) regmax[(b * grid.n + r) * C + c] = m;
+        float acc = KIND == MDX_POOL_MAC ? -INFINITY : 0.0f;
+        for (int e = lane; e < rh * rw; e += 64) {           // (the map is L2-resident after region 0)
+            const float v = pool_elem<KIND, MODE>(p[(i0 + e / rw) * W + j0 + e % rw], pw, eps);
+            acc = KIND == MDX_POOL_MAC ? fmaxf(acc, v) : acc + v;
+        }
+        acc = KIND == MDX_POOL_MAC ? wave_max(acc) : wave_sum(acc);
+        if (KIND != MDX_POOL_MAC) acc = acc / (float)(rh * rw);
+        if (KIND == MDX_POOL_GEM && MODE != 1) acc = powf(acc, inv_p);
+        if (lane == 0) regions_out[(b * grid.n + r) * C + c] = acc;
     }
 }
 
+static int fill_grid(RmacGrid *grid, const int32_t *regions, int nregions, int H, int W, const char *who)
+{
+    grid->n = nregions;
+    for (int r = 0; r < nregions; ++r) {
+        grid->i0[r] = regions[4 * r]; grid->j0[r] = regions[4 * r + 1]; grid->h[r] = regions[4 * r + 2]; grid->w[r] = regions[4 * r + 3];
+        MDX_CHECK_ARG(grid->i0[r] >= 0 && grid->j0[r] >= 0 && grid->h[r] > 0 && grid->w[r] > 0 && grid->i0[r] + grid->h[r] <= H && grid->j0[r] + grid->w[r] <= W,
+                      "%s: region %d = (%d, %d, %d, %d) outside the %d x %d map", who, r, grid->i0[r], grid->j0[r], grid->h[r], grid->w[r], H, W);
+    }
+    return MDX_OK;
+}
+
+template <int KIND>
+static void launch_roi(int mode, const float *feat, int64_t planes, int C, int H, int W, const RmacGrid &grid, float p, float eps, float *out,
+                       hipStream_t s)
+{
+    const dim3 g((unsigned)ceil_div(planes, (int64_t)4)), b(256);
+    const float inv_p = 1.0f / p;
+    switch (mode) {
+        case 1: hipLaunchKernelGGL((roi_pool_kernel<KIND, 1>), g, b, 0, s, feat, planes, C, H, W, grid, p, inv_p, eps, out); break;
+        case 2: hipLaunchKernelGGL((roi_pool_kernel<KIND, 2>), g, b, 0, s, feat, planes, C, H, W, grid, p, inv_p, eps, out); break;
+        case 3: hipLaunchKernelGGL((roi_pool_kernel<KIND, 3>), g, b, 0, s, feat, planes, C, H, W, grid, p, inv_p, eps, out); break;
+        default: hipLaunchKernelGGL((roi_pool_kernel<KIND, 0>), g, b, 0, s, feat, planes, C, H, W, grid, p, inv_p, eps, out); break;
+    }
+}
+}   // extern "C++"
+
+int mdx_roipool(const float *feat, int B, int C, int H, int W, const int32_t *regions, int nregions, int kind, float p, float pool_eps,
+                float *out, void *stream)
+{
+    MDX_CHECK_ARG(feat && regions && out, "mdx_roipool: NULL pointer");
+    MDX_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "mdx_roipool: bad shape [%d,%d,%d,%d]", B, C, H, W);
+    MDX_CHECK_ARG(nregions >= 1 && nregions <= RMAC_MAX_REGIONS, "mdx_roipool: %d regions, 1..%d supported", nregions, RMAC_MAX_REGIONS);
+    RmacGrid grid;
+    int rc = fill_grid(&grid, regions, nregions, H, W, "mdx_roipool");
+    if (rc != MDX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t planes = (int64_t)B * C;
+    switch (kind) {
+        case MDX_POOL_GEM: {
+            MDX_CHECK_ARG(p > 0.0f && pool_eps > 0.0f, "mdx_roipool: gem needs p > 0 and eps > 0");
+            launch_roi<MDX_POOL_GEM>(p == 1.0f ? 1 : p == 2.0f ? 2 : p == 3.0f ? 3 : 0, feat, planes, C, H, W, grid, p, pool_eps, out, s);
+            break;
+        }
+        case MDX_POOL_MAC: launch_roi<MDX_POOL_MAC>(1, feat, planes, C, H, W, grid, 1.0f, 0.0f, out, s); break;
+        case MDX_POOL_SPOC: launch_roi<MDX_POOL_SPOC>(1, feat, planes, C, H, W, grid, 1.0f, 0.0f, out, s); break;
+        default: MDX_CHECK_ARG(false, "mdx_roipool: unknown pooling kind %d", kind);
+    }
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
+// eps < 0: the region vectors are summed as they are (Rpool's `o.sum(1)`, pooling.py:91)
 __global__ __launch_bounds__(256) void rmac_sum_kernel(const float *__restrict__ regmax, int C, int nreg, float eps, float *__restrict__ out)
 {
     __shared__ float part[4];
@@ -339,18 +399,30 @@ __global__ __launch_bounds__(256) void rmac_sum_kernel(const float *__restrict__
     const float *m = regmax + (int64_t)blockIdx.x * nreg * C;
     float *o = out + (int64_t)blockIdx.x * C;
     for (int r = 0; r < nreg; ++r) {
-        float ss = 0.0f;
-        for (int k = tid; k < C; k += 256) ss += m[r * (int64_t)C + k] * m[r * (int64_t)C + k];
-        ss = wave_sum(ss);
-        __syncthreads();                       // `part` of the previous region has been read by everybody
-        if ((tid & 63) == 0) part[tid >> 6] = ss;
-        __syncthreads();
-        const float den = sqrtf((part[0] + part[1]) + (part[2] + part[3])) + eps;
+        float den = 1.0f;
+        if (eps >= 0.0f) {                     // (uniform)
+            float ss = 0.0f;
+            for (int k = tid; k < C; k += 256) ss += m[r * (int64_t)C + k] * m[r * (int64_t)C + k];
+            ss = wave_sum(ss);
+            __syncthreads();                   // `part` of the previous region has been read by everybody
+            if ((tid & 63) == 0) part[tid >> 6] = ss;
+            __syncthreads();
+            den = sqrtf((part[0] + part[1]) + (part[2] + part[3])) + eps;
+        }
         for (int k = tid; k < C; k += 256) {
             const float v = m[r * (int64_t)C + k] / den;
             o[k] = r == 0 ? v : o[k] + v;       // a thread owns its channels: no hazard between regions
         }
     }
+}
+
+int mdx_region_sum(const float *vecs, int B, int nregions, int C, float l2n_eps, float *out, void *stream)
+{
+    MDX_CHECK_ARG(vecs && out, "mdx_region_sum: NULL pointer");
+    MDX_CHECK_ARG(B > 0 && C > 0 && nregions >= 1, "mdx_region_sum: bad shape [%d,%d,%d]", B, nregions, C);
+    hipLaunchKernelGGL(rmac_sum_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, vecs, C, nregions, l2n_eps, out);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
 }
 
 int64_t mdx_rmac_workspace(int B, int C, int nregions)
@@ -372,15 +444,11 @@ int mdx_rmac(const float *feat, int B, int C, int H, int W, const int32_t *regio
         return MDX_ERR_WORKSPACE;
     }
     RmacGrid grid;
-    grid.n = nregions;
-    for (int r = 0; r < nregions; ++r) {
-        grid.i0[r] = regions[4 * r]; grid.j0[r] = regions[4 * r + 1]; grid.h[r] = regions[4 * r + 2]; grid.w[r] = regions[4 * r + 3];
-        MDX_CHECK_ARG(grid.i0[r] >= 0 && grid.j0[r] >= 0 && grid.h[r] > 0 && grid.w[r] > 0 && grid.i0[r] + grid.h[r] <= H && grid.j0[r] + grid.w[r] <= W,
-                      "mdx_rmac: region %d = (%d, %d, %d, %d) outside the %d x %d map", r, grid.i0[r], grid.j0[r], grid.h[r], grid.w[r], H, W);
-    }
+    int rc = fill_grid(&grid, regions, nregions, H, W, "mdx_rmac");
+    if (rc != MDX_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int64_t planes = (int64_t)B * C;
-    hipLaunchKernelGGL(rmac_max_kernel, dim3((unsigned)ceil_div(planes, (int64_t)4)), dim3(256), 0, s, feat, planes, C, H, W, grid, (float *)workspace);
+    launch_roi<MDX_POOL_MAC>(1, feat, planes, C, H, W, grid, 1.0f, 0.0f, (float *)workspace, s);
     hipLaunchKernelGGL(rmac_sum_kernel, dim3((unsigned)B), dim3(256), 0, s, (const float *)workspace, C, nregions, eps, out);
     MDX_LAUNCH_CHECK();
     return MDX_OK;

@@ -5,8 +5,8 @@ Drop-in for ``mdir/external/cirtorch/layers/{functional,pooling,normalization}.p
 ``MAC``/``SPoC``/``GeM`` pooling.py:14-47, ``L2N`` normalization.py:10-20).  The
 arithmetic runs in the HIP library (``mdx_pool_l2n`` / ``mdx_l2n_rows``); there is
 no torch-op or CPU fallback.  ``rmac`` / ``RMAC`` (functional.py:26-72, pooling.py:50-60; round 5) complete the
-``POOLING`` registry of imageretrievalnet.py:32-37; ``Rpool`` (regional pooling with a whitening per region) and the losses are
-out of scope.
+``POOLING`` registry of imageretrievalnet.py:32-37, ``roipool`` / ``Rpool`` (functional.py:75-121, pooling.py:62-95; round 5)
+the ``regional: True`` networks; the losses are out of scope.
 """
 import functools
 import math
@@ -134,6 +134,57 @@ class RMAC(nn.Module):
 
     def __repr__(self):
         return self.__class__.__name__ + "(L={})".format(self.L)
+
+
+def roipool(x, rpool, L=3, eps=1e-6):
+    """``[B,C,H,W] -> [B,R,C,1,1]``: ``rpool`` of the whole map and of every R-MAC region (functional.py:75-121).  One launch
+    for the poolings the library knows (``mdx_roipool``); a foreign module is called region by region, as the reference does."""
+    regions = rmac_regions(int(x.shape[2]), int(x.shape[3]), int(L))
+    kind = pool_kind(rpool)
+    if kind is not None:
+        out = ops.roipool(x.contiguous(), regions, kind[0], kind[1], kind[2])
+    else:
+        out = torch.cat([rpool(x[:, :, i:i + h, j:j + w].contiguous()).reshape(x.shape[0], 1, -1) for i, j, h, w in regions], dim=1)
+    return out.reshape(out.shape[0], out.shape[1], out.shape[2], 1, 1)
+
+
+class Rpool(nn.Module):
+    """Regional pooling (pooling.py:62-95): region vectors -> L2N -> (whiten -> L2N) -> sum over the regions -> L2N.
+    State-dict keys as upstream: ``rpool.*`` (e.g. ``rpool.p``), ``whiten.weight`` / ``whiten.bias``."""
+
+    def __init__(self, rpool, whiten=None, L=3, eps=1e-6):
+        super().__init__()
+        self.rpool = rpool
+        self.L = L
+        self.whiten = whiten
+        self.norm = L2N()
+        self.eps = eps
+        self._whiten_index = (None, None)
+
+    def _whiten_rows(self, rows):
+        """``norm(whiten(rows))`` for ``[n, D]`` rows: mdx_scores on the resident weight shard + mdx_l2n_rows with the bias."""
+        w = self.whiten.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if self._whiten_index[0] != key:
+            self._whiten_index = (key, ops.DescriptorIndex(w.detach().contiguous(), "ND"))
+        y = self._whiten_index[1].scores(rows.contiguous(), "ND")              # [n, D_out]: row i = W rows_i
+        bias = self.whiten.bias.detach() if self.whiten.bias is not None else None
+        return ops.l2n_rows_(y, bias=bias, eps=self.norm.eps)
+
+    def forward(self, x, aggregate=True):
+        o = roipool(x, self.rpool, self.L, self.eps)
+        b, r, d = o.shape[:3]
+        rows = ops.l2n_rows_(o.reshape(b * r, d).contiguous(), eps=self.norm.eps)
+        if self.whiten is not None:
+            rows = self._whiten_rows(rows)
+        o = rows.reshape(b, r, -1, 1, 1)
+        if aggregate:
+            total = ops.region_sum(o.reshape(b, r, -1).contiguous())           # [B, D]: sum over the regions
+            o = ops.l2n_rows_(total, eps=self.norm.eps).reshape(b, -1, 1, 1)
+        return o
+
+    def __repr__(self):
+        return super().__repr__() + "(L={})".format(self.L)
 
 
 class L2N(nn.Module):

@@ -25,7 +25,7 @@ from . import ops
 from .backbones import OUTPUT_DIM, TrunkSequential, build_features
 from .datasets import ImagesFromList, ToUint8HWC, device_convert, get_data_root, make_loader
 from .graphs import ShapeGraphs, graphs_enabled, parallel_map
-from .layers import POOLING, L2N, pool_kind
+from .layers import POOLING, L2N, Rpool, pool_kind
 from .jpeg import pixels as pixels_of
 from .resample import DeviceThumbnail
 
@@ -104,7 +104,9 @@ def _local_file(url_or_path, directory):
 def init_network(params):
     """Build an ``ImageRetrievalNet`` from the reference's parameter dict
     (architecture, local_whitening, pooling, regional, whitening, mean, std,
-    pretrained, model_dir).  Regional pooling is out of scope."""
+    pretrained, model_dir).  ``regional: True`` wraps the pooling into ``Rpool`` with a regional whitening
+    ``nn.Linear(dim, dim)`` (imageretrievalnet.py:205-222; its pre-computed weights are a download upstream: random here unless
+    a checkpoint's state dict fills ``pool.whiten.*``)."""
     architecture = params.get("architecture", "resnet101")
     local_whitening = params.get("local_whitening", False)
     pooling = params.get("pooling", "gem")
@@ -117,14 +119,14 @@ def init_network(params):
 
     if architecture not in OUTPUT_DIM:
         raise ValueError("Unsupported or unknown architecture: {}!".format(architecture))
-    if regional:
-        raise NotImplementedError("regional pooling (Rpool) is outside the MI355X hot path")
     if pooling not in POOLING:
         raise KeyError("pooling '%s' is not one of %s" % (pooling, sorted(POOLING)))
     dim = OUTPUT_DIM[architecture]
     features = build_features(architecture)
     lwhiten = nn.Linear(dim, dim, bias=True) if local_whitening else None
     pool = POOLING[pooling]()
+    if regional:
+        pool = Rpool(pool, nn.Linear(dim, dim, bias=True))
 
     whiten = None
     if whitening:

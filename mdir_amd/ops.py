@@ -109,6 +109,37 @@ def rmac(feat, regions, eps=1e-6):
     return out
 
 
+def roipool(feat, regions, kind="gem", p=3.0, pool_eps=1e-6):
+    """Regional pooling ``[B,C,H,W] -> [B,R,C]``: the pooling ``kind`` of every region ``(row0, col0, height, width)``, no
+    normalisation -- ``LF.roipool`` (functional.py:75-121) through ``mdx_roipool``."""
+    fp = _dev(feat, torch.float32, "feature map")
+    if feat.dim() != 4:
+        raise ValueError("feature map must be [B,C,H,W]")
+    B, C, H, W = feat.shape
+    n = len(regions)
+    if not 1 <= n <= 64:
+        raise ValueError("1..64 regions supported, got %d" % n)
+    flat = (ctypes.c_int32 * (4 * n))(*[int(v) for reg in regions for v in reg])
+    out = torch.empty((B, n, C), dtype=torch.float32, device=feat.device)
+    with _on(feat):
+        check(_lib.lib().mdx_roipool(fp, B, C, H, W, flat, n, POOL_KINDS[kind], float(p), float(pool_eps), _vp(out.data_ptr()), _stream()),
+              "mdx_roipool")
+    return out
+
+
+def region_sum(vecs, l2n_eps=None):
+    """``[B,R,C] -> [B,C]``: sum over the regions in order; ``l2n_eps`` not None: each region vector L2-normalised first."""
+    vp = _dev(vecs, torch.float32, "region vectors")
+    if vecs.dim() != 3:
+        raise ValueError("region vectors must be [B,R,C]")
+    B, R, C = vecs.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=vecs.device)
+    with _on(vecs):
+        check(_lib.lib().mdx_region_sum(vp, B, R, C, -1.0 if l2n_eps is None else float(l2n_eps), _vp(out.data_ptr()), _stream()),
+              "mdx_region_sum")
+    return out
+
+
 def l2n_rows_(x, bias=None, eps=1e-6):
     """In place ``(x + bias) / (||x + bias|| + eps)`` per row of a [R,D] matrix."""
     xp = _dev(x, torch.float32, "x")

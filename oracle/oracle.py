@@ -97,6 +97,34 @@ def rmac(x, L=3, eps=1e-6):
     return v
 
 
+def roipool(x, pool, L=3):
+    """``[B,C,H,W] -> [B,R,C]``: ``pool`` (a function ``[B,C,h,w] -> [B,C]``) of the whole map and of every R-MAC region, in
+    the reference's order (``layers/functional.py:75-121``)."""
+    x = np.asarray(x, dtype=F32)
+    out = [pool(x)]
+    for i0, j0, wl in rmac_regions(x.shape[2], x.shape[3], L):
+        out.append(pool(np.ascontiguousarray(x[:, :, i0:i0 + wl, j0:j0 + wl])))
+    return np.stack(out, axis=1).astype(F32)
+
+
+def rpool(x, pool, weight=None, bias=None, L=3, eps=1e-6, aggregate=True):
+    """Regional pooling (``layers/pooling.py:62-95``): every region pooled and L2-normalised, optionally whitened
+    (``W r + b``) and normalised again, then summed over the regions and normalised -- ``[B,C]`` (``aggregate``) or the
+    regional vectors ``[B,R,C]``."""
+    o = roipool(x, pool, L)
+    B, R, C = o.shape
+    o = l2n(o.reshape(B * R, C), eps)
+    if weight is not None:
+        o = (o @ np.asarray(weight, dtype=F32).T).astype(F32)
+        if bias is not None:
+            o = (o + np.asarray(bias, dtype=F32)).astype(F32)
+        o = l2n(o, eps)
+    o = o.reshape(B, R, -1)
+    if aggregate:
+        return l2n(o.sum(axis=1, dtype=F32), eps)
+    return o
+
+
 def l2n(x, eps=1e-6):
     """L2-normalise over axis 1 with eps ADDED TO THE NORM.
 

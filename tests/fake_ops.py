@@ -30,6 +30,20 @@ def rmac(feat, regions, eps=1e-6):
     return torch.from_numpy(np.ascontiguousarray(v))
 
 
+def roipool(feat, regions, kind="gem", p=3.0, pool_eps=1e-6):
+    x = feat.detach().numpy()
+    fn = {"gem": lambda a: O.gem(a, p, pool_eps), "mac": O.mac, "spoc": O.spoc}[kind]
+    out = np.stack([fn(np.ascontiguousarray(x[:, :, i0:i0 + h, j0:j0 + w])) for i0, j0, h, w in regions], axis=1)
+    return torch.from_numpy(np.ascontiguousarray(out.astype(np.float32)))
+
+
+def region_sum(vecs, l2n_eps=None):
+    v = vecs.detach().numpy()
+    if l2n_eps is not None:
+        v = np.stack([O.l2n(v[:, r], l2n_eps) for r in range(v.shape[1])], axis=1)
+    return torch.from_numpy(np.ascontiguousarray(v.sum(axis=1, dtype=np.float32)))
+
+
 def l2n_rows_(x, bias=None, eps=1e-6):
     v = x.detach().numpy()
     if bias is not None:
@@ -172,7 +186,7 @@ def project_f64(p, x, center=None):
     return torch.from_numpy(p.detach().numpy() @ xv)
 
 
-NAMES = ("rmac", "clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "scores_rowmajor", "rank_full", "topk", "rank_of",
+NAMES = ("rmac", "roipool", "region_sum", "clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "scores_rowmajor", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 

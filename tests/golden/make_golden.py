@@ -337,6 +337,7 @@ def main():
     make_next_rows()
     make_tables()
     make_rmac()
+    make_rpool()
     print("golden fixtures written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-28s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))
@@ -532,6 +533,27 @@ def make_rmac():
         for L in (3, 2):
             g17["rmac_c%d_h%d_w%d_b%d_L%d" % (c, h, w, b, L)] = LF.rmac(x.clone(), L=L, eps=1e-6).numpy().reshape(b, c)
     np.savez_compressed(os.path.join(HERE, "g17_rmac.npz"), **g17)
+
+
+def make_rpool():
+    """G18: regional pooling (cirtorch/layers/functional.py:75-121 roipool, layers/pooling.py:62-95 Rpool) with GeM / MAC / SPoC
+    regions, with and without the regional whitening, aggregated and per region."""
+    from cirtorch.layers.pooling import GeM, MAC, Rpool, SPoC
+    torch.manual_seed(18)
+    g18 = {}
+    for c, h, w in [(64, 24, 32), (32, 17, 23), (16, 7, 5), (8, 12, 12)]:
+        seed = 1800 + h * 100 + w
+        x = torch.from_numpy(sparse_map(seed, (2, c, h, w)))
+        lin = torch.nn.Linear(c, c)
+        g18["seed_c%d_h%d_w%d" % (c, h, w)] = seed
+        g18["weight_c%d" % c], g18["bias_c%d" % c] = lin.weight.detach().numpy(), lin.bias.detach().numpy()
+        for name, mod in (("gem", GeM(p=2.5)), ("mac", MAC()), ("spoc", SPoC())):
+            for tag, wh in (("plain", None), ("whiten", lin)):
+                rp = Rpool(mod, wh)
+                with torch.no_grad():
+                    g18["agg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)] = rp(x).numpy().reshape(2, -1)
+                    g18["reg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)] = rp(x, aggregate=False).numpy()[..., 0, 0]
+    np.savez_compressed(os.path.join(HERE, "g18_rpool.npz"), **g18)
 
 
 def _jsonable(o):

@@ -527,3 +527,40 @@ def test_rmac_on_the_device(golden):
         got = net(x)
         want = O.l2n(O.rmac(net.features(x).cpu().numpy(), 3, 1e-6), 1e-6)
     np.testing.assert_allclose(got.t().cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_regional_pooling_on_the_device(golden):
+    """mdx_roipool + mdx_l2n_rows + the regional whitening on the weight shard + mdx_region_sum = Rpool.forward (pooling.py:62-95):
+    golden G18 (GeM / MAC / SPoC regions, with and without whitening, aggregated and per region) and a `regional: True` network."""
+    from conftest import sparse_map
+    from mdir_amd import layers
+    from mdir_amd.networks import init_network
+    SHAPES, TOL, DEVICE = [(64, 24, 32), (32, 17, 23), (16, 7, 5), (8, 12, 12)], 2e-5, DEV
+    to_dev = dev
+
+    g = golden("g18_rpool.npz")
+    for c, h, w in SHAPES:
+        x = to_dev(sparse_map(int(g["seed_c%d_h%d_w%d" % (c, h, w)]), (2, c, h, w)))
+        for name, mod in (("gem", layers.GeM(p=2.5)), ("mac", layers.MAC()), ("spoc", layers.SPoC())):
+            for tag in ("plain", "whiten"):
+                lin = None
+                if tag == "whiten":
+                    lin = torch.nn.Linear(c, c)
+                    lin.load_state_dict({"weight": torch.from_numpy(g["weight_c%d" % c]), "bias": torch.from_numpy(g["bias_c%d" % c])})
+                rp = layers.Rpool(mod, lin).to(x.device)
+                with torch.no_grad():
+                    agg, reg = rp(x), rp(x, aggregate=False)
+                assert tuple(agg.shape) == (2, c, 1, 1) and tuple(reg.shape[:1]) == (2,) and tuple(reg.shape[2:]) == (c, 1, 1)
+                np.testing.assert_allclose(agg.cpu().numpy().reshape(2, c), g["agg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)], rtol=TOL, atol=2e-6)
+                np.testing.assert_allclose(reg.cpu().numpy()[..., 0, 0], g["reg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)], rtol=TOL, atol=2e-6)
+    assert repr(layers.Rpool(layers.MAC())).endswith("(L=3)")
+    torch.manual_seed(0)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "regional": True, "whitening": False, "pretrained": False}).to(DEVICE).eval()
+    assert isinstance(net.pool, layers.Rpool) and set(k for k in net.state_dict() if k.startswith("pool.")) == {"pool.rpool.p", "pool.whiten.weight", "pool.whiten.bias"}
+    assert net.meta["regional"] is True and net.fusable_tail() is None
+    xin = torch.rand(2, 3, 130, 97, device=DEVICE)
+    with torch.no_grad():
+        got = net(xin)
+        feat = net.features(xin).cpu().numpy()
+    want = O.l2n(O.rpool(feat, lambda a: O.gem(a, 3.0, 1e-6), net.pool.whiten.weight.detach().cpu().numpy(), net.pool.whiten.bias.detach().cpu().numpy()), 1e-6)
+    np.testing.assert_allclose(got.t().cpu().numpy(), want, rtol=1e-4, atol=2e-6)

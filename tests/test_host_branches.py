@@ -41,8 +41,7 @@ def test_normalize_strict_shape_argument():
 
 
 def test_init_cirnet_requires_its_keys_and_init_network_refuses_what_is_out_of_scope():
-    """cirnet.py:10-13 (every key of the list must be given); imageretrievalnet.py:155-164 architectures; regional pooling (Rpool) is
-    named as outside the path instead of silently building something else; an unknown pooling is a KeyError as in the reference."""
+    """cirnet.py:10-13 (every key of the list must be given); imageretrievalnet.py:155-164 architectures; an unknown pooling is a KeyError as in the reference."""
     from mdir_amd.network import init_cirnet
     from mdir_amd.networks import init_network
     full = {"cir_architecture": "alexnet", "local_whitening": False, "pooling": "gem", "regional": False, "whitening": False, "pretrained": False}
@@ -56,8 +55,6 @@ def test_init_cirnet_requires_its_keys_and_init_network_refuses_what_is_out_of_s
     assert net.meta["mean"] == [0.485, 0.456, 0.406] and net.meta["std"] == [0.229, 0.224, 0.225]
     with pytest.raises(ValueError, match="Unsupported or unknown architecture"):
         init_network({"architecture": "resnet7", "pretrained": False})
-    with pytest.raises(NotImplementedError, match="regional"):
-        init_network({"architecture": "alexnet", "regional": True, "pretrained": False})
     with pytest.raises(KeyError, match="not one of"):
         init_network({"architecture": "alexnet", "pooling": "rpool", "pretrained": False})
 
@@ -342,3 +339,52 @@ def test_ranks_get_private_miopen_caches(monkeypatch):
     private_miopen_caches(3)
     assert os.environ["MIOPEN_USER_DB_PATH"].endswith("rank3/db") and os.path.isdir(os.environ["MIOPEN_USER_DB_PATH"])
     assert os.environ["MIOPEN_CUSTOM_CACHE_DIR"] == "/somewhere/else"
+
+
+def test_regional_pooling_module_and_network(fops, golden):
+    """`Rpool` / `roipool` / `init_network(regional=True)` (pooling.py:62-95, functional.py:75-121, imageretrievalnet.py:205-222):
+    golden G18 through the host layer; state-dict keys as upstream (`pool.rpool.p`, `pool.whiten.*`)."""
+    from conftest import sparse_map
+    from mdir_amd import layers
+    from mdir_amd.networks import init_network
+    from oracle import oracle as O
+    SHAPES, TOL, DEVICE = [(32, 17, 23), (16, 7, 5), (8, 12, 12)], 1e-5, "cpu"
+    to_dev = torch.from_numpy
+
+    g = golden("g18_rpool.npz")
+    for c, h, w in SHAPES:
+        x = to_dev(sparse_map(int(g["seed_c%d_h%d_w%d" % (c, h, w)]), (2, c, h, w)))
+        for name, mod in (("gem", layers.GeM(p=2.5)), ("mac", layers.MAC()), ("spoc", layers.SPoC())):
+            for tag in ("plain", "whiten"):
+                lin = None
+                if tag == "whiten":
+                    lin = torch.nn.Linear(c, c)
+                    lin.load_state_dict({"weight": torch.from_numpy(g["weight_c%d" % c]), "bias": torch.from_numpy(g["bias_c%d" % c])})
+                rp = layers.Rpool(mod, lin).to(x.device)
+                with torch.no_grad():
+                    agg, reg = rp(x), rp(x, aggregate=False)
+                assert tuple(agg.shape) == (2, c, 1, 1) and tuple(reg.shape[:1]) == (2,) and tuple(reg.shape[2:]) == (c, 1, 1)
+                np.testing.assert_allclose(agg.cpu().numpy().reshape(2, c), g["agg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)], rtol=TOL, atol=2e-6)
+                np.testing.assert_allclose(reg.cpu().numpy()[..., 0, 0], g["reg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)], rtol=TOL, atol=2e-6)
+    assert repr(layers.Rpool(layers.MAC())).endswith("(L=3)")
+    torch.manual_seed(0)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "regional": True, "whitening": False, "pretrained": False}).to(DEVICE).eval()
+    assert isinstance(net.pool, layers.Rpool) and set(k for k in net.state_dict() if k.startswith("pool.")) == {"pool.rpool.p", "pool.whiten.weight", "pool.whiten.bias"}
+    assert net.meta["regional"] is True and net.fusable_tail() is None
+    xin = torch.rand(2, 3, 130, 97, device=DEVICE)
+    with torch.no_grad():
+        got = net(xin)
+        feat = net.features(xin).cpu().numpy()
+    want = O.l2n(O.rpool(feat, lambda a: O.gem(a, 3.0, 1e-6), net.pool.whiten.weight.detach().cpu().numpy(), net.pool.whiten.bias.detach().cpu().numpy()), 1e-6)
+    np.testing.assert_allclose(got.t().cpu().numpy(), want, rtol=1e-4, atol=2e-6)
+
+    # a pooling module the library does not know is called region by region, as the reference does
+    class Odd(torch.nn.Module):
+        def forward(self, t):
+            return t.amax(dim=(2, 3), keepdim=True) * 2
+    x = torch.rand(1, 4, 6, 9)
+    out = layers.roipool(x, Odd(), 2)
+    regs = layers.rmac_regions(6, 9, 2)
+    assert tuple(out.shape) == (1, len(regs), 4, 1, 1)
+    for k, (i, j, hh, ww) in enumerate(regs):
+        np.testing.assert_allclose(out[0, k, :, 0, 0].numpy(), 2 * x[0, :, i:i + hh, j:j + ww].amax(dim=(1, 2)).numpy())

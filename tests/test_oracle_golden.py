@@ -531,3 +531,16 @@ def test_g17_rmac(golden):
             np.testing.assert_allclose(O.rmac(x, L=L), g["rmac_c%d_h%d_w%d_b%d_L%d" % (c, h, w, b, L)], rtol=2e-6, atol=2e-6)
     assert len(O.rmac_regions(24, 32, 3)) == 20 and len(O.rmac_regions(12, 12, 3)) == 14 and len(O.rmac_regions(3, 40, 3)) == 50
     assert O.rmac_regions(1, 5, 3) == O.rmac_regions(1, 5, 1)                  # windows of size 0 (levels 2, 3 of a 1-pixel side) are skipped
+
+
+def test_g18_rpool(golden):
+    """Regional pooling (functional.py:75-121, pooling.py:62-95): the oracle against the reference's Rpool outputs."""
+    g = golden("g18_rpool.npz")
+    pools = {"gem": lambda a: O.gem(a, 2.5, 1e-6), "mac": O.mac, "spoc": O.spoc}
+    for c, h, w in [(64, 24, 32), (32, 17, 23), (16, 7, 5), (8, 12, 12)]:
+        x = sparse_map(int(g["seed_c%d_h%d_w%d" % (c, h, w)]), (2, c, h, w))
+        for name, fn in pools.items():
+            for tag, wb in (("plain", (None, None)), ("whiten", (g["weight_c%d" % c], g["bias_c%d" % c]))):
+                np.testing.assert_allclose(O.rpool(x, fn, wb[0], wb[1]), g["agg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)], rtol=1e-5, atol=2e-6)
+                np.testing.assert_allclose(O.rpool(x, fn, wb[0], wb[1], aggregate=False), g["reg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)],
+                                           rtol=1e-5, atol=2e-6)
