@@ -418,6 +418,9 @@ int mdx_gram_f64(const double *a, int64_t d, int64_t n, const double *center, do
  * transposed, so that both operands are read in 1-KiB runs).  An odd n costs one more short launch (the large-tile kernel
  * moves column pairs). */
 int64_t mdx_project_f64_workspace(int64_t dout, int64_t d);
+/* x [d, n] float64, in place: every COLUMN divided by (its L2 norm + eps) = `X / (np.linalg.norm(X, ord=2, axis=0, keepdims=True)
+ * + 1e-6)` of whitenapply (whiten.py:10-11) when it is handed float64 `P` (then the reference computes in float64). */
+int mdx_l2n_cols_f64(double *x, int64_t d, int64_t n, double eps, void *stream);
 int mdx_project_f64(const double *p, int64_t dout, int64_t d, const double *x, int64_t n, const double *center,
                     double *out, void *workspace, int64_t workspace_bytes, void *stream);
 

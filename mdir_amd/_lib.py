@@ -102,6 +102,7 @@ def _declare(lib):
         "mdx_gram_f64": (i32, [p, i64, i64, p, p, p, i64, p]),
         "mdx_project_f64_workspace": (i64, [i64, i64]),
         "mdx_project_f64": (i32, [p, i64, i64, p, i64, p, p, p, i64, p]),
+        "mdx_l2n_cols_f64": (i32, [p, i64, i64, ctypes.c_double, p]),
         "mdx_comm_unique_id": (i32, [p]),
         "mdx_comm_init": (i32, [pp, p, i32, i32]),
         "mdx_comm_destroy": (i32, [p]),
@@ -120,7 +121,7 @@ EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_capture_recover", "mdx_rmac
            "mdx_ms_aggregate_batch", "mdx_pool_multi", "mdx_l2n_aggregate", "mdx_bn_act", "mdx_u8_to_chw", "mdx_resample_u8", "mdx_bilinear_pyramid", "mdx_jpeg_probe", "mdx_jpeg_coefficients", "mdx_jpeg_pixels",
            "mdx_index_create", "mdx_index_create_ex", "mdx_index_bytes", "mdx_index_create_in", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
            "mdx_scores", "mdx_scores_rowmajor", "mdx_scores_workspace_ex", "mdx_scores_ex", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of", "mdx_rank_positions",
-           "mdx_gather_scores", "mdx_rank_count", "mdx_conv1x1_transpose_weights", "mdx_conv1x1_bn_act", "mdx_clahe_workspace", "mdx_clahe_u8_to_chw", "mdx_gram_f64_workspace", "mdx_gram_f64", "mdx_project_f64_workspace", "mdx_project_f64", "mdx_comm_unique_id", "mdx_comm_init",
+           "mdx_gather_scores", "mdx_rank_count", "mdx_conv1x1_transpose_weights", "mdx_conv1x1_bn_act", "mdx_clahe_workspace", "mdx_clahe_u8_to_chw", "mdx_gram_f64_workspace", "mdx_gram_f64", "mdx_project_f64_workspace", "mdx_project_f64", "mdx_l2n_cols_f64", "mdx_comm_unique_id", "mdx_comm_init",
            "mdx_comm_destroy", "mdx_comm_info", "mdx_query_bounds", "mdx_allgather_scores", "mdx_exchange_scores")
 
 

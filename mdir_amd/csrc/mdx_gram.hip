@@ -515,6 +515,26 @@ int64_t mdx_project_f64_workspace(int64_t dout, int64_t d)
     return transposed_bytes(d, dout);                                   // p transposed
 }
 
+// x [d, n] (float64, column = one descriptor): every column divided by (its L2 norm + eps), in place: `X / (norm(X, axis 0) + 1e-6)`
+// of whitenapply (whiten.py:10-11) for float64 inputs.  A thread owns a column (rows are read coalesced across the columns).
+__global__ __launch_bounds__(256) void l2n_cols_f64_kernel(double *__restrict__ x, int64_t d, int64_t n, double eps)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double ss = 0.0;
+    for (int64_t i = 0; i < d; ++i) ss += x[i * n + j] * x[i * n + j];
+    const double den = sqrt(ss) + eps;
+    for (int64_t i = 0; i < d; ++i) x[i * n + j] /= den;
+}
+
+int mdx_l2n_cols_f64(double *x, int64_t d, int64_t n, double eps, void *stream)
+{
+    MDX_CHECK_ARG(x && d > 0 && n > 0 && eps >= 0.0, "mdx_l2n_cols_f64: bad arguments");
+    hipLaunchKernelGGL(l2n_cols_f64_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, x, d, n, eps);
+    MDX_LAUNCH_CHECK();
+    return MDX_OK;
+}
+
 int mdx_project_f64(const double *p, int64_t dout, int64_t d, const double *x, int64_t n, const double *center, double *out,
                     void *workspace, int64_t workspace_bytes, void *stream)
 {

@@ -671,6 +671,16 @@ def gram_f64(a, center=None):
     return out
 
 
+def l2n_cols_f64_(x, eps=1e-6):
+    """In place: every column of a float64 ``[d, n]`` matrix divided by (its L2 norm + eps) (``mdx_l2n_cols_f64``)."""
+    xp = _dev(x, torch.float64, "x")
+    if x.dim() != 2:
+        raise ValueError("x must be [d, n]")
+    with _on(x):
+        check(_lib.lib().mdx_l2n_cols_f64(xp, x.shape[0], x.shape[1], float(eps), _stream()), "mdx_l2n_cols_f64")
+    return x
+
+
 def project_f64(p, x, center=None):
     """``p @ (x - center)`` for float64 ``p [dout, d]``, ``x [d, n]``, ``center [d]`` -> ``[dout, n]``
     (``np.dot(P, X-m)``, whiten.py:45)."""

@@ -2,11 +2,11 @@
 ``mdir/external/cirtorch/utils/whiten.py:4-12`` (called from
 ``cirtorch/examples/test.py:246-249`` on the whole ``[D,N]`` matrix).
 
-The projection is one ``mdx_scores`` call per 128 descriptors against a resident
-shard of ``P[:d]`` (fp32 MFMA, database = rows of P) followed by ``mdx_l2n_rows``.
-Compute is fp32 on the GPU; float64 inputs are accepted and the result is returned
-in the dtype numpy would have produced, but carries fp32 accuracy (the reference
-computes float64 on the CPU when handed float64 ``P``)."""
+fp32 inputs: one ``mdx_scores`` call against a resident shard of ``P[:d]`` (fp32 MFMA, database = rows of P) followed by
+``mdx_l2n_rows``.  When any input is float64 the reference computes in float64 (numpy promotes; the pickled ``Lw`` / ``P`` of
+``whitenlearn`` ARE float64): so does this -- ``mdx_project_f64`` (centring fused, f64 MFMA) + ``mdx_l2n_cols_f64`` -- and agrees
+with numpy to 1e-12 instead of carrying fp32 accuracy into a float64 result (round 5; a differential run against the reference
+showed 1e-7)."""
 import numpy as np
 import torch
 
@@ -19,6 +19,9 @@ def whitenapply(X, m, P, dimensions=None, device="cuda"):
         dimensions = P.shape[0]
     out_dtype = np.result_type(np.asarray(X).dtype, np.asarray(m).dtype, np.asarray(P).dtype)
     dev = torch.device(device)
+    if out_dtype == np.float64:
+        y = ops.project_f64(_as_f64(np.asarray(P)[:dimensions], dev), _as_f64(X, dev), _as_f64(np.asarray(m).reshape(-1), dev))   # [d, N]
+        return ops.l2n_cols_f64_(y, eps=1e-6).cpu().numpy()
     Xd = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32), device=dev)
     Pd = torch.as_tensor(np.ascontiguousarray(np.asarray(P)[:dimensions], dtype=np.float32), device=dev)
     md = torch.as_tensor(np.ascontiguousarray(np.asarray(m).reshape(-1), dtype=np.float32), device=dev)

@@ -44,6 +44,12 @@ def region_sum(vecs, l2n_eps=None):
     return torch.from_numpy(np.ascontiguousarray(v.sum(axis=1, dtype=np.float32)))
 
 
+def l2n_cols_f64_(x, eps=1e-6):
+    v = x.numpy()
+    v /= (np.linalg.norm(v, ord=2, axis=0, keepdims=True) + eps)
+    return x
+
+
 def l2n_rows_(x, bias=None, eps=1e-6):
     v = x.detach().numpy()
     if bias is not None:
@@ -186,7 +192,7 @@ def project_f64(p, x, center=None):
     return torch.from_numpy(p.detach().numpy() @ xv)
 
 
-NAMES = ("rmac", "roipool", "region_sum", "clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "scores_rowmajor", "rank_full", "topk", "rank_of",
+NAMES = ("l2n_cols_f64_", "rmac", "roipool", "region_sum", "clahe_u8_to_chw", "gram_f64", "project_f64", "pool_l2n", "l2n_rows_", "ms_aggregate", "ms_aggregate_batch", "pool_multi", "l2n_aggregate", "resample_u8", "DescriptorIndex", "scores_rowmajor", "rank_full", "topk", "rank_of",
          "gather_scores", "rank_count_")
 
 

@@ -9,6 +9,7 @@ stored.  Re-run:  python tests/golden/make_golden.py
 
 The fixtures are DATA; the GPU box never sees /root/reference.
 """
+import io
 import json
 import os
 import pickle
@@ -338,6 +339,7 @@ def main():
     make_tables()
     make_rmac()
     make_rpool()
+    make_map_fuzz()
     print("golden fixtures written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-28s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))
@@ -554,6 +556,67 @@ def make_rpool():
                     g18["agg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)] = rp(x).numpy().reshape(2, -1)
                     g18["reg_%s_%s_c%d_h%d_w%d" % (name, tag, c, h, w)] = rp(x, aggregate=False).numpy()[..., 0, 0]
     np.savez_compressed(os.path.join(HERE, "g18_rpool.npz"), **g18)
+
+
+def fuzz_map_case(seed):
+    """One random compute_map problem (shared with tests/test_evaluate.py through this generator): permutation rankings, id lists
+    as lists or arrays, empty / overlapping ok and junk, a missing junk key, kappas beyond N."""
+    rng = np.random.default_rng(seed)
+    n, nq = int(rng.integers(1, 60)), int(rng.integers(1, 6))
+    ranks = np.stack([rng.permutation(n) for _ in range(nq)], axis=1)
+    gnd = []
+    for _ in range(nq):
+        ok = rng.choice(n, int(rng.integers(0, min(n, 6) + 1)), replace=False)
+        junk = rng.choice(n, int(rng.integers(0, min(n, 4) + 1)), replace=False)
+        g = {"ok": ok.tolist() if rng.random() < 0.5 else ok, "junk": junk.tolist() if rng.random() < 0.5 else junk}
+        if rng.random() < 0.2:
+            del g["junk"]
+        gnd.append(g)
+    kappas = sorted(set(int(v) for v in rng.integers(1, n + 5, size=int(rng.integers(0, 4)))))
+    return ranks, gnd, kappas
+
+
+def fuzz_revisited_case(seed):
+    rng = np.random.default_rng(seed)
+    n, nq = int(rng.integers(5, 80)), int(rng.integers(1, 5))
+    ranks = np.stack([rng.permutation(n) for _ in range(nq)], axis=1)
+    gnd = []
+    for _ in range(nq):
+        ids = rng.permutation(n)[:int(rng.integers(0, min(n, 12)))]
+        cut = sorted(rng.integers(0, len(ids) + 1, size=2))
+        gnd.append({"easy": ids[:cut[0]], "hard": ids[cut[0]:cut[1]], "junk": ids[cut[1]:], "bbx": None})
+    return ranks, gnd
+
+
+def make_map_fuzz():
+    """G19: 300 random compute_map problems and 100 random revisited-protocol problems (cirtorch/utils/evaluate.py:39-152): the
+    inputs come back from the seeds (fuzz_map_case / fuzz_revisited_case above), only the reference's outputs are stored."""
+    import contextlib
+    import copy
+    from cirtorch.utils.evaluate import compute_map, compute_map_and_print
+    g19 = {}
+    for seed in range(300):
+        ranks, gnd, kappas = fuzz_map_case(seed)
+        try:
+            mAP, aps, pr, prs = compute_map(ranks.copy(), copy.deepcopy(gnd), list(kappas))
+        except Exception as err:          # e.g. no query with positives: the reference divides by zero (evaluate.py:108)
+            g19["error_%d" % seed] = np.array([type(err).__name__])
+            continue
+        g19["map_%d" % seed] = np.array([mAP])
+        g19["aps_%d" % seed], g19["pr_%d" % seed], g19["prs_%d" % seed] = np.asarray(aps, dtype=np.float64), np.asarray(pr, dtype=np.float64), np.asarray(prs, dtype=np.float64)
+    for seed in range(100):
+        ranks, gnd = fuzz_revisited_case(1000 + seed)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                avg, per = compute_map_and_print("roxford5k" if seed % 2 else "rparis6k", ranks.copy(), copy.deepcopy(gnd))
+        except Exception as err:
+            g19["rev_error_%d" % seed] = np.array([type(err).__name__])
+            continue
+        for k in ("map_easy", "map_medium", "map_hard"):
+            g19["rev_%s_%d" % (k, seed)] = np.array([avg[k]])
+        for k in ("ap_easy", "ap_medium", "ap_hard"):
+            g19["rev_%s_%d" % (k, seed)] = np.asarray(per[k], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "g19_map_fuzz.npz"), **g19)
 
 
 def _jsonable(o):

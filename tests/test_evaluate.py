@@ -2,6 +2,7 @@
 import json
 
 import numpy as np
+import pytest
 import torch
 
 from mdir_amd import evaluate as E
@@ -230,3 +231,51 @@ def test_protocol_levels_on_shared_masks_equal_the_concatenated_lists():
             for x, y, z in zip(want, a, b):
                 np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
                 np.testing.assert_array_equal(np.asarray(x), np.asarray(z))
+
+
+def test_random_map_problems_match_the_reference():
+    """G19: 300 random compute_map problems and 100 random revisited-protocol problems (evaluate.py:39-152) whose inputs are
+    regenerated from seeds (tests/golden/make_golden.py: fuzz_map_case / fuzz_revisited_case) against the reference's stored
+    outputs -- lists and arrays of ids, empty and overlapping ok / junk, a missing junk key, kappas beyond N, queries without
+    positives (NaN, excluded), and the reference's own ZeroDivisionError when NO query has positives."""
+    import contextlib
+    import copy
+    import io
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    try:
+        from make_golden import fuzz_map_case, fuzz_revisited_case
+    finally:
+        sys.path.remove(GOLDEN)
+    g = np.load(os.path.join(GOLDEN, "g19_map_fuzz.npz"))
+    errors = 0
+    for seed in range(300):
+        ranks, gnd, kappas = fuzz_map_case(seed)
+        if "error_%d" % seed in g:
+            errors += 1
+            with pytest.raises(BaseException) as caught:
+                E.compute_map(ranks.copy(), copy.deepcopy(gnd), list(kappas))
+            assert type(caught.value).__name__ == str(g["error_%d" % seed][0]), seed
+            continue
+        mAP, aps, pr, prs = E.compute_map(ranks.copy(), copy.deepcopy(gnd), list(kappas))
+        np.testing.assert_allclose(mAP, g["map_%d" % seed][0], rtol=0, atol=1e-12, err_msg=str(seed))
+        np.testing.assert_allclose(np.asarray(aps, dtype=np.float64), g["aps_%d" % seed], rtol=0, atol=1e-12, err_msg=str(seed))
+        np.testing.assert_allclose(np.asarray(pr, dtype=np.float64), g["pr_%d" % seed], rtol=0, atol=1e-12, err_msg=str(seed))
+        np.testing.assert_allclose(np.asarray(prs, dtype=np.float64), g["prs_%d" % seed], rtol=0, atol=1e-12, err_msg=str(seed))
+    assert 0 < errors < 100
+    for seed in range(100):
+        ranks, gnd = fuzz_revisited_case(1000 + seed)
+        name = "roxford5k" if seed % 2 else "rparis6k"
+        if "rev_error_%d" % seed in g:
+            with pytest.raises(BaseException) as caught, contextlib.redirect_stdout(io.StringIO()):
+                E.compute_map_and_print(name, ranks.copy(), copy.deepcopy(gnd))
+            assert type(caught.value).__name__ == str(g["rev_error_%d" % seed][0]), seed
+            continue
+        with contextlib.redirect_stdout(io.StringIO()):
+            avg, per = E.compute_map_and_print(name, ranks.copy(), copy.deepcopy(gnd))
+        for k in ("map_easy", "map_medium", "map_hard"):
+            np.testing.assert_allclose(avg[k], g["rev_%s_%d" % (k, seed)][0], rtol=0, atol=1e-12, err_msg="%s %d" % (k, seed))
+        for k in ("ap_easy", "ap_medium", "ap_hard"):
+            np.testing.assert_allclose(np.asarray(per[k], dtype=np.float64), g["rev_%s_%d" % (k, seed)], rtol=0, atol=1e-12, err_msg="%s %d" % (k, seed))

@@ -564,3 +564,46 @@ def test_regional_pooling_on_the_device(golden):
         feat = net.features(xin).cpu().numpy()
     want = O.l2n(O.rpool(feat, lambda a: O.gem(a, 3.0, 1e-6), net.pool.whiten.weight.detach().cpu().numpy(), net.pool.whiten.bias.detach().cpu().numpy()), 1e-6)
     np.testing.assert_allclose(got.t().cpu().numpy(), want, rtol=1e-4, atol=2e-6)
+
+
+def test_whitenapply_in_float64_and_random_map_problems_on_the_device():
+    """whitenapply (whiten.py:4-12) with the float64 `P` / `m` that whitenlearn pickles: float64 on the f64 matrix cores, equal to
+    numpy to 1e-12 (fp32 inputs keep the fp32 route).  compute_map on a DEVICE ranking (mdx_rank_positions) over the 300 random
+    problems of golden G19: the reference's values."""
+    import copy
+    from conftest import GOLDEN
+    from mdir_amd.evaluate import compute_map
+    from mdir_amd.whiten import whitenapply
+    rng = np.random.default_rng(8)
+    for d, n, dims in ((64, 500, None), (300, 1025, 128), (2048, 300, None), (17, 3, 5)):
+        X, m, P = rng.standard_normal((d, n)), rng.standard_normal((d, 1)) * 0.01, rng.standard_normal((d, d)) / np.sqrt(d)
+        kept = P[:dims] if dims else P
+        want = kept @ (X - m)
+        want = want / (np.linalg.norm(want, ord=2, axis=0, keepdims=True) + 1e-6)
+        got = whitenapply(X.copy(), m, P, dims)
+        assert got.dtype == np.float64 and got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+        got32 = whitenapply(X.astype(np.float32), m.astype(np.float32), P.astype(np.float32), dims)
+        assert got32.dtype == np.float32
+        np.testing.assert_allclose(got32, want, rtol=0, atol=5e-6)
+        mixed = whitenapply(X.astype(np.float32), m, P, dims)          # fp32 descriptors, float64 Lw (examples/test.py:246-249): float64
+        assert mixed.dtype == np.float64
+        np.testing.assert_allclose(mixed, (lambda y: y / (np.linalg.norm(y, ord=2, axis=0, keepdims=True) + 1e-6))(kept @ (X.astype(np.float32) - m)),
+                                   rtol=0, atol=1e-12)
+    sys.path.insert(0, GOLDEN)
+    try:
+        from make_golden import fuzz_map_case
+    finally:
+        sys.path.remove(GOLDEN)
+    g = np.load(os.path.join(GOLDEN, "g19_map_fuzz.npz"))
+    checked = 0
+    for seed in range(300):
+        ranks, gnd, kappas = fuzz_map_case(seed)
+        if "error_%d" % seed in g:
+            continue
+        mAP, aps, pr, prs = compute_map(dev(ranks), copy.deepcopy(gnd), list(kappas))
+        np.testing.assert_allclose(mAP, g["map_%d" % seed][0], rtol=0, atol=1e-12, err_msg=str(seed))
+        np.testing.assert_allclose(np.asarray(aps, dtype=np.float64), g["aps_%d" % seed], rtol=0, atol=1e-12, err_msg=str(seed))
+        np.testing.assert_allclose(np.asarray(prs, dtype=np.float64), g["prs_%d" % seed], rtol=0, atol=1e-12, err_msg=str(seed))
+        checked += 1
+    assert checked > 250

@@ -84,7 +84,7 @@ def test_layers_state_dict_and_registry():
     g = GeM()
     assert list(g.state_dict().keys()) == ["p"] and g.state_dict()["p"].shape == (1,)
     assert float(g.p) == 3.0 and g.eps == 1e-6 and L2N().eps == 1e-6
-    assert set(POOLING) == {"mac", "spoc", "gem"}
+    assert set(POOLING) == {"mac", "spoc", "gem", "rmac"}            # imageretrievalnet.py:32-37
     g.load_state_dict({"p": torch.tensor([2.5])})
     assert g.p_value() == 2.5
     with torch.no_grad():
