@@ -380,3 +380,49 @@ def extract_vectors(net, images, image_size, transform, bbxs=None, ms=[1], msp=1
     reference's signature and return layout (imageretrievalnet.py:277-304)."""
     vecs = extract_vectors_device(net, images, image_size, transform, bbxs, ms, msp, print_freq, device)
     return vecs.t().contiguous().cpu()
+
+
+# ---------------------------------------------------------------- regional / local descriptors (imageretrievalnet.py:325-384)
+
+def extract_ssr(net, input):
+    """The regional vectors of one image, ``[D, R]`` on the host (imageretrievalnet.py:354-355): ``Rpool`` without aggregation."""
+    return net.pool(net.features(input), aggregate=False).squeeze(0).squeeze(-1).squeeze(-1).permute(1, 0).cpu().data
+
+
+def extract_ssl(net, input):
+    """The local descriptors of one image, ``[D, H*W]`` on the host (imageretrievalnet.py:383-384): every location of the feature
+    map L2-normalised over the channels (``net.norm`` on the map) -- one row per location through ``mdx_l2n_rows``."""
+    feat = net.features(input)
+    c = feat.shape[1]
+    rows = feat.squeeze(0).reshape(c, -1).t().contiguous()              # [H*W, C]
+    return ops.l2n_rows_(rows, eps=net.norm.eps).t().contiguous().cpu().data
+
+
+def _extract_per_image(net, images, image_size, transform, bbxs, ms, print_freq, device, one):
+    from .datasets import ImagesFromList, make_loader
+    if not device:
+        net.cuda()
+        device = torch.device("cuda")
+    net.eval()
+    loader = make_loader(ImagesFromList(root="", images=images, imsize=image_size, bbxs=bbxs, transform=transform), range(len(images)),
+                         int(os.environ.get("MDIR_AMD_WORKERS", "8")), device)
+    vecs = []
+    with torch.no_grad():
+        for i, item in enumerate(loader):
+            if len(ms) != 1:
+                raise NotImplementedError           # as upstream ("TODO: not implemented yet", :344-347, :373-376)
+            vecs.append(one(net, item.to(device)))
+            if (i + 1) % print_freq == 0 or (i + 1) == len(images):
+                print("\r>>>> {}/{} done...".format(i + 1, len(images)), end="")
+        print("")
+    return vecs
+
+
+def extract_regional_vectors(net, images, image_size, transform, bbxs=None, ms=[1], msp=1, print_freq=10, device=None):
+    """List of ``[D, R_i]`` host tensors, one per image (imageretrievalnet.py:325-352; ``regional: True`` networks)."""
+    return _extract_per_image(net, images, image_size, transform, bbxs, ms, print_freq, device, extract_ssr)
+
+
+def extract_local_vectors(net, images, image_size, transform, bbxs=None, ms=[1], msp=1, print_freq=10, device=None):
+    """List of ``[D, H_i*W_i]`` host tensors, one per image (imageretrievalnet.py:358-381)."""
+    return _extract_per_image(net, images, image_size, transform, bbxs, ms, print_freq, device, extract_ssl)

@@ -237,3 +237,34 @@ for trial in range(40):
     if tuple(want.shape) != tuple(got.shape) or not np.allclose(want.numpy(), got.numpy(), rtol=1e-4, atol=2e-6, equal_nan=True):
         bad += 1; print("value mismatch", trial, pooling, regional, whitening, lw, ms, msp, tuple(want.shape), tuple(got.shape), float((want - got).abs().max()) if tuple(want.shape) == tuple(got.shape) else None)
 print("extract_vectors mismatches:", bad)
+# ---------------------------------------------------------------- regional / local descriptors (imageretrievalnet.py:325-384)
+bad = 0
+for trial in range(12):
+    torch.manual_seed(100 + trial)
+    c = 8
+    feats = [nn.Conv2d(3, c, 3, stride=2, padding=1), nn.ReLU(inplace=True), nn.Conv2d(c, c, 3, stride=2, padding=1), nn.ReLU(inplace=True)]
+    pooling = str(rng.choice(["gem", "mac", "spoc"]))
+    meta = {"architecture": "toy", "local_whitening": False, "pooling": pooling, "regional": True, "whitening": False,
+            "mean": [0.485, 0.456, 0.406], "std": [0.229, 0.224, 0.225], "outputdim": c, "out_channels": c}
+    rnet = RN.ImageRetrievalNet(copy.deepcopy(feats), None, RP.Rpool({"gem": RP.GeM, "mac": RP.MAC, "spoc": RP.SPoC}[pooling](), nn.Linear(c, c)), None, dict(meta)).eval()
+    mnet = MN.ImageRetrievalNet(copy.deepcopy(feats), None, ML.Rpool(ML.POOLING[pooling](), nn.Linear(c, c)), None, dict(meta)).eval()
+    mnet.load_state_dict(rnet.state_dict(), strict=True)
+    paths = []
+    for i in range(2):
+        w, h = int(rng.integers(40, 160)), int(rng.integers(40, 160))
+        pth = os.path.join(tmp, "r%d_%d.png" % (trial, i))
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(pth); paths.append(pth)
+    tr = Compose([ToTensor(), Normalize(meta["mean"], meta["std"])])
+    with torch.no_grad():
+        # the reference's functions call .cuda(): their one-image forms on the same loader items instead
+        from mdir_amd.datasets import ImagesFromList
+        items = [ImagesFromList("", [pth], imsize=96, transform=tr)[0][None] for pth in paths]
+        want_r = [RN.extract_ssr(rnet, x) for x in items]
+        want_l = [RN.extract_ssl(rnet, x) for x in items]
+        with contextlib.redirect_stdout(io.StringIO()):
+            got_r = MN.extract_regional_vectors(mnet, paths, 96, tr, device="cpu")
+            got_l = MN.extract_local_vectors(mnet, paths, 96, tr, device="cpu")
+    for a_, b_ in list(zip(want_r, got_r)) + list(zip(want_l, got_l)):
+        if tuple(a_.shape) != tuple(b_.shape) or not np.allclose(a_.numpy(), b_.numpy(), rtol=1e-4, atol=2e-6):
+            bad += 1; print("regional/local mismatch", trial, pooling, tuple(a_.shape), tuple(b_.shape))
+print("regional / local mismatches:", bad)

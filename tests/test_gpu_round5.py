@@ -607,3 +607,33 @@ def test_whitenapply_in_float64_and_random_map_problems_on_the_device():
         np.testing.assert_allclose(np.asarray(prs, dtype=np.float64), g["prs_%d" % seed], rtol=0, atol=1e-12, err_msg=str(seed))
         checked += 1
     assert checked > 250
+
+
+def test_regional_and_local_vectors_on_the_device(tmp_path, monkeypatch):
+    """extract_regional_vectors / extract_local_vectors (imageretrievalnet.py:325-384) with device=None (the network moves to the GPU,
+    as upstream): per image the oracle's regional vectors of the device's own feature map and its per-location L2N."""
+    from PIL import Image
+    from mdir_amd.datasets import Compose, ImagesFromList, Normalize, ToTensor
+    from mdir_amd.networks import extract_local_vectors, extract_regional_vectors, init_network
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    torch.manual_seed(0)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "regional": True, "whitening": False, "pretrained": False})
+    net.meta["out_channels"] = 256
+    rng = np.random.default_rng(1)
+    paths = []
+    for i, (w, h) in enumerate(((150, 110), (97, 160), (64, 64))):
+        paths.append(str(tmp_path / ("i%d.png" % i)))
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(paths[-1])
+    tr = Compose([ToTensor(), Normalize(net.meta["mean"], net.meta["std"])])
+    reg = extract_regional_vectors(net, paths, 128, tr)
+    loc = extract_local_vectors(net, paths, 128, tr)
+    assert next(net.parameters()).is_cuda
+    for i, p in enumerate(paths):
+        x = ImagesFromList("", [p], imsize=128, transform=tr)[0][None].to(DEV)
+        with torch.no_grad():
+            feat = net.features(x).cpu().numpy()
+        want = O.rpool(feat, lambda a: O.gem(a, 3.0, 1e-6), net.pool.whiten.weight.detach().cpu().numpy(), net.pool.whiten.bias.detach().cpu().numpy(),
+                       aggregate=False)[0]
+        np.testing.assert_allclose(reg[i].numpy(), want.T, rtol=1e-4, atol=2e-6)
+        rows = feat[0].reshape(256, -1)
+        np.testing.assert_allclose(loc[i].numpy(), rows / (np.linalg.norm(rows, axis=0, keepdims=True) + 1e-6), rtol=1e-5, atol=1e-7)

@@ -388,3 +388,37 @@ def test_regional_pooling_module_and_network(fops, golden):
     assert tuple(out.shape) == (1, len(regs), 4, 1, 1)
     for k, (i, j, hh, ww) in enumerate(regs):
         np.testing.assert_allclose(out[0, k, :, 0, 0].numpy(), 2 * x[0, :, i:i + hh, j:j + ww].amax(dim=(1, 2)).numpy())
+
+
+def test_regional_and_local_vectors(fops, tmp_path, capsys):
+    """extract_regional_vectors / extract_local_vectors (imageretrievalnet.py:325-384): one [D, R] / [D, H*W] host tensor per image,
+    the regional vectors of `Rpool(aggregate=False)`, the per-location L2N of the feature map; several scales are upstream's
+    NotImplementedError."""
+    from PIL import Image
+    from mdir_amd.datasets import Compose, ImagesFromList, Normalize, ToTensor
+    from mdir_amd.layers import rmac_regions
+    from mdir_amd.networks import extract_local_vectors, extract_regional_vectors, init_network
+    from oracle import oracle as O
+    torch.manual_seed(0)
+    net = init_network({"architecture": "alexnet", "pooling": "mac", "regional": True, "whitening": False, "pretrained": False}).eval()
+    net.meta["out_channels"] = 256
+    rng = np.random.default_rng(1)
+    paths = []
+    for i, (w, h) in enumerate(((150, 110), (97, 160))):
+        paths.append(str(tmp_path / ("i%d.png" % i)))
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(paths[-1])
+    tr = Compose([ToTensor(), Normalize(net.meta["mean"], net.meta["std"])])
+    reg = extract_regional_vectors(net, paths, 128, tr, device="cpu")
+    loc = extract_local_vectors(net, paths, 128, tr, device="cpu", print_freq=1)
+    assert ">>>> 2/2 done..." in capsys.readouterr().out
+    for i, p in enumerate(paths):
+        x = ImagesFromList("", [p], imsize=128, transform=tr)[0][None]
+        with torch.no_grad():
+            feat = net.features(x).numpy()
+        want = O.rpool(feat, O.mac, net.pool.whiten.weight.detach().numpy(), net.pool.whiten.bias.detach().numpy(), aggregate=False)[0]
+        assert tuple(reg[i].shape) == (256, len(rmac_regions(feat.shape[2], feat.shape[3], 3))) and not reg[i].is_cuda
+        np.testing.assert_allclose(reg[i].numpy(), want.T, rtol=1e-4, atol=2e-6)
+        rows = feat[0].reshape(256, -1)
+        np.testing.assert_allclose(loc[i].numpy(), rows / (np.linalg.norm(rows, axis=0, keepdims=True) + 1e-6), rtol=1e-5, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        extract_regional_vectors(net, paths, 128, tr, ms=[1, 0.5], device="cpu")
