@@ -163,27 +163,6 @@ static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_
 {
     constexpr int lds = LC_NSTAGE * (QT + QR + 4 * R) * LC_KC * 1024;
     const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
-    if constexpr (MM::STEPS == 4 && !RM && R == 2 && QT == 4 && QR == 1) {
-        // experiment (round 5): ONE workgroup per CU with 8 pipelined consumer waves (two per SIMD, in lock-step, sharing a query stage)
-        const char *e8 = getenv("MDX_SCORES_CW8");
-        if (e8 && e8[0] != '0') {
-            const bool pipe8 = e8[0] != '2';           // "2": the round-4 schedule with 8 consumers
-            auto k8p = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR, 8, RM, true>;
-            auto k8 = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR, 8, RM, false>;
-            constexpr int lds8 = LC_NSTAGE * (QT + QR + 8 * R) * LC_KC * 1024;
-            static bool opted8[64], opted8p[64];
-            int rc8 = pipe8 ? lds_opt_in((const void *)k8p, lds8, opted8p) : lds_opt_in((const void *)k8, lds8, opted8);
-            if (rc8 != MDX_OK) return rc8;
-            const int64_t blocks8 = ceil_div(RT, (int64_t)8 * R);
-            if (pipe8)
-                hipLaunchKernelGGL(k8p, dim3((unsigned)blocks8, (unsigned)passes), dim3(768), lds8, s, db, qt, out, n, KB, nq_valid,
-                                   (unsigned long long *)nullptr, ld);
-            else
-                hipLaunchKernelGGL(k8, dim3((unsigned)blocks8, (unsigned)passes), dim3(768), lds8, s, db, qt, out, n, KB, nq_valid,
-                                   (unsigned long long *)nullptr, ld);
-            return MDX_OK;
-        }
-    }
     if constexpr (MM::STEPS == 4 && !RM && R == 2) {
         // the pipelined consumer (PIPE): MDX_SCORES_PIPE=0/1 picks the form per launch (A/B in one process: tools/chain_power_probe.py)
         const char *e = getenv("MDX_SCORES_PIPE");

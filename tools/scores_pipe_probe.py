@@ -20,9 +20,8 @@ g = torch.Generator(device=dev)
 g.manual_seed(1)
 
 
-def timed(ix, q, out, pipe, reps=20, cw8="0"):
+def timed(ix, q, out, pipe, reps=20):
     os.environ["MDX_SCORES_PIPE"] = pipe
-    os.environ["MDX_SCORES_CW8"] = cw8
     for _ in range(3):
         ix.scores(q, "ND", out=out)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -52,11 +51,5 @@ for name in ("gaussian unit rows", "all zero"):
         t1 = timed(ix, q, o1, "1")
         print("%-20s round %d: shipped %.3f ms   pipelined %.3f ms   (%+.1f %%)   bit-equal %s"
               % (name, r, t0, t1, 100.0 * (t1 - t0) / t0, bool(torch.equal(o0, o1))), flush=True)
-        if os.environ.get("PROBE_CW8"):
-            o2 = torch.empty_like(o0)
-            t2 = timed(ix, q, o2, "1", cw8="1")
-            t3 = timed(ix, q, o2, "1", cw8="2")
-            print("%-20s round %d: 8 consumers pipelined %.3f ms (%+.1f %% vs shipped)   8 consumers r04 schedule %.3f ms   bit-equal %s"
-                  % (name, r, t2, 100.0 * (t2 - t0) / t0, t3, bool(torch.equal(o0, o2))), flush=True)
     del ix, o0, o1
     torch.cuda.empty_cache()

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Where does the exact similarity kernel's idle fifth come from?  Timing-only builds of the library (results wrong): no LDS-DMA
 # after the ring's first fill (-DMDX_ABL_NOLOAD), no ds_read after the first chunk (-DMDX_ABL_NOLDSREAD), both; each timed on
-# gaussian unit rows and on all-zero operands by tools/scores_pipe_probe.py (shipped pipelined kernel and, PROBE_CW8=1, one
-# workgroup of 8 consumers per CU, MDX_SCORES_CW8).  The variant libraries are built here when they are not there (~40 s each).
+# gaussian unit rows and on all-zero operands by tools/scores_pipe_probe.py (the 8-consumer rows of the profile: library and probe
+# of commit 16ee919, MDX_SCORES_CW8 / PROBE_CW8).  The variant libraries are built here when they are not there (~40 s each).
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/where_r05; rm -rf $OUT; mkdir -p $OUT
 SRC="mdx_index.hip mdx_rank.hip mdx_pool.hip mdx_trunk.hip mdx_jpeg.hip mdx_comm.hip mdx_gram.hip mdx_conv.hip mdx_clahe.hip"
 for v in NOLOAD NOLDSREAD "NOLOAD -DMDX_ABL_NOLDSREAD"; do
@@ -10,6 +10,6 @@ for v in NOLOAD NOLDSREAD "NOLOAD -DMDX_ABL_NOLDSREAD"; do
   [ -f $R/mdir_amd/libmdx_abl_$n.so ] || (cd $R/mdir_amd/csrc && /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-result -DMDX_ABL_$v -shared -o ../libmdx_abl_$n.so $SRC)
 done
 for v in "" _abl_NOLOAD _abl_NOLDSREAD _abl_NOLOADNOLDSREAD; do
-  MDIR_AMD_LIB=$R/mdir_amd/libmdx$v.so PROBE_CW8=1 timeout 300 python3 $R/tools/scores_pipe_probe.py 2 > $OUT/probe$v.log 2>&1
+  MDIR_AMD_LIB=$R/mdir_amd/libmdx$v.so timeout 300 python3 $R/tools/scores_pipe_probe.py 2 > $OUT/probe$v.log 2>&1
   echo "== libmdx$v.so"; grep round $OUT/probe$v.log | sed 's/bit-equal.*//'
 done

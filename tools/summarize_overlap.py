@@ -67,7 +67,7 @@ at an eighth of the chip.  The arithmetic bound the verdict quotes (12.7 GB per 
 needs the two kernels to share CUs at full occupancy each, which the register file forbids.
 
 Measured afterwards (same `tools/overlap_run.py`, 20 batches, one box): with ONE similarity workgroup of 8 pipelined consumers
-per CU (`MDX_SCORES_CW8=1`: 12 waves = 3 x 128 registers per SIMD, 126 KiB of LDS) the sort's histograms do become resident beside
+per CU (the experiment switch `MDX_SCORES_CW8=1` of commit `16ee919`: 12 waves = 3 x 128 registers per SIMD, 126 KiB of LDS) the sort's histograms do become resident beside
 it -- piped 3.33-3.35 ms against 3.45-3.50 serial in that form, and against 3.37-3.47 for the shipped kernel serial: nothing
 gained over the shipped one-stream step, because the scatter's 44 KiB still do not fit beside 126; with a two-stage ring (84 KiB,
 the scatter fits) the similarity itself loses 0.3 ms (3.79-3.82 serial, 3.63-3.68 piped).
