@@ -2,8 +2,9 @@
 a descriptor matrix).  Same stage protocol as ``mdir/stages/cirtorch_format/test.py:17-89`` --
 ``embed(params, data) -> (metadata, names, vecs [N,D][, whitened [N,d]])`` -- built from this package's own
 pieces: ``init_network`` + ``extract_vectors`` (device buffer, one hipGraph per image shape) and ``whitenapply``
-(``mdx_scores`` + ``mdx_l2n_rows``).  The other stages of that reference file (learning / converting / storing
-whitenings) are outside the hot path and not provided.
+(``mdx_scores`` + ``mdx_l2n_rows``).  ``learn_whitening`` (test.py:92-152 + ``_compute_whitening`` :241-268; round 5) learns the
+supervised whitening of a training set that is on disk (nothing is downloaded); converting / storing contained networks
+(``convert_contained_net``, ``load_whitening``) is not provided.
 
 An upstream checkpoint is ``{"meta": {architecture, pooling, whitening, mean, std, ...}, "state_dict"}``; a
 whitening is a pickled ``{'m': [D,1], 'P': [D,D]}`` stored as ``<whitening>_None_<image_size>_<multiscale>.lw.pkl``
@@ -57,3 +58,61 @@ def embed(params, data, device=None):
     with open(os.path.join(whitening_dir, "%s_%s_%s_%s.lw.pkl" % (whitening, None, image_size, multiscale)), "rb") as handle:
         lw = pickle.load(handle)
     return {}, names, vecs.T, whitenapply(vecs, lw["m"], lw["P"], device=device or "cuda").T
+
+
+def cid2filename(cid, prefix):
+    """``cirtorch/datasets/datahelpers.py:9-22``: ``<prefix>/<last 2>/<2 before>/<2 before>/<cid>``."""
+    return os.path.join(prefix, cid[-2:], cid[-4:-2], cid[-6:-4], cid)
+
+
+def _compute_whitening(whitening, net, image_size, transform, ms, msp, device=None):
+    """``test.py:241-268``: descriptors of the training set ``<data root>/train/<whitening>`` (``<whitening>-whiten.pkl`` with
+    ``cids`` / ``qidxs`` / ``pidxs``, images under ``ims/``), then ``whitenlearn`` on the device."""
+    import time
+    from .datasets import get_data_root
+    from .whiten import whitenlearn
+    start = time.time()
+    print(">> {}: Learning whitening...".format(whitening))
+    db_root = os.path.join(get_data_root(), "train", whitening)
+    with open(os.path.join(db_root, "{}-whiten.pkl".format(whitening)), "rb") as f:
+        db = pickle.load(f)
+    images = [cid2filename(db["cids"][i], os.path.join(db_root, "ims")) for i in range(len(db["cids"]))]
+    print(">> {}: Extracting...".format(whitening))
+    wvecs = extract_vectors(net, images, image_size, transform, ms=ms, msp=msp, device=device)
+    print(">> {}: Learning...".format(whitening))
+    m, P = whitenlearn(wvecs.numpy(), db["qidxs"], db["pidxs"], device=device or "cuda")
+    elapsed = time.time() - start
+    print(">> {}: elapsed time: {:.0f}s".format(whitening, elapsed))
+    return {"m": m, "P": P}, elapsed
+
+
+def learn_whitening(params, data, device=None):
+    """``test.py:92-152``: ``({"whitening_learn": seconds}, Lw)``, or ``({"whitening_learn": seconds},)`` with the whitening
+    pickled as ``<whitening_dir>/<whitening>_None_<image_size>_<multiscale>.lw.pkl`` (the name ``embed`` looks for)."""
+    params = dict(params)
+    checkpoint, whitening = params.pop("net"), params.pop("whitening")
+    whitening_dir = params.pop("whitening_dir", None)
+    image_size, multiscale = params.pop("image_size", 1024), params.pop("multiscale", True)
+    params.pop("imgdir", None)
+    assert not params
+    assert not data
+    assert os.path.exists(checkpoint), checkpoint
+    whitening = {"sfm30k": "retrieval-SfM-30k", "sfm120k": "retrieval-SfM-120k"}.get(whitening, whitening)
+    print(">> Loading network:\n>>>> '{}'".format(checkpoint))
+    net = load_upstream(checkpoint).eval()
+    print(">>>> loaded network: ")
+    print(net.meta_repr())
+    if device is None:
+        net.cuda()
+    else:
+        net.to(device)
+    scales = (MS_SCALES if multiscale else [1]) if isinstance(multiscale, bool) else multiscale
+    msp = float(net.pool.p) if net.meta["pooling"] == "gem" and net.whiten is None and len(scales) > 1 else 1
+    transform = Compose([ToTensor(), Normalize(net.meta["mean"], net.meta["std"])])
+    Lw, elapsed = _compute_whitening(whitening, net, image_size, transform, scales, msp, device)
+    if whitening_dir:
+        os.makedirs(whitening_dir, exist_ok=True)
+        with open(os.path.join(whitening_dir, "%s_%s_%s_%s.lw.pkl" % (whitening, None, image_size, multiscale)), "wb") as handle:
+            pickle.dump(Lw, handle)
+        return {"whitening_learn": int(elapsed)},
+    return {"whitening_learn": int(elapsed)}, Lw

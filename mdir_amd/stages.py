@@ -143,3 +143,104 @@ def infer(params, data, device=None):
     total = time.time() - t0
     metadata = {"stats": {"total_time": int(total), "avg_time": total / len(loader)}}
     return (metadata,) + output.postprocess()
+
+
+# ---------------------------------------------------------------- whitening stages (mdir/stages/whiten.py:10-87; SURVEY 8 row f3's callers)
+
+class ResourceUsage:
+    """``mdir/tools/stats.py:70-131`` as far as the stages report it: current RAM / device memory and the process's cumulative CPU
+    and IO counters (``psutil``; the reference's per-process figure from ``nvidia-smi`` has no counterpart here and is None)."""
+
+    def __init__(self):
+        self.resources = {}
+
+    def take_current_stats(self):
+        import psutil
+        self.resources["ram_memory_gib"] = round(psutil.Process().memory_info().vms / 2 ** 30, 3)
+        if torch.cuda.is_available():
+            self.resources["gpu"] = {"memory_nvidia_gib": None, "memory_torch_gib": round(torch.cuda.memory_allocated() / 2 ** 30, 3)}
+        return self
+
+    def get_resources(self):
+        import time
+        import psutil
+        proc = psutil.Process()
+        with proc.oneshot():
+            cpu = proc.cpu_times()
+            stats = {"cpu": {"user_s": int(cpu.user), "system_s": int(cpu.system), "children_user_s": int(cpu.children_user),
+                             "children_system_s": int(cpu.children_system), "proc_wall_s": int(time.time() - proc.create_time())}}
+            stats["cpu"]["tree_used_s"] = sum(stats["cpu"][k] for k in ("user_s", "system_s", "children_user_s", "children_system_s"))
+            stats["cpu"]["avg_cores"] = round(stats["cpu"]["tree_used_s"] / max(stats["cpu"]["proc_wall_s"], 1), 1)
+            io = proc.io_counters()
+            stats["io"] = {"read_count": io.read_count, "write_count": io.write_count,
+                           "read_gib": round(io.read_bytes / 2 ** 30, 3), "write_gib": round(io.write_bytes / 2 ** 30, 3)}
+        return {**self.resources, **stats}
+
+
+def whiten(params, data, device="cuda"):
+    """Apply a pre-computed whitening to ``[N,D]`` descriptors (``stages/whiten.py:10-24``): ``(metadata, names, [N,d])``."""
+    import time
+    from .whiten import whitenapply
+    dimensions = params.pop("dimensions", None) or None
+    assert not params, params.keys()
+    whitening, names, values = data
+    assert len(names) == len(values)
+    resources = ResourceUsage()
+    time0 = time.time()
+    whitened = whitenapply(values.T, whitening["m"], whitening["P"], dimensions, device=device)
+    metadata = {"timings": {"whitening_apply": round(time.time() - time0, 2)},
+                "resource_usage": resources.take_current_stats().get_resources()}
+    return metadata, names, whitened.T
+
+
+def learn_lw_whitening(params, data, device="cuda"):
+    """Learn the supervised whitening from (query, positive) NAME pairs (``stages/whiten.py:27-69``): ``(metadata, {'m','P'})``.
+    A covariance that is not positive definite is retried on shrinking random subsets of the pairs, up to 100 trials, as upstream."""
+    import sys
+    import time
+    from .whiten import whitenlearn
+    assert not params
+    names, values, queries, positives = data
+    assert len(names) == len(values)
+    assert len(queries) == len(positives)
+    values = values.astype(np.float64).T
+    name_index = {x: i for i, x in enumerate(names)}
+    qidxs = np.array([name_index[x] for x in queries])
+    pidxs = np.array([name_index[x] for x in positives])
+    resources = ResourceUsage()
+    time0 = time.time()
+    max_trials, max_excluded, trial = 100, 0.95, 0
+    while True:
+        try:
+            if trial == 0:
+                qwhit, pwhit = qidxs, pidxs
+            else:
+                idxs = np.random.permutation(len(qidxs))[:int(len(qidxs) * (1 - trial / max_trials * max_excluded))]
+                print("Using subset of queries (%s/%s) trial %s" % (len(idxs), len(qidxs), trial), file=sys.stderr)
+                qwhit, pwhit = qidxs[idxs], pidxs[idxs]
+            whit_m, whit_p = whitenlearn(values, qwhit, pwhit, device=device)
+            break
+        except np.linalg.LinAlgError as e:
+            if str(e) != "Matrix is not positive definite" or trial >= max_trials - 1:
+                raise
+            trial += 1
+    metadata = {"stats": {"failed_times": trial, "vectors_used": round(len(qwhit) / float(len(qidxs)), 2), "vectors_total": len(qidxs)},
+                "timings": {"whitening_learn": round(time.time() - time0, 2)},
+                "resource_usage": resources.take_current_stats().get_resources()}
+    return metadata, {"m": whit_m, "P": whit_p}
+
+
+def learn_pca_whitening(params, data, device="cuda"):
+    """Learn the PCA whitening of ``[N,D]`` descriptors (``stages/whiten.py:72-87``): ``(metadata, {'m','P'})``."""
+    import time
+    from .whiten import pcawhitenlearn
+    shrink = params.pop("shrink", None) or None
+    assert not params
+    values, = data
+    values = values.astype(np.float64).T
+    resources = ResourceUsage()
+    time0 = time.time()
+    whit_m, whit_p = pcawhitenlearn(values, shrink, device=device)
+    metadata = {"timings": {"whitening_learn": round(time.time() - time0, 2)},
+                "resource_usage": resources.take_current_stats().get_resources()}
+    return metadata, {"m": whit_m, "P": whit_p}

@@ -268,3 +268,30 @@ for trial in range(12):
         if tuple(a_.shape) != tuple(b_.shape) or not np.allclose(a_.numpy(), b_.numpy(), rtol=1e-4, atol=2e-6):
             bad += 1; print("regional/local mismatch", trial, pooling, tuple(a_.shape), tuple(b_.shape))
 print("regional / local mismatches:", bad)
+# ---------------------------------------------------------------- whitening stages (mdir/stages/whiten.py)
+from mdir.stages import whiten as RS
+from mdir_amd import stages as MS
+bad = 0
+for trial in range(10):
+    n, d = int(rng.integers(40, 90)), int(rng.integers(4, 14))
+    vals = rng.standard_normal((n, d)).astype(np.float32)
+    names = ["n%d" % i for i in range(n)]
+    k = int(rng.integers(8, n // 2))
+    queries, positives = names[:k], names[k:2 * k]
+    _, want = RS.learn_lw_whitening({}, (names, vals.copy(), queries, positives))
+    _, got = MS.learn_lw_whitening({}, (names, vals.copy(), queries, positives), device="cpu")
+    # eigenvectors are defined up to sign: compare P up to the sign of its rows, and what whitening does to the data
+    sign = np.sign(np.sum(want["P"] * got["P"], axis=1, keepdims=True))
+    if not (np.allclose(want["m"], got["m"]) and np.abs(want["P"] - got["P"] * sign).max() <= 1e-6 * np.abs(want["P"]).max()):       # relative to the largest entry: small pair sets are ill-conditioned
+        bad += 1; print("learn_lw_whitening mismatch", trial, np.abs(want["P"] - got["P"] * sign).max(), np.abs(want["P"]).max())
+    _, wpca = RS.learn_pca_whitening({"shrink": None}, (vals.copy(),))
+    _, gpca = MS.learn_pca_whitening({"shrink": None}, (vals.copy(),), device="cpu")
+    sign = np.sign(np.sum(wpca["P"] * gpca["P"], axis=1, keepdims=True))
+    if not np.allclose(wpca["P"], gpca["P"] * sign, rtol=1e-6, atol=1e-8):
+        bad += 1; print("learn_pca_whitening mismatch", trial)
+    dims = None if trial % 2 else int(rng.integers(1, d + 1))
+    _, _, ww = RS.whiten({"dimensions": dims}, (want, names, vals.copy()))
+    _, _, gw = MS.whiten({"dimensions": dims}, (want, names, vals.copy()), device="cpu")
+    if ww.shape != gw.shape or not np.allclose(ww, gw, rtol=0, atol=1e-12):
+        bad += 1; print("whiten stage mismatch", trial, np.abs(ww - gw).max())
+print("whitening stage mismatches:", bad)

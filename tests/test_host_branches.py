@@ -422,3 +422,86 @@ def test_regional_and_local_vectors(fops, tmp_path, capsys):
         np.testing.assert_allclose(loc[i].numpy(), rows / (np.linalg.norm(rows, axis=0, keepdims=True) + 1e-6), rtol=1e-5, atol=1e-7)
     with pytest.raises(NotImplementedError):
         extract_regional_vectors(net, paths, 128, tr, ms=[1, 0.5], device="cpu")
+
+
+def test_whitening_stages(fops, golden, tmp_path, monkeypatch, capsys):
+    """mdir/stages/whiten.py:10-87 (`whiten`, `learn_lw_whitening`, `learn_pca_whitening`) and cirtorch_format/test.py:92-152,241-268
+    (`learn_whitening` on a training set that is on disk): the stage protocol around whitenapply / whitenlearn / pcawhitenlearn
+    (golden G12 pins those), the retry on a matrix that is not positive definite, the file name `embed` looks for."""
+    from PIL import Image
+    from mdir_amd import cirtorch_format as C
+    from mdir_amd import stages
+    from mdir_amd import whiten as W
+    from mdir_amd.networks import init_network
+    rng = np.random.default_rng(3)
+    n, d = 60, 12
+    vals = rng.standard_normal((n, d)).astype(np.float32)
+    names = ["im%03d" % i for i in range(n)]
+    queries, positives = names[:20], names[20:40]
+    meta, Lw = stages.learn_lw_whitening({}, (names, vals, queries, positives), device="cpu")
+    m, P = W.whitenlearn(vals.astype(np.float64).T, np.arange(20), np.arange(20, 40), device="cpu")
+    np.testing.assert_allclose(Lw["m"], m)
+    np.testing.assert_allclose(Lw["P"], P)
+    assert meta["stats"] == {"failed_times": 0, "vectors_used": 1.0, "vectors_total": 20}
+    assert set(meta) == {"stats", "timings", "resource_usage"} and {"ram_memory_gib", "cpu", "io"} <= set(meta["resource_usage"])
+    meta, pca = stages.learn_pca_whitening({"shrink": None}, (vals,), device="cpu")
+    m2, P2 = W.pcawhitenlearn(vals.astype(np.float64).T, None, device="cpu")
+    np.testing.assert_allclose(pca["P"], P2)
+    meta, out_names, white = stages.whiten({"dimensions": 5}, (Lw, names, vals), device="cpu")
+    assert out_names is names and white.shape == (n, 5) and "whitening_apply" in meta["timings"]
+    np.testing.assert_allclose(white, W.whitenapply(vals.T, Lw["m"], Lw["P"], 5, device="cpu").T)
+    np.testing.assert_allclose(np.linalg.norm(white, axis=1), 1.0, atol=1e-5)
+    with pytest.raises(AssertionError):
+        stages.whiten({"dimensions": 5, "bogus": 1}, (Lw, names, vals), device="cpu")
+    # not positive definite on the first trials: retried on random subsets, then given up after 100 (stages/whiten.py:43-60)
+    calls = []
+
+    def flaky(X, q, p, device="cuda"):
+        calls.append(len(q))
+        if len(calls) <= 2:
+            raise np.linalg.LinAlgError("Matrix is not positive definite")
+        return W.whitenlearn.__wrapped__(X, q, p, device=device) if hasattr(W.whitenlearn, "__wrapped__") else (np.zeros((d, 1)), np.eye(d))
+    monkeypatch.setattr(W, "whitenlearn", flaky)
+    np.random.seed(0)
+    meta, _ = stages.learn_lw_whitening({}, (names, vals, queries, positives), device="cpu")
+    assert meta["stats"]["failed_times"] == 2 and calls[0] == 20 and calls[1] < 20 and calls[2] <= calls[1]
+    assert "Using subset of queries" in capsys.readouterr().err
+
+    def other(X, q, p, device="cuda"):
+        raise np.linalg.LinAlgError("Singular matrix")
+    monkeypatch.setattr(W, "whitenlearn", other)
+    with pytest.raises(np.linalg.LinAlgError, match="Singular"):
+        stages.learn_lw_whitening({}, (names, vals, queries, positives), device="cpu")
+    monkeypatch.undo()
+    fake_ops.install(monkeypatch)
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    # learn_whitening: <root>/data/train/<set>/<set>-whiten.pkl + ims/<..>/<cid>
+    monkeypatch.setenv("CIRTORCH_ROOT", str(tmp_path))
+    root = tmp_path / "data" / "train" / "toyset"
+    cids = ["%032x" % i for i in range(30)]
+    for cid in cids:
+        path = C.cid2filename(cid, str(root / "ims"))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        Image.fromarray(rng.integers(0, 255, (70, 90, 3), dtype=np.uint8)).save(path, format="JPEG")
+    assert C.cid2filename("abcdef0123456789", "/x") == "/x/89/67/45/abcdef0123456789"
+    with open(root / "toyset-whiten.pkl", "wb") as f:
+        pickle.dump({"cids": cids, "qidxs": list(range(10)), "pidxs": list(range(10, 20))}, f)
+    torch.manual_seed(2)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False})
+    meta_up = {"architecture": "alexnet", "pooling": "gem", "whitening": False, "mean": net.meta["mean"], "std": net.meta["std"], "outputdim": 256,
+               "local_whitening": False, "regional": False}
+    torch.save({"meta": meta_up, "state_dict": net.state_dict()}, str(tmp_path / "up.pth"))
+    timing, Lw2 = C.learn_whitening({"net": str(tmp_path / "up.pth"), "whitening": "toyset", "image_size": 64, "multiscale": False}, (), device="cpu")
+    assert set(timing) == {"whitening_learn"} and Lw2["P"].shape == (256, 256) and Lw2["m"].shape == (256, 1)
+    res = C.learn_whitening({"net": str(tmp_path / "up.pth"), "whitening": "toyset", "image_size": 64, "multiscale": False,
+                             "whitening_dir": str(tmp_path / "wh")}, (), device="cpu")
+    assert len(res) == 1 and os.path.exists(tmp_path / "wh" / "toyset_None_64_False.lw.pkl")
+    with open(tmp_path / "wh" / "toyset_None_64_False.lw.pkl", "rb") as f:
+        np.testing.assert_allclose(pickle.load(f)["P"], Lw2["P"])
+    # ... which is the file `embed` looks for
+    imgs = [os.path.relpath(C.cid2filename(c, str(root / "ims")), str(root / "ims")) for c in cids[:3]]
+    out = C.embed({"net": str(tmp_path / "up.pth"), "imgdir": str(root / "ims"), "whitening": "toyset", "whitening_dir": str(tmp_path / "wh"),
+                   "image_size": 64, "multiscale": False}, (imgs,), device="cpu")
+    assert out[3].shape == (3, 256)
+    with pytest.raises(AssertionError):
+        C.learn_whitening({"net": str(tmp_path / "up.pth"), "whitening": "toyset"}, (["x"],), device="cpu")
