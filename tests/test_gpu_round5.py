@@ -637,3 +637,24 @@ def test_regional_and_local_vectors_on_the_device(tmp_path, monkeypatch):
         np.testing.assert_allclose(reg[i].numpy(), want.T, rtol=1e-4, atol=2e-6)
         rows = feat[0].reshape(256, -1)
         np.testing.assert_allclose(loc[i].numpy(), rows / (np.linalg.norm(rows, axis=0, keepdims=True) + 1e-6), rtol=1e-5, atol=1e-7)
+
+
+def test_whitening_stages_on_the_device(golden):
+    """mdir/stages/whiten.py on the default device: `learn_lw_whitening` on golden G12's descriptors and pairs gives the reference's
+    (m, P) (rows up to sign) through mdx_gram_f64 / mdx_project_f64; `whiten` with that float64 whitening equals numpy to 1e-12."""
+    from mdir_amd import stages
+    g = golden("g12_whitenlearn.npz")
+    X, q, p = g["X"], g["qidxs"], g["pidxs"]                  # [D, N] float32 descriptors, pair indices
+    names = ["v%d" % i for i in range(X.shape[1])]
+    meta, Lw = stages.learn_lw_whitening({}, (names, X.T.copy(), [names[i] for i in q], [names[i] for i in p]))
+    assert meta["stats"]["failed_times"] == 0 and "gpu" in meta["resource_usage"]
+    np.testing.assert_allclose(Lw["m"], g["m_lw"], rtol=1e-9, atol=1e-12)
+    sign = np.sign(np.sum(Lw["P"] * g["P_lw"], axis=1, keepdims=True))
+    assert np.abs(Lw["P"] * sign - g["P_lw"]).max() <= 1e-7 * np.abs(g["P_lw"]).max()
+    _, _, white = stages.whiten({"dimensions": None}, (Lw, names, X.T.copy()))
+    want = Lw["P"] @ (X.astype(np.float64) - Lw["m"])
+    want = (want / (np.linalg.norm(want, ord=2, axis=0, keepdims=True) + 1e-6)).T
+    np.testing.assert_allclose(white, want, rtol=0, atol=1e-12)
+    _, pca = stages.learn_pca_whitening({}, (X.T.copy(),))
+    sign = np.sign(np.sum(pca["P"] * g["P_pca"], axis=1, keepdims=True))
+    assert np.abs(pca["P"] * sign - g["P_pca"]).max() <= 1e-7 * np.abs(g["P_pca"]).max()
