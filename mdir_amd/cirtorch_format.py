@@ -3,8 +3,9 @@ a descriptor matrix).  Same stage protocol as ``mdir/stages/cirtorch_format/test
 ``embed(params, data) -> (metadata, names, vecs [N,D][, whitened [N,d]])`` -- built from this package's own
 pieces: ``init_network`` + ``extract_vectors`` (device buffer, one hipGraph per image shape) and ``whitenapply``
 (``mdx_scores`` + ``mdx_l2n_rows``).  ``learn_whitening`` (test.py:92-152 + ``_compute_whitening`` :241-268; round 5) learns the
-supervised whitening of a training set that is on disk (nothing is downloaded); converting / storing contained networks
-(``convert_contained_net``, ``load_whitening``) is not provided.
+supervised whitening of a training set that is on disk (nothing is downloaded); ``convert_contained_net`` (:156-201) rewrites an
+upstream checkpoint as the ``CirNetwork`` checkpoint ``load_network`` reads, ``load_whitening`` (:204-238) takes the whitening an
+upstream checkpoint carries in ``meta['Lw']``.
 
 An upstream checkpoint is ``{"meta": {architecture, pooling, whitening, mean, std, ...}, "state_dict"}``; a
 whitening is a pickled ``{'m': [D,1], 'P': [D,D]}`` stored as ``<whitening>_None_<image_size>_<multiscale>.lw.pkl``
@@ -116,3 +117,56 @@ def learn_whitening(params, data, device=None):
             pickle.dump(Lw, handle)
         return {"whitening_learn": int(elapsed)},
     return {"whitening_learn": int(elapsed)}, Lw
+
+
+def convert_contained_net(params, data):
+    """``test.py:156-201``: upstream ``{"meta", "state_dict"}`` at ``source`` -> this path's checkpoint ``{"type": "CirNetwork",
+    "network_params": {"model", "runtime"}, "model_state"}`` at ``net`` (learning/network.py:142-150).  Every key of the upstream
+    ``meta`` must be accounted for (``outputdim`` and ``Lw`` are dropped), as upstream's integrity check demands."""
+    params = dict(params)
+    source, target = params.pop("source"), params.pop("net")
+    assert not params
+    assert not data
+    assert os.path.exists(source), source
+    print(">> Loading network:\n>>>> '{}'".format(source))
+    official = torch.load(source, map_location="cpu", weights_only=False)
+    meta = dict(official.pop("meta"))
+    model = {"architecture": "cirnet", "cir_architecture": meta.pop("architecture"), "local_whitening": meta.pop("local_whitening", False),
+             "pooling": meta.pop("pooling"), "regional": meta.pop("regional", False), "whitening": meta.pop("whitening"), "pretrained": True}
+    runtime = {"wrappers": "", "data": {"mean_std": [meta.pop("mean"), meta.pop("std")], "transforms": "pil2np | totensor | normalize"}}
+    # "frozen": the one key added to what upstream writes (test.py:169-189) -- upstream's own loader demands it
+    # (learning/network.py:156 asserts the key set {"type", "frozen", "network_params", "model_state"}) and would refuse upstream's file
+    net_state = {"type": "CirNetwork", "frozen": True, "network_params": {"model": model, "runtime": runtime},
+                 "model_state": official.pop("state_dict")}
+    del meta["outputdim"]
+    del meta["Lw"]
+    assert not meta, meta
+    assert not official, official
+    if os.path.dirname(target):
+        os.makedirs(os.path.dirname(target), exist_ok=True)
+    torch.save(net_state, target)
+    return {},
+
+
+def load_whitening(params, data):
+    """``test.py:204-238``: the whitening ``meta['Lw'][<set>]['ms' | 'ss']`` of an upstream checkpoint -- returned, or pickled
+    under the name ``embed`` looks for when ``whitening_dir`` is given."""
+    params = dict(params)
+    checkpoint, whitening = params.pop("net"), params.pop("whitening")
+    whitening_dir = params.pop("whitening_dir", None)
+    image_size, multiscale = params.pop("image_size", 1024), params.pop("multiscale", True)
+    params.pop("imgdir", None)
+    assert not params
+    assert not data
+    assert os.path.exists(checkpoint), checkpoint
+    whitening = {"sfm30k": "retrieval-SfM-30k", "sfm120k": "retrieval-SfM-120k"}.get(whitening, whitening)
+    print(">> Loading network:\n>>>> '{}'".format(checkpoint))
+    state = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    assert isinstance(multiscale, bool)
+    Lw = state["meta"]["Lw"][whitening]["ms" if multiscale else "ss"]
+    if whitening_dir:
+        os.makedirs(whitening_dir, exist_ok=True)
+        with open(os.path.join(whitening_dir, "%s_%s_%s_%s.lw.pkl" % (whitening, None, image_size, multiscale)), "wb") as handle:
+            pickle.dump(Lw, handle)
+        return {},
+    return {}, Lw

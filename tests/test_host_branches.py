@@ -505,3 +505,55 @@ def test_whitening_stages(fops, golden, tmp_path, monkeypatch, capsys):
     assert out[3].shape == (3, 256)
     with pytest.raises(AssertionError):
         C.learn_whitening({"net": str(tmp_path / "up.pth"), "whitening": "toyset"}, (["x"],), device="cpu")
+
+
+def test_upstream_checkpoint_conversion_and_carried_whitening(fops, tmp_path, monkeypatch):
+    """cirtorch_format/test.py:156-238: `convert_contained_net` turns an upstream {"meta", "state_dict"} file into the CirNetwork
+    checkpoint `load_network` reads (same descriptors from both); `load_whitening` takes `meta['Lw'][set]['ms' | 'ss']`; the
+    upstream integrity check (every meta key accounted for) is kept."""
+    from PIL import Image
+    from mdir_amd import cirtorch_format as C
+    from mdir_amd.datasets import initialize_transforms
+    from mdir_amd.network import load_network
+    from mdir_amd.networks import extract_vectors, init_network
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    rng = np.random.default_rng(9)
+    torch.manual_seed(4)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False})
+    Lw = {"retrieval-SfM-120k": {"ms": {"m": rng.standard_normal((256, 1)), "P": rng.standard_normal((256, 256))},
+                                 "ss": {"m": rng.standard_normal((256, 1)), "P": rng.standard_normal((256, 256))}}}
+    meta = {"architecture": "alexnet", "pooling": "gem", "whitening": False, "mean": net.meta["mean"], "std": net.meta["std"], "outputdim": 256,
+            "local_whitening": False, "regional": False, "Lw": Lw}
+    src, dst = str(tmp_path / "upstream.pth"), str(tmp_path / "conv" / "net.pth")
+    torch.save({"meta": meta, "state_dict": net.state_dict()}, src)
+    assert C.convert_contained_net({"source": src, "net": dst}, ()) == ({},)
+    saved = torch.load(dst, weights_only=False)
+    assert saved["type"] == "CirNetwork" and set(saved) == {"type", "frozen", "network_params", "model_state"} and saved["frozen"] is True
+    assert saved["network_params"]["model"] == {"architecture": "cirnet", "cir_architecture": "alexnet", "local_whitening": False, "pooling": "gem",
+                                                 "regional": False, "whitening": False, "pretrained": True}
+    assert saved["network_params"]["runtime"] == {"wrappers": "", "data": {"mean_std": [net.meta["mean"], net.meta["std"]],
+                                                                            "transforms": "pil2np | totensor | normalize"}}
+    loaded = load_network({"path": dst, "runtime": None}, "cpu").eval()
+    paths = []
+    for i in range(2):
+        paths.append(str(tmp_path / ("i%d.png" % i)))
+        Image.fromarray(rng.integers(0, 255, (80, 100, 3), dtype=np.uint8)).save(paths[-1])
+    tr = initialize_transforms("pil2np | totensor | normalize", [net.meta["mean"], net.meta["std"]])
+    with torch.no_grad():
+        a = extract_vectors(loaded, paths, 64, tr, device="cpu")
+        b = extract_vectors(C.load_upstream(src).eval(), paths, 64, tr, device="cpu")
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=1e-7)
+    # an upstream meta key nobody accounts for is refused, as upstream
+    torch.save({"meta": dict(meta, surprise=1), "state_dict": net.state_dict()}, str(tmp_path / "odd.pth"))
+    with pytest.raises(AssertionError):
+        C.convert_contained_net({"source": str(tmp_path / "odd.pth"), "net": dst}, ())
+    with pytest.raises(AssertionError):
+        C.convert_contained_net({"source": str(tmp_path / "absent.pth"), "net": dst}, ())
+    got = C.load_whitening({"net": src, "whitening": "sfm120k", "multiscale": True}, ())
+    assert got[0] == {} and got[1] is not None and np.array_equal(got[1]["P"], Lw["retrieval-SfM-120k"]["ms"]["P"])
+    assert np.array_equal(C.load_whitening({"net": src, "whitening": "retrieval-SfM-120k", "multiscale": False}, ())[1]["P"], Lw["retrieval-SfM-120k"]["ss"]["P"])
+    assert C.load_whitening({"net": src, "whitening": "sfm120k", "whitening_dir": str(tmp_path / "wh"), "image_size": 512}, ()) == ({},)
+    with open(tmp_path / "wh" / "retrieval-SfM-120k_None_512_True.lw.pkl", "rb") as f:
+        assert np.array_equal(pickle.load(f)["m"], Lw["retrieval-SfM-120k"]["ms"]["m"])
+    with pytest.raises(AssertionError):
+        C.load_whitening({"net": src, "whitening": "sfm120k", "multiscale": [1, 0.5]}, ())
