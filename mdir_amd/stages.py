@@ -244,3 +244,35 @@ def learn_pca_whitening(params, data, device="cuda"):
     metadata = {"timings": {"whitening_learn": round(time.time() - time0, 2)},
                 "resource_usage": resources.take_current_stats().get_resources()}
     return metadata, {"m": whit_m, "P": whit_p}
+
+
+def paste_pca_normalize(params, data, device="cuda"):
+    """Concatenate descriptor matrices side by side, optionally keep the ``dimensions`` principal directions, L2-normalise the rows
+    (``stages/whiten.py:90-118``): ``(metadata, [N, sum D])``.  The PCA is upstream's: the SCALAR mean of the whole matrix is
+    subtracted, the eigenvectors of ``value.T @ value`` with the largest eigenvalues span the subspace the rows are projected onto
+    (the dimension of the rows does not change).  The Gram matrix and the projection run on the f64 matrix cores, the symmetric
+    eigen-decomposition next to the data (upstream: ``np.linalg.eig`` on the host)."""
+    import time
+    from . import ops
+    from .whiten import _as_f64
+    dimensions = params.pop("dimensions") or None
+    assert not params
+    assert len(set(len(x) for x in data)) == 1
+    if data[0].shape == (0,):
+        return {}, data[0]
+    value = np.concatenate(data, axis=1)
+    if dimensions:
+        resources = ResourceUsage()
+        time0 = time.time()
+        value = value - np.mean(value)
+        vt = _as_f64(value.T, device)                                    # [D, N]
+        eigval, eigvec = torch.linalg.eigh(ops.gram_f64(vt))             # ascending: the last `dimensions` columns are the largest
+        vecs = eigvec[:, -dimensions:].contiguous()
+        proj = ops.project_f64(ops.gram_f64(vecs), vt)                   # (V V^T) value^T  -> [D, N]
+        value = proj.t().contiguous().cpu().numpy()
+        metadata = {"timings": {"pca_compute": round(time.time() - time0, 2)},
+                    "resource_usage": resources.take_current_stats().get_resources()}
+    else:
+        metadata = {}
+    value = value / np.expand_dims(np.linalg.norm(value, axis=1), axis=1)
+    return metadata, value

@@ -294,4 +294,11 @@ for trial in range(10):
     _, _, gw = MS.whiten({"dimensions": dims}, (want, names, vals.copy()), device="cpu")
     if ww.shape != gw.shape or not np.allclose(ww, gw, rtol=0, atol=1e-12):
         bad += 1; print("whiten stage mismatch", trial, np.abs(ww - gw).max())
+    parts = [rng.standard_normal((n, int(rng.integers(2, 6)))) for _ in range(int(rng.integers(1, 4)))]
+    total = sum(x.shape[1] for x in parts)
+    dims = None if trial % 3 == 0 else int(rng.integers(1, total + 1))
+    _, wp = RS.paste_pca_normalize({"dimensions": dims}, [x.copy() for x in parts])
+    _, gp = MS.paste_pca_normalize({"dimensions": dims}, [x.copy() for x in parts], device="cpu")
+    if wp.shape != gp.shape or not np.allclose(np.real(wp), gp, rtol=1e-7, atol=1e-9):
+        bad += 1; print("paste_pca_normalize mismatch", trial, dims, np.abs(np.real(wp) - gp).max())
 print("whitening stage mismatches:", bad)

@@ -557,3 +557,26 @@ def test_upstream_checkpoint_conversion_and_carried_whitening(fops, tmp_path, mo
         assert np.array_equal(pickle.load(f)["m"], Lw["retrieval-SfM-120k"]["ms"]["m"])
     with pytest.raises(AssertionError):
         C.load_whitening({"net": src, "whitening": "sfm120k", "multiscale": [1, 0.5]}, ())
+
+
+def test_paste_pca_normalize_stage(fops):
+    """stages/whiten.py:90-118: matrices side by side, upstream's PCA (scalar mean, projection onto the span of the leading
+    eigenvectors of value.T @ value, same width), rows L2-normalised; an empty first matrix is handed back."""
+    from mdir_amd import stages
+    rng = np.random.default_rng(4)
+    a, b = rng.standard_normal((30, 4)), rng.standard_normal((30, 3))
+    meta, out = stages.paste_pca_normalize({"dimensions": None}, [a.copy(), b.copy()], device="cpu")
+    want = np.concatenate([a, b], axis=1)
+    np.testing.assert_allclose(out, want / np.linalg.norm(want, axis=1, keepdims=True), atol=1e-12)
+    assert meta == {}
+    meta, out = stages.paste_pca_normalize({"dimensions": 3}, [a.copy(), b.copy()], device="cpu")
+    v = want - np.mean(want)
+    w, vec = np.linalg.eigh(v.T @ v)
+    vecs = vec[:, np.argsort(w)[-3:]]
+    proj = v @ (vecs @ vecs.T)
+    np.testing.assert_allclose(out, proj / np.linalg.norm(proj, axis=1, keepdims=True), rtol=1e-9, atol=1e-11)
+    assert out.shape == (30, 7) and "pca_compute" in meta["timings"] and np.linalg.matrix_rank(out, tol=1e-8) == 3
+    empty = np.empty((0,))
+    assert stages.paste_pca_normalize({"dimensions": 2}, [empty])[1] is empty
+    with pytest.raises(AssertionError):
+        stages.paste_pca_normalize({"dimensions": 2}, [a, b[:5]])
