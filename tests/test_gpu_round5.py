@@ -658,3 +658,13 @@ def test_whitening_stages_on_the_device(golden):
     _, pca = stages.learn_pca_whitening({}, (X.T.copy(),))
     sign = np.sign(np.sum(pca["P"] * g["P_pca"], axis=1, keepdims=True))
     assert np.abs(pca["P"] * sign - g["P_pca"]).max() <= 1e-7 * np.abs(g["P_pca"]).max()
+    # paste_pca_normalize (stages/whiten.py:90-118) on the device: the numpy statements on the same matrices
+    rng = np.random.default_rng(6)
+    a, b = rng.standard_normal((500, 40)), rng.standard_normal((500, 24))
+    _, out = stages.paste_pca_normalize({"dimensions": 16}, [a.copy(), b.copy()])
+    v = np.concatenate([a, b], axis=1)
+    v = v - np.mean(v)
+    w, vec = np.linalg.eigh(v.T @ v)
+    vecs = vec[:, np.argsort(w)[-16:]]
+    proj = v @ (vecs @ vecs.T)
+    np.testing.assert_allclose(out, proj / np.linalg.norm(proj, axis=1, keepdims=True), rtol=1e-8, atol=1e-10)
