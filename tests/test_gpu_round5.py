@@ -668,3 +668,35 @@ def test_whitening_stages_on_the_device(golden):
     vecs = vec[:, np.argsort(w)[-16:]]
     proj = v @ (vecs @ vecs.T)
     np.testing.assert_allclose(out, proj / np.linalg.norm(proj, axis=1, keepdims=True), rtol=1e-8, atol=1e-10)
+
+
+def test_learn_whitening_moves_the_network_itself(tmp_path, monkeypatch):
+    """cirtorch_format/test.py:92-152 with no device argument (`net.cuda()`, :131): a training set on disk -> the supervised whitening,
+    equal to the run with an explicit device."""
+    from PIL import Image
+    from mdir_amd import cirtorch_format as C
+    from mdir_amd.networks import init_network
+    monkeypatch.setenv("MDIR_AMD_WORKERS", "0")
+    monkeypatch.setenv("CIRTORCH_ROOT", str(tmp_path))
+    rng = np.random.default_rng(3)
+    root = tmp_path / "data" / "train" / "toyset"
+    cids = ["%032x" % i for i in range(24)]
+    for cid in cids:
+        path = C.cid2filename(cid, str(root / "ims"))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        Image.fromarray(rng.integers(0, 255, (200, 260, 3), dtype=np.uint8)).save(path, format="JPEG")
+    import pickle
+    with open(root / "toyset-whiten.pkl", "wb") as f:
+        pickle.dump({"cids": cids, "qidxs": list(range(8)), "pidxs": list(range(8, 16))}, f)
+    torch.manual_seed(2)
+    net = init_network({"architecture": "alexnet", "pooling": "gem", "whitening": False, "pretrained": False})
+    meta = {"architecture": "alexnet", "pooling": "gem", "whitening": False, "mean": net.meta["mean"], "std": net.meta["std"], "outputdim": 256,
+            "local_whitening": False, "regional": False}
+    torch.save({"meta": meta, "state_dict": net.state_dict()}, str(tmp_path / "up.pth"))
+    args = {"net": str(tmp_path / "up.pth"), "whitening": "toyset", "image_size": 224, "multiscale": True}
+    _, a = C.learn_whitening(dict(args), ())
+    _, b = C.learn_whitening(dict(args), (), device=DEV)
+    assert a["P"].shape == (256, 256) and a["P"].dtype == np.float64
+    np.testing.assert_allclose(a["m"], b["m"], rtol=0, atol=1e-9)
+    sign = np.sign(np.sum(a["P"] * b["P"], axis=1, keepdims=True))
+    assert np.abs(a["P"] - b["P"] * sign).max() <= 1e-6 * np.abs(a["P"]).max()

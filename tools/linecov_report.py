@@ -56,6 +56,9 @@ EXPLAINED = [
     ("mdir_amd/trace.py", "except OSError", "the image has libroctx64.so; the branch is the loop's step to the second library name"),
     ("mdir_amd/_lib.py", "subprocess.check_call", "`make` of the library: exercised by __graft_entry__.build() (the driver's build check), not by pytest"),
     ("eval.py", "torch.cuda.set_device(local)", "one process per GPU over RCCL (torchrun on a multi-GPU node): needs more than one GPU; the same function's gloo dry-run branch is tested (test_eval_py_two_processes_print_the_same_numbers)"),
+    ("mdir_amd/sharded.py", "except (RuntimeError, NotImplementedError)", "a collective backend that refuses an uneven all_to_all_single (gloo and RCCL take it); the all-gather form it falls back to is tested through MDIR_AMD_EXCHANGE=allgather"),
+    ("mdir_amd/sharded.py", "ok = 0", "same branch as above"),
+    ("eval.py", "dist.init_process_group(\"nccl\"", "one process per GPU over RCCL (torchrun on a multi-GPU node): needs more than one GPU; the same function's gloo dry-run branch is tested (test_eval_py_two_processes_print_the_same_numbers)"),
     ("mdir_amd/backbones.py", "return mod(x)", "a ResNet downsample module that is not conv + bn (none of the architectures of imageretrievalnet.py:155-164 has one)"),
     ("mdir_amd/sharded.py", "return None", "phase_ms before any rank_queries call on a device"),
 ]
