@@ -9,11 +9,13 @@ axis=0)` (mdir/components/optim/score/cirscore.py:69-70).  Inputs are resident i
 HBM when the timed region starts.  With --gpus N the 1M database is row-sharded
 (strong scaling); see mdir_amd/sharded.py for the exchange.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows ROWS] [--no-cpu-baseline] [--no-secondary]
-                    [--no-pipelined] [--extract-images M] [--profile] [--comm torch|mdx]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows ROWS] [--no-cpu-baseline] [--secondary]
+                    [--extract-images M] [--profile] [--comm torch|mdx|p2p]
 
-`--profile` = the headline loop alone (no CPU baseline, side legs, two-stream leg or extraction): the form
-tools/profile_round.sh runs under rocprofv3, so that the per-kernel averages of the committed profile add up to the step.
+The default run = the headline loop + `cpu_baseline` (with the float64 arbiter of `cpu_path_parity`) + the descriptors/s leg
+(with its own `cpu_baseline` and trunk `roofline`).  `--secondary` appends the side legs of tools/bench_secondary.py.
+`--profile` = the headline loop alone (no CPU baseline, side legs or extraction): the form tools/profile_round.sh runs under
+rocprofv3, so that the per-kernel averages of the committed profile add up to the step.
 
 Prints ONE JSON line on rank 0.
 """
@@ -201,29 +203,78 @@ def verify_ranking(sc, rk):
     return ok_perm, ok_order
 
 
-def side_legs(args, sharded, qvecs, sc, rk, ws, gnd, device, extra):
-    """Side leg of the single-GPU run that launches the headline's similarity kernel with the sort-free evaluation (skipped by
-    --no-pipelined / --profile).  The two-stream leg of rounds 2-4 (ranking of batch k beside the similarity of batch k+1) is
-    gone: it measured +0.2 ... +1 %, and profiles/r05_overlap.md shows why -- the similarity kernel's 16 waves per CU hold every
-    SIMD's whole register file, so the sort's workgroups only become resident when it ends."""
-    from mdir_amd import ops
-    # the same evaluation without materialising a ranking: similarity + rank positions of the labelled
-    # ids (mdx_rank_of) -- what compute_map actually needs; identical mAP (asserted above), reported beside
-    from mdir_amd.ops import _csr
-    lists = [np.concatenate([g["easy"], g["hard"], g["junk"]]) for g in gnd]
-    ids_t, off_t, _ = _csr(lists, device)
-    cnt = torch.zeros(ids_t.numel(), dtype=torch.int64, device=device)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        sharded.index.scores(qvecs, "DN", out=sc)
-        cnt.zero_()
-        ops.rank_count_(cnt, sc, 0, ops.gather_scores(sc, ids_t, off_t), ids_t, off_t)
-    torch.cuda.synchronize()
-    t_pos = (time.perf_counter() - t1) / args.steps
-    extra["sort_free_map_route"] = {"value": round(NQ / t_pos, 2), "unit": "queries/s", "ms_per_step": round(t_pos * 1e3, 4),
-                                    "what": "similarity + rank positions of the %d labelled ids (no full ranking), same mAP"
-                                            % int(ids_t.numel())}
+def f64_arbiter(rows, qvecs, sc, rk, rk_cpu, sc_cpu, gnd, vecs_host=None):
+    """WHICH of the two fp32 orders is right where they differ.  The reference's statement
+    (cirscore.py:69-70) evaluated in float64 -- every dot product of the fp32 descriptors accumulated in float64 (device dgemm,
+    cross-checked against numpy float64 on the host for the disputed rows), ranked descending with ties by ascending id -- is the
+    arbiter between the GPU's k-ordered fp32 fma chain (``sc`` [Q,N], ``rk`` [Q,N]) and the host's BLAS fp32 product + numpy
+    argsort (``sc_cpu`` [N,Q], ``rk_cpu`` [N,Q]).  ``rows`` [N,D] fp32 and ``qvecs`` [D,Q] on the device.  Returns a dict."""
+    from mdir_amd.evaluate import compute_map_and_print
+    device, (nq, n) = rows.device, sc.shape
+    q64 = qvecs.double()
+    s64 = torch.empty((nq, n), dtype=torch.float64, device=device)
+    for a in range(0, n, 131072):
+        b = min(n, a + 131072)
+        s64[:, a:b] = (rows[a:b].double() @ q64).t()
+    rk64 = torch.sort(s64, dim=1, descending=True, stable=True).indices          # ties: ascending id (the build's tie rule)
+    rkc = torch.from_numpy(np.ascontiguousarray(rk_cpu.T)).to(device)
+    out = {"what": "float64 arbiter: the same fp32 descriptors multiplied with float64 accumulation and ranked (ties by ascending id); "
+                   "counts of ranking slots / labelled rows where each fp32 path names the row the float64 order names"}
+    disputed = rk != rkc
+    g_ok, c_ok = rk == rk64, rkc == rk64
+    nd = int(disputed.sum())
+    out["slots_where_gpu_and_cpu_differ"] = nd
+    out["of_slots"] = int(rk.numel())
+    out["gpu_order_agrees_with_f64"] = int((g_ok & disputed).sum())
+    out["cpu_order_agrees_with_f64"] = int((c_ok & disputed).sum())
+    out["neither_agrees_with_f64"] = nd - int(((g_ok | c_ok) & disputed).sum())
+    out["whole_ranking_slots_equal_to_f64"] = {"gpu": int(g_ok.sum()), "cpu": int(c_ok.sum())}
+    out["top100_slots_equal_to_f64"] = {"gpu": int(g_ok[:, :100].sum()), "cpu": int(c_ok[:, :100].sum()), "of": 100 * nq}
+    # how far apart, in float64, are two rows that an fp32 path puts in the other order than float64 does
+    def worst_gap(order, ok):
+        bad = torch.nonzero(~ok)
+        if not len(bad):
+            return 0.0
+        qq, ss = bad[:, 0], bad[:, 1]
+        return float((s64[qq, order[qq, ss]] - s64[qq, rk64[qq, ss]]).abs().max())
+    out["gpu_max_f64_gap_between_misordered_rows"] = worst_gap(rk, g_ok)
+    out["cpu_max_f64_gap_between_misordered_rows"] = worst_gap(rkc, c_ok)
+    out["gpu_max_abs_score_error_vs_f64"] = float((sc.double() - s64).abs().max())
+    scc = torch.from_numpy(np.ascontiguousarray(sc_cpu.T)).to(device)
+    out["cpu_max_abs_score_error_vs_f64"] = float((scc.double() - s64).abs().max())
+    del scc, g_ok, c_ok
+    # labelled rows (all that mAP depends on): their positions under the three orders
+    ar = torch.arange(n, device=device)
+    inv = torch.empty(n, dtype=torch.int64, device=device)
+    moved = g_moved_ok = c_moved_ok = g_lab_ok = c_lab_ok = total = 0
+    for q in range(nq):
+        ids = torch.from_numpy(np.concatenate([gnd[q]["easy"], gnd[q]["hard"], gnd[q]["junk"]]).astype(np.int64)).to(device)
+        pos = []
+        for order in (rk, rkc, rk64):
+            inv[order[q]] = ar
+            pos.append(inv[ids].clone())
+        pg, pc, p6 = pos
+        mv = pg != pc
+        moved += int(mv.sum())
+        g_moved_ok += int(((pg == p6) & mv).sum())
+        c_moved_ok += int(((pc == p6) & mv).sum())
+        g_lab_ok += int((pg == p6).sum())
+        c_lab_ok += int((pc == p6).sum())
+        total += len(ids)
+    out["labelled_rows"] = {"of": total, "ranked_differently_by_gpu_and_cpu": moved, "of_those_gpu_position_equals_f64": g_moved_ok,
+                            "of_those_cpu_position_equals_f64": c_moved_ok, "gpu_position_equals_f64": g_lab_ok, "cpu_position_equals_f64": c_lab_ok}
+    with contextlib.redirect_stdout(sys.stderr):
+        avg64, _ = compute_map_and_print("roxford5k", rk64.t(), gnd)
+    out["map_medium_f64_order"] = avg64["map_medium"]
+    if vecs_host is not None and nd:
+        # the device's float64 values of (a sample of) the disputed rows against numpy float64 on the HOST: the arbiter's own check
+        where = torch.nonzero(disputed)[:4000].cpu().numpy()
+        qh = qvecs.cpu().numpy().astype(np.float64)
+        ids_g = rk[where[:, 0], where[:, 1]].cpu().numpy()
+        host = np.einsum("dk,dk->k", vecs_host[:, ids_g].astype(np.float64), qh[:, where[:, 0]])
+        dev = s64[torch.from_numpy(where[:, 0]).to(device), torch.from_numpy(ids_g).to(device)].cpu().numpy()
+        out["host_f64_crosscheck"] = {"rows": int(len(where)), "max_abs_diff_device_f64_vs_numpy_f64": float(np.abs(host - dev).max())}
+    return out
 
 
 def launch_ranks(n):
@@ -254,18 +305,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", dest="n", type=int, default=N_ROXFORD + N_DISTRACTORS, help="database rows (default 1 004 993)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] side legs")
+    ap.add_argument("--secondary", action="store_true",
+                    help="also run the side legs of tools/bench_secondary.py (configs[1] / configs[4] shapes, split-precision modes, top-100, "
+                         "one evaluation, whitening learning, CLAHE, the sort-free route) and append them to the line")
+    ap.add_argument("--no-secondary", action="store_true", help="(accepted for older command lines: the side legs are off by default)")
     ap.add_argument("--extract-images", type=int, default=40,
                     help="images PER SIZE (16 sizes) of the (untimed) descriptors/sec leg: ResNet101-GeM, 3 scales + whitening; 0 = skip")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the sort-free evaluation leg (name kept from the rounds that also had a "
-                    "two-stream leg here)")
-    ap.add_argument("--profile", action="store_true", help="the headline loop only: --no-cpu-baseline --no-secondary --no-pipelined --extract-images 0")
+    ap.add_argument("--no-pipelined", action="store_true", help="(accepted for older command lines; no effect)")
+    ap.add_argument("--profile", action="store_true", help="the headline loop only: --no-cpu-baseline --extract-images 0")
     ap.add_argument("--comm", choices=("torch", "mdx"), default=None,
                     help="N > 1: the exchange of partial scores through torch.distributed (default) or through the C-ABI communicator "
                          "(mdx_comm_* / mdx_exchange_scores over RCCL; same as MDIR_AMD_COMM=mdx)")
     args = ap.parse_args()
     if args.profile:
-        args.no_cpu_baseline = args.no_secondary = args.no_pipelined = True
+        args.no_cpu_baseline, args.secondary = True, False
         args.extract_images = 0
     if args.comm:
         os.environ["MDIR_AMD_COMM"] = args.comm
@@ -298,6 +351,9 @@ def main():
             dist.init_process_group("gloo", timeout=limit)
         else:
             dist.init_process_group("nccl", device_id=device, timeout=limit)
+        # the ranks that wait while rank 0 times the CPU reference do so on a gloo side group with its own generous limit: the
+        # baseline must not be able to cost the measured line through the 900 s limit of the data-path group
+        wait_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
         # communicator set-up (lazy peer connections) is not a step: ShardedIndex runs a small all-to-all when it is
         # built and all ranks agree there (all-reduce) on the exchange form -- see mdir_amd/sharded.py
 
@@ -399,6 +455,12 @@ def main():
                     "kernel_ms": round(kernel_ms, 4), "algorithmic_flops": flops, "algorithmic_bytes": algo_bytes,
                     "hbm_GBps_at_algorithmic_bytes": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 1),
                     "hbm_frac_of_8TBps": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        if prof.get("scores_kernel_trace_avg_us"):
+            # the second reading of the same kernel: its average duration in the committed rocprofv3 kernel trace (same command
+            # under the profiler, same sources by hash).  HIP events in this run and the trace of that run sit side by side.
+            us = prof["scores_kernel_trace_avg_us"]
+            roofline["rocprof_kernel_avg_us"] = us
+            roofline["frac_rocprof"] = round(flops / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
         if prof.get("scores_kernel_sustained_clock_ghz"):
             # from the same committed profile (SQ counter pass), not measured in this run: the kernel is power-limited, the peak
             # figure assumes 2.4 GHz (profiles/r02_scores_stamps.md)
@@ -425,12 +487,12 @@ def main():
             "bound": "hbm", "achieved": round(rank_algo / (rank_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(rank_algo / (rank_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": rank_traffic, "traffic_source": rank_src,
             "kernel_ms": round(rank_ms, 4), "algorithmic_bytes": rank_algo,
+            "frac_rocprof": (round(rank_algo / (prof["ranking_trace_sum_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+                             if prof.get("ranking_trace_sum_us") and rank_traffic else None),
             "traffic_over_algorithmic": round(rank_traffic / rank_algo, 2) if rank_traffic else None,
             "hbm_GBps_at_real_traffic": round(rank_traffic / (rank_ms * 1e-3) / 1e9, 1) if rank_traffic else None,
             "what": "12 launches per ranking; the 4-pass form moves ~4.8x the bytes of an ideal one-pass argsort and streams them at the "
                     "rate HBM gives a read+write mix (DESIGN section 4): only fewer passes would help, and the MSD / one-sweep forms measured slower"}
-        if not args.no_pipelined:
-            side_legs(args, sharded, qvecs, sc, rk, ws, gnd, device, extra)
     else:
         rk_mine, sc_mine, (qlo, qhi) = keep["rk"], keep["sc"], keep["q"]
         ok = torch.tensor([1], device="cpu" if dryrun else device)
@@ -517,7 +579,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             vecs_host = rows.t().contiguous().cpu().numpy()       # reference layout [D,N]
-            _, rk_cpu, t_dot, t_sort = cpu_baseline(vecs_host, qvecs.cpu().numpy())
+            sc_cpu, rk_cpu, t_dot, t_sort = cpu_baseline(vecs_host, qvecs.cpu().numpy())
             import multiprocessing
             extra["cpu_baseline"] = {
                 "value": round(NQ / (t_dot + t_sort), 3), "unit": "queries/s",
@@ -574,7 +636,19 @@ def main():
                         "ties by ascending id) may order rows differently only inside runs of scores closer than the summation-order "
                         "bound 2e-6 (5x tighter than the 1e-5 score tolerance); asserted above for every such row.  mAP then differs by what such swaps of labelled rows move (compare map_medium "
                         "with map_medium_cpu); the printed 2-decimal mAP is the same"}
-            del vecs_host, rk_cpu
+            # ... and WHICH order is right where the two differ: the float64 arbiter
+            try:
+                arb = f64_arbiter(rows, qvecs, sc, rk, rk_cpu, sc_cpu, gnd, vecs_host)
+                extra["cpu_path_parity"].update({
+                    "gpu_order_agrees_with_f64": arb["gpu_order_agrees_with_f64"], "cpu_order_agrees_with_f64": arb["cpu_order_agrees_with_f64"],
+                    "map_medium_f64_order": arb["map_medium_f64_order"], "f64_arbiter": arb})
+                assert arb["gpu_max_abs_score_error_vs_f64"] <= SUM_ORDER_TOL and arb["gpu_max_f64_gap_between_misordered_rows"] <= SUM_ORDER_TOL, \
+                    "the GPU chain is further from the float64 order than the summation-order bound"
+            except AssertionError:
+                raise
+            except Exception as exc:
+                extra["cpu_path_parity"]["f64_arbiter"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            del vecs_host, rk_cpu, sc_cpu
         except Exception as exc:          # the reported baseline must not cost the measured line
             extra["cpu_baseline"] = {"value": None, "unit": "queries/s", "error": "%s: %s" % (type(exc).__name__, exc)}
 
@@ -612,178 +686,17 @@ def main():
                 del vecs_host, rk_cpu
             except Exception as exc:          # the reported baseline must not cost the measured line
                 extra["cpu_baseline"] = {"value": None, "unit": "queries/s", "error": "%s: %s" % (type(exc).__name__, exc)}
-        dist.barrier()
+        dist.barrier(group=wait_group)
 
-    if rank == 0 and world == 1 and not args.no_secondary:
-        # BASELINE.json's other single-GPU configurations, timed beside the headline (side legs: they cannot cost the
-        # measured line): configs[1] rOxford5k alone (70 x 4 993, latency-bound) and configs[4]'s fp16 descriptors on the
-        # fp16 MFMA (same 1 M x 2048 problem, shard stored as fp16: HBM-bound)
+    if rank == 0 and world == 1 and args.secondary:
+        # BASELINE.json's other single-GPU configurations and the side legs of earlier rounds (tools/bench_secondary.py): NOT part
+        # of the default run since round 6 -- they cannot cost the measured line, and they no longer cost the driver's minutes
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_secondary
         try:
-            def timed(fn, reps=20):
-                for _ in range(3):
-                    fn()
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                for _ in range(reps):
-                    fn()
-                b.record()
-                torch.cuda.synchronize()
-                return a.elapsed_time(b) / reps
-            sec = {}
-            small = ops.DescriptorIndex(rows[:N_ROXFORD].contiguous(), "ND")
-            sc5 = torch.empty((NQ, N_ROXFORD), dtype=torch.float32, device=device)
-            rk5 = torch.empty((NQ, N_ROXFORD), dtype=torch.int64, device=device)
-            ws5 = torch.empty(ops.rank_workspace_bytes(N_ROXFORD, NQ), dtype=torch.uint8, device=device)
-            t_s, t_r = timed(lambda: small.scores(qvecs, "DN", out=sc5)), timed(lambda: ops.rank_full(sc5, out=rk5, workspace=ws5))
-            sec["configs1_roxford5k"] = {"workload": "N=%d Q=%d D=%d fp32, similarity + exact full ranking" % (N_ROXFORD, NQ, DIM),
-                                         "scores_us": round(1e3 * t_s, 1), "rank_us": round(1e3 * t_r, 1),
-                                         "queries_per_s": round(NQ / ((t_s + t_r) * 1e-3), 1), "bound": "launch latency"}
-            small.close()
-            # the serving form of configs[2]: the 100 best rows per query instead of the full ranking (mdx_topk, exact)
-            t_k = timed(lambda: ops.topk(sc, 100, workspace=ws), reps=10)
-            ids100, _ = ops.topk(sc, 100, workspace=ws)
-            assert bool((ids100 == rk[:, :100]).all())                   # = the head of the full ranking
-            kms = extra.get("roofline", {}).get("kernel_ms") or 0.0
-            sec["configs2_top100"] = {"workload": "N=%d Q=%d: exact top-100 per query instead of the full ranking" % (n_total, NQ),
-                                      "topk_ms": round(t_k, 4), "queries_per_s_with_the_fp32_similarity": round(NQ / ((kms + t_k) * 1e-3), 1) if kms else None}
-            # one evaluation multiplies its database once: the same exact product on the row-major [N,D] matrix read where it lies
-            # (mdx_scores_rowmajor: no index, no second 8 GB), next to what building an index for one product costs
-            sc_rm = torch.empty_like(sc)
-            t_rm = timed(lambda: ops.scores_rowmajor(rows, qvecs, "DN", out=sc_rm), reps=10)
-
-            def build_multiply():
-                ix1 = ops.DescriptorIndex(rows, "ND")
-                ix1.scores(qvecs, "DN", out=sc_rm)
-                ix1.close()
-            t_bm = timed(build_multiply, reps=5)
-            sec["configs2_one_evaluation"] = {
-                "workload": "N=%d Q=%d D=%d fp32: the exact similarity of ONE evaluation, descriptors row-major on the device" % (n_total, NQ, DIM),
-                "in_place_ms": round(t_rm, 4), "index_build_plus_multiply_ms": round(t_bm, 4), "resident_index_ms": kms or None,
-                "bit_identical_to_the_index_route": bool(torch.equal(sc_rm, sc)),
-                "what": "mdx_scores_rowmajor (the kernels of the headline on the caller's matrix) against mdx_index_create_in + mdx_scores + "
-                        "destroy with the tiles in PyTorch's pool (own hipMalloc + hipFree of the 8 GB shard: ~190 ms per pair)"}
-            assert sec["configs2_one_evaluation"]["bit_identical_to_the_index_route"]
-
-            def wall(fn, reps=3):
-                best = None
-                for _ in range(reps):
-                    torch.cuda.synchronize()
-                    t_w = time.perf_counter()
-                    with contextlib.redirect_stdout(sys.stderr):
-                        out_w = fn()
-                    torch.cuda.synchronize()
-                    t_w = time.perf_counter() - t_w
-                    best = t_w if best is None or t_w < best else best
-                return out_w, best * 1e3
-            # the whole evaluation of cirscore.py:65-71 on resident descriptors, wall clock: product (in place) + mAP
-            (avg_d, _), t_default = wall(lambda: compute_map_and_print_from_scores("roxford5k", ops.scores_rowmajor(rows, qvecs, "DN", out=sc_rm), gnd))
-            (avg_l, _), t_literal = wall(lambda: compute_map_and_print("roxford5k", ops.rank_full(ops.scores_rowmajor(rows, qvecs, "DN", out=sc_rm), out=rk, workspace=ws).t(), gnd))
-            assert avg_d["map_medium"] == avg_l["map_medium"] == extra["map_medium"]
-            sec["configs2_one_evaluation"].update({
-                "evaluation_ms_default_route": round(t_default, 3), "evaluation_ms_literal_route": round(t_literal, 3),
-                "routes": "default = product + rank positions of the labelled ids (mdx_rank_of) + host AP; literal = product + full argsort + "
-                          "positions inside the ranking (mdx_rank_positions) + host AP; same mAP as the headline's"})
-            del sc_rm
-            # the LABELLED split-precision modes on the SAME fp32 shard (not the headline, not the parity contract -- timed beside it
-            # with what they do to the result): MDX_F32_SPLIT3 = three bf16 pieces per operand, six products on the bf16 MFMA;
-            # MDX_F32_SPLIT2 = block floating point, two fp16 pieces with a scaled residual, three products on the fp16 MFMA
-            sc3 = torch.empty_like(sc)
-            for mode, what, kern in (
-                    ("split3", "MDX_F32_SPLIT3: x = h + m + l in bf16, products hh+hm+mh+hl+lh+mm on v_mfma_f32_16x16x32_bf16, fp32 accumulation",
-                     "mdx::scores_split3_kernel<QT=5,R=2,NSTAGE=3,CW=8> (8 MFMA waves splitting in registers + 4 LDS-DMA loader waves)"),
-                    ("split2", "MDX_F32_SPLIT2: block floating point, X = h + m / 2^11 in fp16 (scaled residual), products hh + (hm+mh) / 2^11 on "
-                               "v_mfma_f32_16x16x32_f16, cross terms in their own accumulator",
-                     "mdx::scores_split2_kernel<QT=5,R=2,NSTAGE=3,CW=8> (same ring; half the matrix work of split3)")):
-                t_3 = timed(lambda: sharded.index.scores(qvecs, "DN", out=sc3, compute=mode), reps=10)
-                b3 = 4.0 * n_total * DIM + 4.0 * NQ * n_total + (6.0 if mode == "split3" else 4.0) * 80 * DIM
-                d3 = (sc3 - sc).abs()
-                ids3, _ = ops.topk(sc3, 100, workspace=ws)
-                with contextlib.redirect_stdout(sys.stderr):
-                    avg3, _ = compute_map_and_print_from_scores("roxford5k", sc3, gnd)
-                diff3 = torch.nonzero(ids3 != rk[:, :100])
-                gap3 = 0.0
-                if len(diff3):          # where the two top-100 lists name other rows: how far apart are those rows' EXACT scores?
-                    qq = diff3[:, 0]
-                    gap3 = float((sc[qq, ids3[qq, diff3[:, 1]]] - sc[qq, rk[qq, diff3[:, 1]]]).abs().max())
-                assert float(d3.max()) <= SUM_ORDER_TOL and gap3 <= SUM_ORDER_TOL, (mode, float(d3.max()), gap3)
-                sec[mode] = {
-                    "workload": "N=%d Q=%d D=%d, the SAME fp32 shard, %s (labelled second mode; the exact chain stays the headline)" % (n_total, NQ, DIM, what),
-                    "scores_ms": round(t_3, 4), "exact_chain_scores_ms": kms or None,
-                    "roofline": {"kernel": kern, "bound": "hbm", "achieved": round(b3 / (t_3 * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": round(b3 / (t_3 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": b3, "traffic": None,
-                                 "chain_equivalent_TFLOPs": round(2.0 * NQ * n_total * DIM / (t_3 * 1e-3) / 1e12, 1),
-                                 "what": ("power-bound with real operands (all-zero operands: the stream-only time of the same kernel)" if mode == "split3"
-                                          else "at the ring's stream-only time: half of split3's matrix work fits under the stream") + ", profiles/r04_split3.md"},
-                    "queries_per_s_with_the_fp32_ranking": round(NQ / ((t_3 + extra.get("rank_ms_per_step", 0.0)) * 1e-3), 1),
-                    "max_abs_diff_vs_exact_chain": float(d3.max()), "mean_abs_diff_vs_exact_chain": float(d3.mean()), "asserted_bound": SUM_ORDER_TOL,
-                    "map_medium_" + mode: avg3["map_medium"], "map_medium_exact": extra.get("map_medium"),
-                    "top100_slot_agreement_with_exact": round(1.0 - len(diff3) / ids3.numel(), 6),
-                    "top100_max_exact_score_gap_where_ids_differ": gap3,
-                    "top1_agreement_with_exact": round(float((ids3[:, 0] == rk[:, 0]).float().mean()), 6)}
-            del sc3, d3
-            half = ops.DescriptorIndex(rows, "ND", storage="f16")
-            t_h = timed(lambda: half.scores(qvecs, "DN", out=sc), reps=10)
-            hb = half.device_bytes + 4 * NQ * n_total
-            sec["configs4_fp16_shard"] = {"workload": "N=%d Q=%d D=%d, shard and queries stored as fp16, v_mfma_f32_16x16x32_f16, fp32 accumulation"
-                                                      % (n_total, NQ, DIM), "scores_ms": round(t_h, 4),
-                                          "roofline": {"bound": "hbm", "achieved": round(hb / (t_h * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                                       "frac": round(hb / (t_h * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes": float(hb)},
-                                          "queries_per_s_with_the_fp32_ranking": round(NQ / ((t_h + extra.get("rank_ms_per_step", 0.0)) * 1e-3), 1),
-                                          "contract": "scores within 2e-3 of fp32 (input rounding), tests/test_gpu_f16.py"}
-            # what the fp16 shard does to the RESULT at this size (sc now holds the fp16-shard scores, rk the fp32 ranking)
-            with contextlib.redirect_stdout(sys.stderr):
-                avg16, _ = compute_map_and_print_from_scores("roxford5k", sc, gnd)
-            ids16, _ = ops.topk(sc, 100, workspace=ws)
-            sec["configs4_fp16_shard"].update({
-                "map_medium_fp16": avg16["map_medium"], "map_medium_fp32": extra.get("map_medium"),
-                "top100_slot_agreement_with_fp32": round(float((ids16 == rk[:, :100]).float().mean()), 6),
-                "top1_agreement_with_fp32": round(float((ids16[:, 0] == rk[:, 0]).float().mean()), 6)})
-            half.close()
-            # configs[4]'s own shape: 247tokyo1k, query == database (1 125 x 1 125), VGG16 descriptors (512-d) stored as fp16
-            g4 = torch.Generator(device=device)
-            g4.manual_seed(4)
-            tk = torch.randn((1125, 512), generator=g4, device=device)
-            tk /= tk.norm(dim=1, keepdim=True)
-            tix = ops.DescriptorIndex(tk, "ND", storage="f16")
-            tsc = torch.empty((1125, 1125), dtype=torch.float32, device=device)
-            trk = torch.empty((1125, 1125), dtype=torch.int64, device=device)
-            tws = torch.empty(ops.rank_workspace_bytes(1125, 1125), dtype=torch.uint8, device=device)
-            tq = tk.t().contiguous()
-            t_s, t_r = timed(lambda: tix.scores(tq, "DN", out=tsc)), timed(lambda: ops.rank_full(tsc, out=trk, workspace=tws))
-            assert bool((trk[:, 0] == torch.arange(1125, device=device)).all())          # every image retrieves itself first
-            sec["configs4_247tokyo1k_shape"] = {"workload": "N=Q=1125 D=512, fp16 shard, query == database, similarity + exact full ranking",
-                                                "scores_us": round(1e3 * t_s, 1), "rank_us": round(1e3 * t_r, 1),
-                                                "queries_per_s": round(1125 / ((t_s + t_r) * 1e-3), 1), "bound": "launch latency"}
-            tix.close()
-            # rows f3 / f4 of SURVEY.md section 8: the float64 products of whitening learning (whiten.py:22,42,45,46) at
-            # D = 2048 on 20 000 descriptors, and the CLAHE networks' input conversion on a batch of four 1024 x 768 images
-            g5 = torch.Generator(device=device)
-            g5.manual_seed(5)
-            A64 = torch.randn((DIM, 20000), generator=g5, device=device, dtype=torch.float64)
-            P64 = torch.randn((DIM, DIM), generator=g5, device=device, dtype=torch.float64)
-            m64 = torch.randn(DIM, generator=g5, device=device, dtype=torch.float64)
-            t_g, t_p = timed(lambda: ops.gram_f64(A64), reps=5), timed(lambda: ops.project_f64(P64, A64, m64), reps=5)
-            tri = (DIM // 128) * (DIM // 128 + 1) // 2
-            fl_g, fl_p = 2.0 * 20000 * 128 * 128 * tri, 2.0 * DIM * DIM * 20000
-            sec["whitening_learning_f64"] = {
-                "workload": "D=%d, n=20000 float64: mdx_gram_f64 (np.dot(df, df.T)) and mdx_project_f64 (np.dot(P, X-m))" % DIM,
-                "gram_ms": round(t_g, 3), "project_ms": round(t_p, 3),
-                "roofline_gram": {"bound": "mfma", "achieved": round(fl_g / t_g / 1e9, 2), "peak": 78.6, "unit": "TFLOP/s",
-                                  "frac": round(fl_g / t_g / 1e9 / 78.6, 4), "what": "flops executed: upper-triangle tiles only"},
-                "roofline_project": {"bound": "mfma", "achieved": round(fl_p / t_p / 1e9, 2), "peak": 78.6, "unit": "TFLOP/s",
-                                     "frac": round(fl_p / t_p / 1e9 / 78.6, 4)}}
-            del A64, P64
-            u8 = torch.randint(0, 256, (4, 768, 1024, 3), generator=g5, device=device, dtype=torch.uint8)
-            mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
-            t_c, t_n = timed(lambda: ops.clahe_u8_to_chw(u8, 4, 8, mean, std)), timed(lambda: ops.u8_to_chw(u8, mean, std))
-            cb = 4 * 768 * 1024 * (3 + 1 + 8 + 1 + 8 + 1 + 12)      # rgb in; L8 and chroma (a, b) written, then read; L8' and fp32 CHW out
-            sec["clahe_preprocess"] = {
-                "workload": "4 x 1024x768 uint8 RGB -> CLAHE (clip 4, 8x8 tiles) on the Lab lightness -> normalised fp32 CHW "
-                            "(parity unpinned: OpenCV's algorithm restated)",
-                "ms_per_batch": round(t_c, 4), "plain_u8_to_chw_ms_per_batch": round(t_n, 4),
-                "roofline": {"bound": "hbm", "achieved": round(cb / (t_c * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(cb / (t_c * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes": float(cb)}}
-            extra["secondary_configs"] = sec
+            bench_secondary.sort_free_leg(args, sharded, qvecs, sc, gnd, device, extra, NQ)
+            extra["secondary_configs"] = bench_secondary.secondary_configs(args, ops, sharded, rows, qvecs, sc, rk, ws, gnd, device, extra,
+                                                                           n_total, NQ, DIM)
         except Exception as exc:
             extra["secondary_configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
@@ -793,7 +706,7 @@ def main():
         # and the resident single-shape figure of round 1 are reported beside it.
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import types
-        from bench_extract import measure, measure_list
+        from bench_extract import cpu_reference_loop, measure, measure_list
         ex, err = None, None
         try:
             with contextlib.redirect_stdout(sys.stderr):
@@ -819,6 +732,12 @@ def main():
                                               roofline_tail=rs["roofline_tail"],
                                               resident_single_shape_descriptors_per_s=rs["value"],
                                               resident_single_shape_backbone_ms_per_image=rs["backbone_ms_per_image"])
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # the reference-style extraction loop on this box's host cores (bounded sample; baseline only)
+                try:
+                    extra["descriptors_per_s"]["cpu_baseline"] = cpu_reference_loop("resnet101", images=8)
+                except Exception as exc:
+                    extra["descriptors_per_s"]["cpu_baseline"] = {"value": None, "unit": "descriptors/s", "error": "%s: %s" % (type(exc).__name__, exc)}
         else:
             extra["descriptors_per_s"] = {"value": None, "unit": "descriptors/s", "n_gpus": world,
                                           "error": err or "the extraction leg failed on another rank"}

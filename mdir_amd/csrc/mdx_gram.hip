@@ -35,9 +35,6 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4u __attribute__((ext_vector_type(4), aligned(8)));    // one 32-byte access at 8-byte alignment
 
 constexpr int GK = 16;
-#ifndef MDX_GRAM_ABL
-#define MDX_GRAM_ABL 0                  // timing switch of tools/gram_ablate.hip (5: no loads inside the loop); 0 = the product
-#endif
 
 // [rows, cols] -> [cols, rows], optionally subtracting center[row] (the Gram form's centring)
 __global__ __launch_bounds__(256) void transpose_f64_kernel(const double *__restrict__ src, int64_t rows, int64_t cols,
@@ -230,9 +227,6 @@ __device__ __forceinline__ LcTile lc_tile_of(unsigned id, unsigned total, int T_
 {
     const unsigned per = total / 8, rem = total % 8, x = id % 8, k = id / 8;
     int64_t L = (int64_t)x * per + (x < rem ? x : rem) + k;            // position in the tile sequence
-#ifdef MDX_GRAM_PLAIN_MAP              // tools/gram_ablate.hip: workgroup id = position (A/B of the XCD-contiguous order)
-    L = id;
-#endif
     LcTile t;
     if (SYM) {
         const int tri = T_rows * (T_rows + 1) / 2;
@@ -298,16 +292,11 @@ __global__ __launch_bounds__((4 + LC_LW) * 64, LC_WG_PER_CU) void gemm_f64_lc_ke
             if (c < nsteps) issue(c);
         for (int c = 0; c < nsteps; ++c) {
             const int younger = (nsteps - 1 - c) < (NSTAGE - 2) ? (nsteps - 1 - c) : (NSTAGE - 2);     // stages issued after stage c
-#if MDX_GRAM_ABL == 5
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // timing switch: only the first stages are ever loaded
-#endif
             if (NSTAGE >= 4 && younger >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 4 ? 2 * PER_LOADER : 0) : "memory");
             else if (NSTAGE >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 3 ? PER_LOADER : 0) : "memory");
             else                   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                               // B_c: stage c has landed, stage c-1 is read
-#if MDX_GRAM_ABL != 5
             if (c + NSTAGE - 1 < nsteps) issue(c + NSTAGE - 1);
-#endif
         }
         return;
     }

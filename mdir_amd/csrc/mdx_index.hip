@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void retile_block_kernel(const float *__restri
 // Loader/consumer kernel (4 MFMA waves + 4 LDS-DMA loader waves), chunks of 2 tiles along k,
 // ring of 3 stages.  R = 2 row tiles per consumer (128-row workgroups, (QT+8)*6 KiB of LDS)
 // for shards of >= 32 768 rows; R = 1 (64-row workgroups) below, so that small shards still
-// spread over the CUs -- measured crossover, tools/scores_ablate.hip.
+// spread over the CUs -- measured crossover (round 2; the harness is in the history at commit 47a9fe2).
 constexpr int LC_KC = 2, LC_NSTAGE = 3;
 #ifndef MDX_SCORES_PIPE_DEFAULT
 #define MDX_SCORES_PIPE_DEFAULT 1      // profiles/r05_scores_schedule.md: -1.0 ... -1.2 % (bit-equal); MDX_SCORES_PIPE=0 keeps the round-4 schedule
@@ -157,31 +157,48 @@ static int lds_opt_in(const void *kern, int lds, bool *done)
     return MDX_OK;
 }
 
+// where a launch puts its scores: rows == nullptr: the plain [nq, n] matrix `out`; else query q's run goes to rows[q] + col0
+// (device array of nq row pointers: mdx_scores_p2p)
+struct Route { float *const *rows; int64_t col0; };
+
 template <int QT, int R, typename MM, int QR = 0, bool RM = false>
 static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_t n, int64_t RT,
-                            int KB, int nq_valid, hipStream_t s, int passes = 1, int64_t ld = 0)
+                            int KB, int nq_valid, hipStream_t s, int passes = 1, int64_t ld = 0, Route route = Route{nullptr, 0})
 {
     constexpr int lds = LC_NSTAGE * (QT + QR + 4 * R) * LC_KC * 1024;
     const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
+    if constexpr (MM::STEPS == 4 && !RM) {
+        if (route.rows) {           // routed epilogue (the shipped schedule of each shape: PIPE for 128-row workgroups)
+            auto kr = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, MM, QR, 4, false, R == 2, 4, true>;
+            static bool opted_r[64];
+            int rcr = lds_opt_in((const void *)kr, lds, opted_r);
+            if (rcr != MDX_OK) return rcr;
+            hipLaunchKernelGGL(kr, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid, ld, route.rows,
+                               route.col0);
+            return MDX_OK;
+        }
+    }
+    if (route.rows) {
+        set_error("routed scores need an fp32 tiled shard");
+        return MDX_ERR_INVALID;
+    }
     if constexpr (MM::STEPS == 4 && !RM && R == 2) {
         // the pipelined consumer (PIPE): MDX_SCORES_PIPE=0/1 picks the form per launch (A/B in one process: tools/chain_power_probe.py)
         const char *e = getenv("MDX_SCORES_PIPE");
         if (e ? e[0] == '1' : MDX_SCORES_PIPE_DEFAULT) {
-            auto kp = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR, 4, RM, true>;
+            auto kp = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, MM, QR, 4, RM, true>;
             static bool opted_p[64];
             int rcp = lds_opt_in((const void *)kp, lds, opted_p);
             if (rcp != MDX_OK) return rcp;
-            hipLaunchKernelGGL(kp, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
-                               (unsigned long long *)nullptr, ld);
+            hipLaunchKernelGGL(kp, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid, ld);
             return MDX_OK;
         }
     }
-    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, false, MM, QR, 4, RM>;   // 2 = non-temporal database stream
+    auto kern = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, MM, QR, 4, RM>;   // 2 = non-temporal database stream
     static bool opted[64];
     int rc = lds_opt_in((const void *)kern, lds, opted);
     if (rc != MDX_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid,
-                       (unsigned long long *)nullptr, ld);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid, ld);
     return MDX_OK;
 }
 
@@ -211,11 +228,11 @@ static int launch_f16_stream(const f32x4 *db, const f32x4 *qt, float *out, int64
 // mode bit0: R = 2 (else 1), bit1: fp16 shard
 template <int QT>
 static int launch_qt(int mode, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT,
-                     int KB, int nq_valid, hipStream_t s, int passes = 1)
+                     int KB, int nq_valid, hipStream_t s, int passes = 1, Route route = Route{nullptr, 0})
 {
     switch (mode) {
-        case 0: return launch_scores_lc<QT, 1, MmaF32>(db, q, out, n, RT, KB, nq_valid, s, passes);
-        case 1: return launch_scores_lc<QT, 2, MmaF32>(db, q, out, n, RT, KB, nq_valid, s, passes);
+        case 0: return launch_scores_lc<QT, 1, MmaF32>(db, q, out, n, RT, KB, nq_valid, s, passes, 0, route);
+        case 1: return launch_scores_lc<QT, 2, MmaF32>(db, q, out, n, RT, KB, nq_valid, s, passes, 0, route);
         case 2:
             if (f16_streams(KB)) return launch_f16_stream<QT, 1>(db, q, out, n, RT, KB, nq_valid, s, passes);
             return launch_scores_lc<QT, 1, MmaF16>(db, q, out, n, RT, KB, nq_valid, s, passes);
@@ -228,31 +245,31 @@ static int launch_qt(int mode, const f32x4 *db, const f32x4 *q, float *out, int6
 // `qt` query tiles of which the last holds <= 8 queries: qt-1 full tiles on the 16x16x4 MFMA + the leftover
 // tile on v_mfma_f32_4x4x1 (fp32 shards with 128-row workgroups)
 static int dispatch_leftover(int qt, const f32x4 *db, const f32x4 *q, float *out, int64_t n, int64_t RT, int KB,
-                             int nq_valid, hipStream_t s)
+                             int nq_valid, hipStream_t s, Route route = Route{nullptr, 0})
 {
     switch (qt) {
-        case 2: return launch_scores_lc<1, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
-        case 3: return launch_scores_lc<2, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
-        case 4: return launch_scores_lc<3, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
-        case 5: return launch_scores_lc<4, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
-        case 6: return launch_scores_lc<5, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
-        case 7: return launch_scores_lc<6, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
-        default: return launch_scores_lc<7, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s);
+        case 2: return launch_scores_lc<1, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s, 1, 0, route);
+        case 3: return launch_scores_lc<2, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s, 1, 0, route);
+        case 4: return launch_scores_lc<3, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s, 1, 0, route);
+        case 5: return launch_scores_lc<4, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s, 1, 0, route);
+        case 6: return launch_scores_lc<5, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s, 1, 0, route);
+        case 7: return launch_scores_lc<6, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s, 1, 0, route);
+        default: return launch_scores_lc<7, 2, MmaF32, 1>(db, q, out, n, RT, KB, nq_valid, s, 1, 0, route);
     }
 }
 
 static int dispatch_qt(int qt, int mode, const f32x4 *db, const f32x4 *q, float *out, int64_t n,
-                       int64_t RT, int KB, int nq_valid, hipStream_t s)
+                       int64_t RT, int KB, int nq_valid, hipStream_t s, Route route = Route{nullptr, 0})
 {
     switch (qt) {
-        case 1: return launch_qt<1>(mode, db, q, out, n, RT, KB, nq_valid, s);
-        case 2: return launch_qt<2>(mode, db, q, out, n, RT, KB, nq_valid, s);
-        case 3: return launch_qt<3>(mode, db, q, out, n, RT, KB, nq_valid, s);
-        case 4: return launch_qt<4>(mode, db, q, out, n, RT, KB, nq_valid, s);
-        case 5: return launch_qt<5>(mode, db, q, out, n, RT, KB, nq_valid, s);
-        case 6: return launch_qt<6>(mode, db, q, out, n, RT, KB, nq_valid, s);
-        case 7: return launch_qt<7>(mode, db, q, out, n, RT, KB, nq_valid, s);
-        default: return launch_qt<8>(mode, db, q, out, n, RT, KB, nq_valid, s);
+        case 1: return launch_qt<1>(mode, db, q, out, n, RT, KB, nq_valid, s, 1, route);
+        case 2: return launch_qt<2>(mode, db, q, out, n, RT, KB, nq_valid, s, 1, route);
+        case 3: return launch_qt<3>(mode, db, q, out, n, RT, KB, nq_valid, s, 1, route);
+        case 4: return launch_qt<4>(mode, db, q, out, n, RT, KB, nq_valid, s, 1, route);
+        case 5: return launch_qt<5>(mode, db, q, out, n, RT, KB, nq_valid, s, 1, route);
+        case 6: return launch_qt<6>(mode, db, q, out, n, RT, KB, nq_valid, s, 1, route);
+        case 7: return launch_qt<7>(mode, db, q, out, n, RT, KB, nq_valid, s, 1, route);
+        default: return launch_qt<8>(mode, db, q, out, n, RT, KB, nq_valid, s, 1, route);
     }
 }
 

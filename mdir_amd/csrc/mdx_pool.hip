@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void pool_multi_kernel(PoolMaps maps, int S, f
 // write-through stores, an arrival ticket and an agent-scope acquire -- was built, is bit-identical, and is SLOWER:
 // 29 us against 12 us (batch 1) / 20 us (batch 4) for these two launches on a 2048 x 24 x 32 map:
 // the hand-off through memory costs more than the kernel boundary it removes, as the MI355X
-// guide's section 5.6 predicts.  Kept in tools/attic/pool_l2n_fused.hip.)
+// guide's section 5.6 predicts.  In the history: git show 47a9fe2:tools/attic/pool_l2n_fused.hip.)
 
 // one workgroup per row: x = (x + bias) / (||x + bias|| + eps)
 __global__ __launch_bounds__(256) void l2n_rows_kernel(float *__restrict__ x, int64_t D,

@@ -79,16 +79,35 @@ struct SegTable {
 // scatter<0> 33 against 23).  The peer blocks of an exchange are equally wide to within a row, so the block is GUESSED from the
 // column (where equal widths would put it) and its pointer and bounds are fetched together: one round trip when the guess
 // holds; any widths stay correct, a wrong guess walks from there.
-struct SegHit { const float *p; int64_t s0, s1; };
+struct SegHit { const float *p; int64_t s0, s1; int g; };
 
 __device__ __forceinline__ SegHit seg_find(const SegTable &t, int64_t i)
 {
     int g = (int)__umulhi((uint32_t)i, t.inv_w);
     if (g > t.nseg - 1) g = t.nseg - 1;
-    SegHit h = {t.p[g], t.start[g], t.start[g + 1]};
+    SegHit h = {t.p[g], t.start[g], t.start[g + 1], g};
     while (i >= h.s1 && g + 1 < t.nseg) { ++g; h.p = t.p[g]; h.s0 = h.s1; h.s1 = t.start[g + 1]; }
     while (i < h.s0 && g > 0) { --g; h.p = t.p[g]; h.s1 = h.s0; h.s0 = t.start[g]; }
+    h.g = g;
     return h;
+}
+
+// A tile that ends in the NEXT block (every block of an exchange is many tiles wide, so a tile meets at most one block
+// boundary): row q of both blocks as pointers that take the element's index in the whole row, and the boundary.  Round 6: such
+// a tile went element by element through seg_elem before -- a table look-up per element and lane, five to eight times the life
+// of a plain tile, and with 16 peer blocks every sixteenth workgroup was one (tools/seg_probe.py).
+struct SegPair { const uint32_t *a, *b; int64_t cut; bool ok; };
+
+__device__ __forceinline__ SegPair seg_pair(const SegTable &t, const SegHit &h, int64_t q, int64_t tile_end)
+{
+    SegPair r = {nullptr, nullptr, h.s1, false};
+    if (h.g + 1 >= t.nseg) return r;
+    const int64_t n0 = t.start[h.g + 1], n1 = t.start[h.g + 2];
+    if (tile_end > n1) return r;            // narrower blocks than a tile: the general path
+    r.a = (const uint32_t *)(h.p + q * (h.s1 - h.s0) - h.s0);
+    r.b = (const uint32_t *)(t.p[h.g + 1] + q * (n1 - n0) - n0);
+    r.ok = true;
+    return r;
 }
 
 // element i of row q
@@ -151,20 +170,36 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const float *__
             first[v] = b0 * SORT_TILE + (v * SORT_THREADS + tid) * 4;
             w[v] = u32x4u{0u, 0u, 0u, 0u};
         }
-        bool straddles = false;                 // (uniform) the tile lies in two column blocks: element-wise below
+        bool straddles = false;                 // (uniform) the tile lies in two column blocks
+        const int64_t tile_end = (b0 + 1) * SORT_TILE < n ? (b0 + 1) * SORT_TILE : n;
+        SegHit h = {nullptr, 0, 0, 0};
         if constexpr (FIRST && SEGT::HAS) {
-            const SegHit h = seg_find(seg, b0 * SORT_TILE);
-            const int64_t tile_end = (b0 + 1) * SORT_TILE < n ? (b0 + 1) * SORT_TILE : n;
+            h = seg_find(seg, b0 * SORT_TILE);
             straddles = tile_end > h.s1;
             p = (const uint32_t *)(h.p + q * (h.s1 - h.s0) - h.s0);
         }
         if (straddles) {
             if constexpr (SEGT::HAS) {
+                const SegPair pr = seg_pair(seg, h, q, tile_end);
+                if (pr.ok) {
 #pragma unroll
-                for (int v = 0; v < 2; ++v)
+                    for (int v = 0; v < 2; ++v) {
+                        const int64_t i0 = first[v];
+                        if (i0 + 4 <= pr.cut) w[v] = *(const u32x4u *)(pr.a + i0);
+                        else if (i0 >= pr.cut && i0 + 4 <= tile_end) w[v] = *(const u32x4u *)(pr.b + i0);
+                        else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (first[v] + j < n) w[v][j] = *(const uint32_t *)seg_elem(seg, q, first[v] + j);
+                            for (int j = 0; j < 4; ++j)
+                                if (i0 + j < tile_end) w[v][j] = (i0 + j < pr.cut ? pr.a : pr.b)[i0 + j];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (first[v] + j < n) w[v][j] = *(const uint32_t *)seg_elem(seg, q, first[v] + j);
+                }
             }
         } else if ((b0 + 1) * SORT_TILE <= n) {        // whole tile (uniform branch): both loads in flight together
 #pragma unroll
@@ -328,14 +363,23 @@ __global__ __launch_bounds__(SORT_THREADS, (SORT_WAVES >= 16 ? 8 : (3 * SORT_WAV
         typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
         const uint32_t *src = (const uint32_t *)scores + base + tile0;
         bool straddles = false;         // (uniform) the tile lies in two column blocks of segmented scores
+        SegHit sh = {nullptr, 0, 0, 0};
         if constexpr (SEGT::HAS) {
-            const SegHit h = seg_find(seg, tile0);
-            straddles = tile0 + tile_n > h.s1;
-            src = (const uint32_t *)(h.p + q * (h.s1 - h.s0) + (tile0 - h.s0));
+            sh = seg_find(seg, tile0);
+            straddles = tile0 + tile_n > sh.s1;
+            src = (const uint32_t *)(sh.p + q * (sh.s1 - sh.s0) + (tile0 - sh.s0));
         }
         if (straddles) {
-            if constexpr (SEGT::HAS)
-                for (int e = tid; e < tile_n; e += SORT_THREADS) skey[e] = desc_key(*seg_elem(seg, q, tile0 + e));
+            if constexpr (SEGT::HAS) {
+                const SegPair pr = seg_pair(seg, sh, q, tile0 + tile_n);
+                if (pr.ok) {
+                    const uint32_t *pa = pr.a + tile0, *pb = pr.b + tile0;
+                    const int cut = (int)(pr.cut - tile0);
+                    for (int e = tid; e < tile_n; e += SORT_THREADS) skey[e] = desc_key(__uint_as_float((e < cut ? pa : pb)[e]));
+                } else {
+                    for (int e = tid; e < tile_n; e += SORT_THREADS) skey[e] = desc_key(*seg_elem(seg, q, tile0 + e));
+                }
+            }
         } else if (tile_n == SORT_TILE) {      // whole tile (uniform branch): both loads in flight together
             u32x4u w[SORT_ITEMS / 4];
 #pragma unroll

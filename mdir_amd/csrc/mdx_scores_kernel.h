@@ -1,6 +1,6 @@
-// The similarity kernel of libmdx.so.  (The MDX_ABL_* / MDX_SHARD_BLOCKED / STAMPS switches below are timing-only forms that the
-// ablation harnesses of rounds 2-4 built -- tools/scores_ablate.hip, tools/split_ablate.hip, in the history at commit 47a9fe2; the
-// library is built without any of them.)
+// The similarity kernel of libmdx.so: ONE form, no compile-time forks.  The timing-only variants that earlier rounds measured
+// (no LDS-DMA beside the MFMAs, no ds_read, no epilogue, the same rows from the L2, in-kernel time stamps, the blocked shard
+// order) are a patch on this file, tools/ablate/scores_kernel_ablate.patch, applied to a scratch copy by tools/scores_where.sh.
 #pragma once
 #include "mdx_common.h"
 
@@ -16,45 +16,24 @@ constexpr int MAX_QT = 8;       // query tiles (of 16) per launch
 // 8-16 pieces of KC KiB at a KB-KiB stride.  The alternative -- blocks of 16 row tiles with the k-block as the slow
 // index, so that a chunk is ONE contiguous 32-KiB run -- was measured and is SLOWER (a pure stream of the shard
 // 1.76 ms against 1.52 ms at 1 M x 2048: the strided pieces spread over more HBM channels at any instant).
-#ifdef MDX_SHARD_BLOCKED        // tools/scores_ablate.hip: A/B timing only
-constexpr int SHARD_BLOCK = 16;
-__host__ __device__ __forceinline__ int64_t shard_tile(int64_t rt, int64_t kb, int64_t KB)
-{
-    return ((rt / SHARD_BLOCK) * KB + kb) * SHARD_BLOCK + (rt % SHARD_BLOCK);
-}
-#else
 __host__ __device__ __forceinline__ int64_t shard_tile(int64_t rt, int64_t kb, int64_t KB) { return rt * KB + kb; }
-#endif
 
 // Workgroup -> row block.  Consecutive workgroup ids go to different XCDs (id mod 8), each with its own L2; a workgroup's
 // output is one run of 512-1 024 B per query row, 4 MB apart.  With block = id the runs that one L2 collects at about the
 // same time are 8 blocks apart; giving each XCD a CONTIGUOUS range of row blocks makes them neighbours, so that they leave the
-// L2 as longer runs (the same trick as the sort's tile order).  -DMDX_XCD_BLOCKS=0: the plain order (A/B in tools/).
-#ifndef MDX_XCD_BLOCKS
-#define MDX_XCD_BLOCKS 1
-#endif
+// L2 as longer runs (the same trick as the sort's tile order).
 // sixteen zero bytes in device memory: what the row-major loader reads for k >= d (a padded chunk multiplied real row values
 // by the zero query tiles before: 0 * Inf = NaN where np.dot has Inf -- ADVICE round 4)
 __device__ __attribute__((aligned(16))) float mdx_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-#ifdef MDX_XCD_BLOCKS_RUNTIME        // tools/split_ablate.hip: both orders in one process
-__device__ int mdx_xcd_blocks_flag = 1;
-#endif
 __device__ __forceinline__ int64_t row_block_of(unsigned id, unsigned nblocks)
 {
-#ifdef MDX_XCD_BLOCKS_RUNTIME
-    if (!mdx_xcd_blocks_flag) return id;
-#endif
-#if MDX_XCD_BLOCKS
     const unsigned per = nblocks / 8, rem = nblocks % 8;          // XCD x takes `per` blocks, the first `rem` XCDs one more
     const unsigned x = id % 8, k = id / 8;
     return (int64_t)x * per + (x < rem ? x : rem) + k;
-#else
-    return id;
-#endif
 }
 
 // A score leaves the kernel once and is next read by another kernel (the ranking).  NT: a non-temporal store, which does
-// not allocate in the caches on its way out.  Measured (tools/split_ablate.hip, -DMDX_EPI_NT=0/1, several processes each): the
+// not allocate in the caches on its way out.  Measured (round 4, NT on / off, several processes each): the
 // HBM-bound split-precision ring kernel 1.60-1.64 -> 1.39-1.46 ms with it -- its query pieces are re-read from the L2 by every
 // workgroup, and 281 MB of output passing through the same caches pushes them out; the power-bound three-piece form, the exact
 // chain (MFMA-bound) and the fp16 kernels: no change or 1 % worse.  So only the split kernels ask for it.
@@ -91,7 +70,7 @@ struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e
 // ===========================================================================
 // Loader / consumer form of the similarity kernel.
 //
-// In-kernel stamps on the kernel above (tools/scores_ablate.hip) show where it loses
+// In-kernel stamps on the single-role kernel of round 1 showed where it lost
 // time: a wave spends about a third of its life BLOCKED ISSUING its global loads (a CU
 // holds only a few tens of KiB of reads in flight, so later load instructions stall at
 // issue), and a wave stalled on VMEM issue cannot issue MFMAs.  Here the roles are split:
@@ -128,16 +107,22 @@ struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e
 // s_barrier B_{c+1}, the reads of the next stage's k-block 0 -- sits in front of the LAST step (k 12-15) of a stage's last
 // k-block: the 8 + 8 MFMAs that follow need nothing from the new stage, so the matrix pipe runs through the barrier and through
 // the LDS round trip that otherwise opens every chunk.  Same MFMAs, same k order per output: same bits.
-template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, bool STAMPS = false, typename MM = MmaF32, int QR = 0, int CWAVES = 4, bool RM = false,
-          bool PIPE = false>
-__global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
+//
+// ROUTED = true (mdx_scores_p2p: the direct-store exchange of a row-sharded database, round 6): query q's run of scores does not go
+// to out + q * n but to route[q] + col0 -- route[q] = row (q - first query of its owner) of the OWNER rank's receive buffer, mapped
+// into this process (hipIpc), col0 = the shard's first global row.  The stores are system-scope (write-through: sc0 sc1), so that
+// nothing of them lingers in this XCD's L2 when the kernel ends and the step's flag goes out.  Same accumulators, same bits.
+template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, typename MM = MmaF32, int QR = 0, int CWAVES = 4, bool RM = false,
+          bool PIPE = false, int LWAVES = 4, bool ROUTED = false>
+__global__ __launch_bounds__((CWAVES + LWAVES) * 64, ((R >= 4 || CWAVES > 4) ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
                                                            float *__restrict__ out, int64_t n, int KB,
-                                                           int nq_valid, unsigned long long *dbg = nullptr, int64_t ld = 0)
+                                                           int nq_valid, int64_t ld = 0, float *const *__restrict__ route = nullptr,
+                                                           int64_t col0 = 0)
 {
     static_assert(!RM || (MM::STEPS == 4 && KC == 2), "row-major databases: fp32, two k-blocks per stage");
     constexpr int CW = CWAVES;                      // consumer waves (8: two per SIMD in ONE workgroup per CU, sharing the query stage)
-    constexpr int LW = 4;                           // loader waves
+    constexpr int LW = LWAVES;                      // loader waves
     static_assert(QR == 0 || (R == 2 && MM::STEPS == 4), "the 4x4x1 leftover path covers 32 fp32 rows per wave");
     constexpr int QTL = QT + QR;                    // query tiles in LDS: QT full ones + the leftover tile
     constexpr int QTILES = QTL * KC;                // KiB tiles of queries per stage
@@ -150,8 +135,6 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long t_entry = 0;
-    if (STAMPS) t_entry = __builtin_amdgcn_s_memrealtime();
     const int nchunks = KB / KC;
     const int64_t rt_wg = row_block_of(blockIdx.x, gridDim.x) * CW * R;       // first row tile of the workgroup
     // blockIdx.y = query pass: several full groups of QT query tiles in one launch (many queries
@@ -176,10 +159,6 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
             } else {
                 const int j = i - QTILES;
                 const int tile = j / KC, kbc = j % KC;              // tile = cw * R + r
-#ifdef MDX_ABL_SAME_ROWS            // tools/scores_ablate.hip -DMDX_ABL_SAME_ROWS, timing only: every workgroup streams the same few
-                                   // rows, so the shard comes from the L2 instead of HBM: 2.37 ms against 2.70 on the same box
-                src[t] = db + shard_tile((int64_t)(blockIdx.x % 16) * CW * R + tile, kbc, KB) * 64 + lane;
-#else
                 if constexpr (RM) {
                     const int64_t row = (rt_wg + tile) * TILE_ROWS + (lane & 15);
                     src[t] = (const f32x4 *)((const float *)db + (row < n ? row : n - 1) * ld);     // the row; k is added per stage
@@ -187,7 +166,6 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                 } else {
                     src[t] = db + shard_tile(rt_wg + tile, kbc, KB) * 64 + lane;
                 }
-#endif
             }
         }
         auto issue = [&](int c) {
@@ -222,9 +200,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
             else if (younger == 1 && NSTAGE > 3)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_LOADER) : "memory");
             else                                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                   // B_c
-#ifndef MDX_ABL_NOLOAD              // timing only (tools/scores_where.sh): the ring is filled once and never again -- no LDS-DMA beside the MFMAs
             if (c + NSTAGE - 1 < nchunks) issue(c + NSTAGE - 1);            // refill the slot of stage c-1
-#endif
         }
         return;
     }
@@ -242,11 +218,8 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     const int l_row = 4 * (lane >> 3) + (lane & 3);             // row inside the wave's 32 rows
     const int l_boff = (l_row >> 4) * KC * 64 + (l_row & 15);   // f32x4 offset of (tile, row) inside the wave's tiles
 
-    unsigned long long t_wait = 0, t_work = 0, ts0 = 0, ts1 = 0;      // STAMPS: diagnostic build only
-    unsigned long long tr0 = 0, tc0 = 0;
-    if (STAMPS) { tr0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory"); tc0 = ts0; }
     if constexpr (PIPE) {
-        static_assert(MM::STEPS == 4 && (KC == 2 || KC == 1) && !RM && !STAMPS, "pipelined consumer: fp32 tiles, one or two k-blocks per stage");
+        static_assert(MM::STEPS == 4 && (KC == 2 || KC == 1) && !RM, "pipelined consumer: fp32 tiles, one or two k-blocks per stage");
         // Registers: a full second operand set does not fit beside the accumulators and the leftover operands (128 registers per
         // wave at two workgroups per CU), so only what a block's FIRST MFMAs need is read ahead -- its database operands bn[] and
         // query tile 0 (an0); query tiles 1.. are read into a[1..] during the previous block's last step, each right after the
@@ -255,20 +228,13 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
         f32x4 a[QT > 0 ? QT : 1], b[R], bn[R], an0;
         f32x4 al[4], bl[4];
         constexpr int PIN = 0x0002 | 0x0004 | 0x0070 | 0x0380 | 0x0400;
-#ifdef MDX_ABL_NOLDSREAD             // timing only: operands are read for the first chunk and reused -- no ds_read beside the MFMAs
-        bool abl_read = true;
-#else
-        constexpr bool abl_read = true;
-#endif
         auto read_first = [&](const f32x4 *slot, int kb) __attribute__((always_inline)) {
-            if (!abl_read) return;
             const f32x4 *bs = slot + (QTILES + wave * R * KC) * 64 + lane;
 #pragma unroll
             for (int r = 0; r < R; ++r) bn[r] = bs[(r * KC + kb) * 64];
             an0 = slot[kb * 64 + lane];
         };
         auto read_left = [&](const f32x4 *slot, int kb) __attribute__((always_inline)) {
-            if (!abl_read) return;
             if constexpr (QR != 0) {
                 const f32x4 *ql = slot + (QT * KC + kb) * 64 + l_q;
                 const f32x4 *bw = slot + (QTILES + wave * R * KC + kb) * 64 + l_boff;
@@ -306,7 +272,7 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                             }
                         }
                     }
-                    if (t == 3 && q != 0 && nslot && abl_read) {        // a[q] is dead: the next block's tile q
+                    if (t == 3 && q != 0 && nslot) {        // a[q] is dead: the next block's tile q
                         __builtin_amdgcn_sched_barrier(0);
                         a[q] = nslot[(q * KC + nkb) * 64 + lane];
                         __builtin_amdgcn_sched_barrier(0);
@@ -328,9 +294,6 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
                 block(slot, 1, true, []() {});
             }
             read_left(slot, KC - 1);
-#ifdef MDX_ABL_NOLDSREAD
-            if (c >= 1) abl_read = false;
-#endif
             block(more ? next : nullptr, 0, false, [&]() __attribute__((always_inline)) {
                 if (more) {
                     __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): every read of this stage is back
@@ -344,7 +307,6 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     for (int c = 0; c < nchunks; ++c) {
         __builtin_amdgcn_s_barrier();                                       // B_c
         __builtin_amdgcn_sched_barrier(0);
-        if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); t_wait += ts1 - ts0; ts0 = ts1; }
         const f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
         const f32x4 *qs = slot + lane;
         const f32x4 *bs = slot + (QTILES + wave * R * KC) * 64 + lane;
@@ -403,12 +365,6 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
         }
         // all LDS reads of this stage are consumed by the MFMAs above before the next barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (STAMPS) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory"); t_work += ts1 - ts0; ts0 = ts1; }
-    }
-    if (STAMPS && dbg && lane == 0) {       // diagnostic build only: wait / work cycles, loop cycles and 100 MHz ticks (in-kernel clock)
-        unsigned long long *d = dbg + ((int64_t)blockIdx.x * CW + wave) * 8;
-        d[0] = t_wait; d[1] = t_work; d[2] = ts0 - tc0; d[3] = __builtin_amdgcn_s_memrealtime() - tr0;
-        d[4] = t_entry; d[5] = tr0;
     }
 
     // Epilogue: the ring is free now (loaders have left, consumers are past their last read);
@@ -416,17 +372,6 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     // 64*R database rows leaves as one contiguous run (full cache lines instead of 64-B pieces).
     constexpr int ROWS = CW * R * TILE_ROWS;        // database rows per workgroup
     constexpr int LDW = ROWS + 4;                   // +4: the four 16-lane groups hit different banks
-#ifdef MDX_ABL_NO_EPILOGUE          // tools/scores_ablate.hip, timing only: what the epilogue costs (every accumulator stays alive in one sum)
-    {
-        f32x4 tot = accl;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int q = 0; q < QT; ++q) tot += acc[r][q];
-        out[(int64_t)(lane % 64) * n + rt_wg * TILE_ROWS + wave] = tot[0] + tot[1] + tot[2] + tot[3];
-        return;
-    }
-#endif
     static_assert((QT * 16 + QR * 8) * LDW * 4 <= NSTAGE * STAGE_TILES * 1024, "output staging must fit in the ring");
     __builtin_amdgcn_s_barrier();
     float *stage = (float *)ring;
@@ -452,15 +397,16 @@ __global__ __launch_bounds__(CWAVES * 64 + 256, ((R >= 4 || CWAVES > 4) ? 1 : 2)
     // queries of this group that exist (the last group of a launch may be partial)
     constexpr int QCAP = QT * TILE_ROWS + QR * 8;   // query rows staged (grid.y > 1 only with QR = 0)
     const int nq_here = (nq_valid - (int)blockIdx.y * QT * TILE_ROWS) < QCAP ? (nq_valid - (int)blockIdx.y * QT * TILE_ROWS) : QCAP;
+    static_assert(ROWS % 64 == 0, "a wave's stores of one step belong to one query");
     for (int e = tid; e < nq_here * ROWS; e += CW * 64) {
         const int qi = e / ROWS, rr = e % ROWS;
-        if (rr < rows_valid) store_score<false>(out + (int64_t)qi * n + row0 + rr, stage[qi * LDW + rr]);
-    }
-    if (STAMPS && dbg && lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long *d = dbg + ((int64_t)blockIdx.x * CW + wave) * 8;
-        d[6] = __builtin_amdgcn_s_memrealtime();
-        d[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID (cu / se / simd / wave slot)
+        if constexpr (ROUTED) {
+            // (qi is the same in all lanes of a wave: the row pointer is a scalar load)
+            float *dst = route[__builtin_amdgcn_readfirstlane((int)blockIdx.y * QT * TILE_ROWS + qi)] + col0 + row0 + rr;
+            if (rr < rows_valid) __hip_atomic_store(dst, stage[qi * LDW + rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            if (rr < rows_valid) store_score<false>(out + (int64_t)qi * n + row0 + rr, stage[qi * LDW + rr]);
+        }
     }
 }
 

@@ -183,11 +183,9 @@ __global__ __launch_bounds__(256) void retile_split3_kernel(const float *__restr
     tiles[((2 * QT_total + qt) * NC + c) * 64 + lane] = l;
 }
 
-// ABL != 0: timing-only ablations for tools/split_ablate.hip (results wrong): 1 = no operand split (raw bits as pieces),
-// 2 = no MFMAs (LDS reads + split only), 3 = consumers idle (the stream + barriers alone), 4 = three products of two pieces
 // NP = 3: three bf16 pieces, six products (MDX_F32_SPLIT3); NP = 2: two fp16 pieces with a scaled residual, three products
 // (MDX_F32_SPLIT2; db_scale = the shard's S, q_cell = the device word holding the queries' largest magnitude)
-template <int NP, int QT, int R, int NSTAGE, int CW, int DB_AUX, int ABL>
+template <int NP, int QT, int R, int NSTAGE, int CW, int DB_AUX>
 __device__ __forceinline__ void split_kernel_body(f32x4 *ring, const f32x4 *__restrict__ db, const u32x4 *__restrict__ qpieces,
                                                   float *__restrict__ out, int64_t n, int KB, int QT_total, int qt_first, int nq_valid,
                                                   float db_scale, const uint32_t *__restrict__ q_cell)
@@ -274,7 +272,6 @@ __device__ __forceinline__ void split_kernel_body(f32x4 *ring, const f32x4 *__re
         const f32x4 *slot = ring + (c % NSTAGE) * (STAGE_TILES * 64);
         const u32x4 *qs = (const u32x4 *)slot + lane;
         const f32x4 *bs = slot + (QTILES + wave * R * 2) * 64 + lane;
-        if constexpr (ABL == 3) continue;
         if constexpr (NP == 2) {
             u32x4 dh[R], dm[R];
 #pragma unroll
@@ -295,13 +292,7 @@ __device__ __forceinline__ void split_kernel_body(f32x4 *ring, const f32x4 *__re
         u32x4 dh[R], dm[R], dl[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if constexpr (ABL == 1) {
-                dh[r] = __builtin_bit_cast(u32x4, bs[(2 * r) * 64]);
-                dm[r] = __builtin_bit_cast(u32x4, bs[(2 * r + 1) * 64]);
-                dl[r] = dh[r] ^ dm[r];
-            } else {
-                split3(bs[(2 * r) * 64], bs[(2 * r + 1) * 64], dh[r], dm[r], dl[r]);
-            }
+            split3(bs[(2 * r) * 64], bs[(2 * r + 1) * 64], dh[r], dm[r], dl[r]);
         }
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
@@ -310,16 +301,9 @@ __device__ __forceinline__ void split_kernel_body(f32x4 *ring, const f32x4 *__re
             for (int r = 0; r < R; ++r) {
                 // smallest terms first: inside the accumulator's rounding they are kept best next to a young sum
                 f32x4 a = acc[r][q];
-                if constexpr (ABL == 2) {       // keep the reads and the split alive without the matrix pipe
-                    a[0] += __uint_as_float((ql[0] ^ dh[r][1] ^ qh[2] ^ dl[r][3] ^ qm[0] ^ dm[r][2]) & 0x3F800000u);
-                    acc[r][q] = a;
-                    continue;
-                }
-                if constexpr (ABL != 4) {       // ABL 4 (timing only): the cost model of a TWO-piece split -- three products, no low pieces
-                    a = mfma_bf16(ql, dh[r], a);
-                    a = mfma_bf16(qh, dl[r], a);
-                    a = mfma_bf16(qm, dm[r], a);
-                }
+                a = mfma_bf16(ql, dh[r], a);
+                a = mfma_bf16(qh, dl[r], a);
+                a = mfma_bf16(qm, dm[r], a);
                 a = mfma_bf16(qm, dh[r], a);
                 a = mfma_bf16(qh, dm[r], a);
                 a = mfma_bf16(qh, dh[r], a);
@@ -365,13 +349,13 @@ __device__ __forceinline__ void split_kernel_body(f32x4 *ring, const f32x4 *__re
     }
 }
 
-template <int QT, int R, int NSTAGE, int CW, int DB_AUX = 2, int ABL = 0>
+template <int QT, int R, int NSTAGE, int CW, int DB_AUX = 2>
 __global__ __launch_bounds__(CW * 64 + 256, 1) void scores_split3_kernel(const f32x4 *__restrict__ db, const u32x4 *__restrict__ qpieces,
                                                                          float *__restrict__ out, int64_t n, int KB, int QT_total,
                                                                          int qt_first, int nq_valid)
 {
     extern __shared__ __attribute__((aligned(16))) f32x4 split_ring[];
-    split_kernel_body<3, QT, R, NSTAGE, CW, DB_AUX, ABL>(split_ring, db, qpieces, out, n, KB, QT_total, qt_first, nq_valid, 1.0f, nullptr);
+    split_kernel_body<3, QT, R, NSTAGE, CW, DB_AUX>(split_ring, db, qpieces, out, n, KB, QT_total, qt_first, nq_valid, 1.0f, nullptr);
 }
 
 template <int QT, int R, int NSTAGE, int CW, int DB_AUX = 2>
@@ -381,7 +365,7 @@ __global__ __launch_bounds__(CW * 64 + 256, 1) void scores_split2_kernel(const f
                                                                          const uint32_t *__restrict__ q_cell)
 {
     extern __shared__ __attribute__((aligned(16))) f32x4 split_ring[];
-    split_kernel_body<2, QT, R, NSTAGE, CW, DB_AUX, 0>(split_ring, db, qpieces, out, n, KB, QT_total, qt_first, nq_valid, db_scale, q_cell);
+    split_kernel_body<2, QT, R, NSTAGE, CW, DB_AUX>(split_ring, db, qpieces, out, n, KB, QT_total, qt_first, nq_valid, db_scale, q_cell);
 }
 
 }  // namespace mdx

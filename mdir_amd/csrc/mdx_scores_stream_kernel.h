@@ -16,7 +16,7 @@
 //   * the prologue issues in the loop's order, pinned with sched_barrier: the compiler derives its counted vmcnt waits from
 //     the issue order it sees on every way into the loop.
 // A persistent variant that lets the stream run on into the next row block across the epilogue was built and is NOT faster
-// (tools/attic/scores_stream_persistent_kernel.h: 0.79 against 0.76 ms; 768 workgroups x 10.2 blocks leave a 7 % tail, and
+// (git show 47a9fe2:tools/attic/scores_stream_persistent_kernel.h: 0.79 against 0.76 ms; 768 workgroups x 10.2 blocks leave a 7 % tail, and
 // what the epilogue costs is its scattered stores, not a stopped stream).  Operand format, MFMA and accumulators are the ring
 // kernel's: results are bit-identical to it (tests/test_gpu_f16.py).
 #pragma once

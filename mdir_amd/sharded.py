@@ -83,17 +83,53 @@ class BlockScores:
         return self.blocks[0] if len(self.blocks) == 1 else torch.cat(self.blocks, dim=1)
 
 
-def private_miopen_caches(local_rank):
+def private_miopen_caches(local_rank, job_id=None):
     """One process per GPU: give every rank its OWN MIOpen user database and kernel cache directory (unless the user has set
     them).  MIOpen keeps both in sqlite files under ~/.config/miopen and ~/.cache/miopen; eight ranks that meet the same new
-    convolution shapes at the same moment would all write them at once.  Must run before the process's first convolution."""
+    convolution shapes at the same moment would all write them at once.  Must run before the process's first convolution.
+
+    The directories live under ``~/.cache/mdir_amd/miopen/<job>/rank<N>`` (``$XDG_CACHE_HOME`` honoured): private to the user
+    (mode 0700, ownership checked -- nobody else can plant code objects there), private to the JOB (``job`` = the launcher's
+    ``TORCHELASTIC_RUN_ID`` + ``MASTER_PORT``, so two jobs of one user on one node, both with local ranks 0..3, do not share
+    sqlite files), and they survive a ``/tmp`` clean-up.  A fresh rank directory is seeded ONCE with a copy of the user's shared
+    MIOpen user database, so that a rank does not start from nothing; the shared files themselves are never written."""
     import os
-    import tempfile
-    base = os.path.join(tempfile.gettempdir(), "mdir_amd_miopen_%d_rank%d" % (os.getuid(), int(local_rank)))
+    import shutil
+    import stat
+    if job_id is None:
+        job_id = "%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "norun"), os.environ.get("MASTER_PORT", str(os.getppid())))
+    job_id = "".join(c if c.isalnum() or c in "-_." else "_" for c in str(job_id))[:80] or "job"
+    cache_home = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    base = os.path.join(cache_home, "mdir_amd", "miopen", job_id, "rank%d" % int(local_rank))
+    made = {}
     for var, sub_dir in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
-        if var not in os.environ:
-            os.makedirs(os.path.join(base, sub_dir), exist_ok=True)
-            os.environ[var] = os.path.join(base, sub_dir)
+        if var in os.environ:
+            continue
+        path = os.path.join(base, sub_dir)
+        fresh = not os.path.isdir(path)
+        os.makedirs(path, mode=0o700, exist_ok=True)
+        # every level this function owns must be a real directory of this user that nobody else can write
+        probe = path
+        while len(probe) >= len(os.path.join(cache_home, "mdir_amd")):
+            st = os.lstat(probe)
+            if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():
+                raise PermissionError("%s is not a directory owned by uid %d: refusing to point MIOpen at it" % (probe, os.getuid()))
+            if st.st_mode & 0o022:
+                os.chmod(probe, st.st_mode & 0o7755 & ~0o022)
+            probe = os.path.dirname(probe)
+        os.environ[var] = path
+        made[var] = (path, fresh)
+    if made.get("MIOPEN_USER_DB_PATH", (None, False))[1]:
+        shared = os.path.join(os.environ.get("XDG_CONFIG_HOME") or os.path.join(os.path.expanduser("~"), ".config"), "miopen")
+        if os.path.isdir(shared):
+            for name in os.listdir(shared):
+                src = os.path.join(shared, name)
+                try:
+                    if os.path.isfile(src) and os.path.getsize(src) < (256 << 20):
+                        shutil.copy2(src, os.path.join(made["MIOPEN_USER_DB_PATH"][0], name))
+                except OSError:
+                    pass            # a seed is a convenience: a file another process is writing is simply not taken
+    return base
 
 
 def shard_bounds(n_total, world, rank):
@@ -111,10 +147,9 @@ def exchange_chunks(n_total, world):
     """How many row chunks every shard is cut into so that the all-to-all of chunk c runs on
     RCCL's stream while the similarity kernel of chunk c+1 runs on the compute stream.  Small
     chunks cost kernel efficiency (measured: tools/shard_model.py, tools/g8_budget.py), so only big shards are split:
-    three chunks at G=2, two at G=4 for 1 M rows (chunk sizes halve, see ``chunk_bounds``), and -- round 5 -- two EQUAL chunks
-    at G=8 (125 k-row shards: two launches of 491 workgroups, one round of the chip's 512 slots each, take the time of the one
-    launch of 982, 0.345 against 0.349 ms, and the first half's transfer then hides behind the second half's kernel;
-    profiles/r05_g8_budget.md).  Same value on every rank (derived from the largest shard)."""
+    three chunks at G=2, two at G=4 for 1 M rows (chunk sizes halve, see ``chunk_bounds``), and two chunks at G=8 (125 k-row
+    shards: a first launch of exactly one round of the chip's 512 workgroup slots + the rest take less time than the one launch
+    of 982 workgroups, and the first chunk's transfer hides behind the second chunk's kernel; profiles/r05_g8_budget.md).  Same value on every rank (derived from the largest shard)."""
     import os
     forced = os.environ.get("MDIR_AMD_EXCHANGE_CHUNKS")
     if forced:
@@ -127,16 +162,25 @@ def exchange_chunks(n_total, world):
 
 
 MIN_CHUNK_ROWS = 60_000
+# one full round of the exact similarity kernel on an MI355X: 256 CUs x 2 resident workgroups x 128 rows (mdx_scores_kernel.h, R = 2)
+FULL_ROUND_ROWS = 512 * 128
 
 
 def chunk_bounds(lo, hi, chunks):
     """Contiguous chunks of rows ``[lo, hi)`` with sizes halving from one to the next (4/7, 2/7, 1/7 for
     three): a link moves a chunk's scores in about half the time the similarity kernel needs for the
     same rows, so the transfer of chunk c hides behind the kernel of the half-sized chunk c+1, and
-    only the LAST, smallest transfer is exposed."""
+    only the LAST, smallest transfer is exposed.
+
+    Shards too small for halving chunks (G = 8 at 1 M rows) are cut in two with the FIRST chunk exactly one full round of
+    the chip's 512 workgroup slots (65 536 rows) and the rest second: 0.344 ms against 0.359 for two equal chunks and 0.356
+    for the one launch (profiles/r05_g8_budget.md; re-measured in profiles/r06_g8_budget.md) -- the first launch has no
+    partial last round, and the smaller second chunk is also the smaller exposed transfer."""
     n = hi - lo
     weights = [1 << (chunks - 1 - c) for c in range(chunks)]
     if n // sum(weights) < MIN_CHUNK_ROWS:
+        if chunks == 2 and FULL_ROUND_ROWS + FULL_ROUND_ROWS // 2 <= n <= 2 * FULL_ROUND_ROWS:
+            return [(lo, lo + FULL_ROUND_ROWS), (lo + FULL_ROUND_ROWS, hi)]
         # the smallest of the halving chunks would not fill the chip once (a similarity launch has 512 workgroup slots of 128
         # rows): equal chunks instead -- at 125 625 rows 2 x 62 812 take 0.345 ms, 83 750 + 41 875 take 0.399 (tools/g8_budget.py)
         weights = [1] * chunks

@@ -331,14 +331,39 @@ def test_rmac_region_grid_module_and_network(fops, golden):
     np.testing.assert_allclose(got.t().numpy(), want, rtol=1e-5, atol=1e-6)
 
 
-def test_ranks_get_private_miopen_caches(monkeypatch):
+def test_ranks_get_private_miopen_caches(monkeypatch, tmp_path):
     """One process per GPU: every rank writes its own MIOpen user db / kernel cache (sqlite files); what the user has set stays."""
     from mdir_amd.sharded import private_miopen_caches
     monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
     monkeypatch.setenv("MIOPEN_CUSTOM_CACHE_DIR", "/somewhere/else")
+    import stat
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "cache"))
+    monkeypatch.setenv("XDG_CONFIG_HOME", str(tmp_path / "config"))
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/A")
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    (tmp_path / "config" / "miopen").mkdir(parents=True)
+    (tmp_path / "config" / "miopen" / "gfx950.udb.txt").write_text("seed")
     private_miopen_caches(3)
-    assert os.environ["MIOPEN_USER_DB_PATH"].endswith("rank3/db") and os.path.isdir(os.environ["MIOPEN_USER_DB_PATH"])
+    db = os.environ["MIOPEN_USER_DB_PATH"]
+    assert db.endswith("rank3/db") and os.path.isdir(db)
     assert os.environ["MIOPEN_CUSTOM_CACHE_DIR"] == "/somewhere/else"
+    # under the user's cache home, one directory per JOB (two jobs of one user share local ranks 0..3, not sqlite files), mode 0700,
+    # seeded once from the user's shared MIOpen database
+    assert db.startswith(str(tmp_path / "cache" / "mdir_amd" / "miopen")) and "job_A_29511" in db
+    assert stat.S_IMODE(os.stat(db).st_mode) == 0o700
+    assert open(os.path.join(db, "gfx950.udb.txt")).read() == "seed"
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    private_miopen_caches(3)
+    assert os.environ["MIOPEN_USER_DB_PATH"] != db                         # another job: another directory
+    # a directory somebody else could write (or a planted symlink) is refused, not used
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("MASTER_PORT", "29513")
+    planted = tmp_path / "cache" / "mdir_amd" / "miopen" / "job_A_29513"
+    planted.parent.mkdir(parents=True, exist_ok=True)
+    os.symlink(str(tmp_path), str(planted))
+    with pytest.raises(PermissionError):
+        private_miopen_caches(0)
 
 
 def test_regional_pooling_module_and_network(fops, golden):

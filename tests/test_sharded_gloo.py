@@ -162,8 +162,11 @@ def test_exchange_chunk_policy():
     assert exchange_chunks(1004993, 2) == 3          # 502 k-row shards: 4/7, 2/7, 1/7 -- only the last transfer is exposed
     assert exchange_chunks(1004993, 4) == 2 and exchange_chunks(1004993, 8) == 2 and exchange_chunks(1004993, 16) == 1
     assert exchange_chunks(4993, 8) == 1
-    # 125 k-row shards (G = 8): two EQUAL chunks, one round of the chip's workgroup slots each; bigger shards halve
-    assert [y - x for x, y in chunk_bounds(0, 125625, 2)] == [62812, 62813]
+    # 125 k-row shards (G = 8): the first chunk is exactly one round of the chip's 512 workgroup slots (65 536 rows), on every
+    # rank (shards differ by a row); shards outside (1.5, 2] rounds are cut in equal halves; bigger shards halve
+    assert [y - x for x, y in chunk_bounds(0, 125625, 2)] == [65536, 60089]
+    assert [y - x for x, y in chunk_bounds(7, 7 + 125624, 2)] == [65536, 60088]
+    assert [y - x for x, y in chunk_bounds(0, 90000, 2)] == [45000, 45000]
     assert [y - x for x, y in chunk_bounds(0, 251249, 2)] == [167499, 83750]
     b = chunk_bounds(10, 21, 3)
     assert b[0][0] == 10 and b[-1][1] == 21 and all(x[1] == y[0] for x, y in zip(b, b[1:]))

@@ -281,11 +281,83 @@ def measure_list(arch="resnet101", workers=8, short=12, mid=40, long=64):
             "graph_capture_and_first_batches_s_per_size": round((times["warm_mid"] - nm * steady) / len(LIST_SHAPES), 3),
             "loader_only_images_per_s": round(nl / t_loader, 1),
             "trunk_conv_tflops_at_steady_state": round(flops / steady / 1e12, 2), "trunk_conv_gflop_per_image": round(flops / 1e9, 1),
+            # the extraction half's own roofline: the trunk's convolutions are the flops of an image (the hand-written tail is
+            # `roofline_tail`, launch-bound).  Two readings: over the whole warm list (what `value` is) and at the steady state.
+            "roofline": {"kernel": "trunk convolutions: MIOpen (owner of the kernels) + mdx::conv1x1_bn_act_kernel for the Bottleneck expand 1x1 "
+                                   "convolutions, mdx::bn_act_kernel epilogues; fp32",
+                         "bound": "mfma", "achieved": round(flops * nl / times["warm_long"] / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(flops * nl / times["warm_long"] / 1e12 / 157.3, 4),
+                         "achieved_at_steady_state": round(flops / steady / 1e12, 2), "frac_at_steady_state": round(flops / steady / 1e12 / 157.3, 4),
+                         "algorithmic_flops_per_image": flops, "traffic": None,
+                         "what": "2 x multiply-adds of every convolution of the three scales (hooks on an eager pass, mean of three of the 16 sizes) "
+                                 "x images / wall time of the whole warm list (loader, graph captures, tail and whitening included in the time)"},
             "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}
 
 
+def cpu_reference_loop(arch="resnet101", images=8, size=(768, 1024), budget_s=40.0):
+    """The REFERENCE-STYLE extraction loop on the host cores, for `descriptors_per_s.cpu_baseline`: batch 1, three scales
+    (``[1, 1/sqrt(2), 1/2]``, F.interpolate bilinear), one trunk forward per scale, GeM / L2N / multi-scale aggregation /
+    whitening as stock torch ops, ``.cpu()`` per image -- the loop of cirtorch/networks/imageretrievalnet.py:284-324
+    (``extract_vectors`` -> ``extract_ms``) under mdir's wrapper chain (components/data/wrapper.py:104-119, 193-195), restated
+    here (nothing of the reference is imported); the same random-init trunk as the GPU leg, synthetic 1024x768 inputs already
+    decoded (the reference overlaps decoding in 6 loader workers).  Timed at 3 threads (what the reference asks for,
+    mdir/stages/validate.py:10-12) and at all cores; each leg stops after ``images`` images or ``budget_s`` seconds."""
+    from mdir_amd.networks import init_network
+    torch.manual_seed(3)
+    net = init_network({"architecture": arch, "pooling": "gem", "whitening": False, "pretrained": False})
+    feats = net.features.eval()
+    D = net.meta["outputdim"]
+    p = float(net.pool.p_value())
+    rng = np.random.default_rng(2)
+    q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    P = torch.tensor((q * rng.uniform(0.5, 2.0, (1, D))).T.copy(), dtype=torch.float32)
+    m = torch.tensor(rng.normal(0, 0.01, (D, 1)), dtype=torch.float32)
+    g = torch.Generator()
+    g.manual_seed(11)
+    imgs = [torch.randn((1, 3) + tuple(size), generator=g) for _ in range(2)]
+    scales = [1.0, 2 ** -0.5, 0.5]
+
+    def one(x):
+        v = torch.zeros(D)
+        for s in scales:
+            xs = x if s == 1.0 else F.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False)
+            f = feats(xs)
+            o = F.avg_pool2d(f.clamp(min=1e-6).pow(p), (f.size(-2), f.size(-1))).pow(1.0 / p)
+            o = o / (torch.norm(o, p=2, dim=1, keepdim=True) + 1e-6)
+            v += o.reshape(-1).pow(p)
+        v = (v / len(scales)).pow(1.0 / p)
+        v /= v.norm()
+        X = P.mm(v.unsqueeze(1).sub(m))
+        return X.div(torch.norm(X, p=2, dim=0, keepdim=True) + 1e-6).squeeze().cpu()
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    out = {}
+    try:
+        with torch.no_grad():
+            for name, threads in (("all_cores", cores), ("threads_3", min(3, cores))):
+                torch.set_num_threads(threads)
+                one(imgs[0])                             # warm-up: oneDNN builds its primitives for the three shapes
+                t0, done = time.perf_counter(), 0
+                while done < images and (done == 0 or time.perf_counter() - t0 < budget_s):
+                    one(imgs[done % 2])
+                    done += 1
+                dt = time.perf_counter() - t0
+                out[name] = {"descriptors_per_s": round(done / dt, 4), "s_per_image": round(dt / done, 3), "images": done, "threads": threads}
+    finally:
+        torch.set_num_threads(before)
+    best = max(out.values(), key=lambda r: r["descriptors_per_s"])
+    return {"value": best["descriptors_per_s"], "unit": "descriptors/s", "cores": best["threads"], "kind": "port",
+            "sample": "%d images of %dx%d per leg (bounded), batch 1, 3 scales, torch CPU ops (oneDNN convolutions) for the trunk and the "
+                      "tail, .cpu() per image: the loop of imageretrievalnet.py:284-324 under the wrapper chain, restated; %s-GeM random init"
+                      % (images, size[1], size[0], arch),
+            "value_3_threads": out["threads_3"]["descriptors_per_s"], "legs": out, "host_cores": cores}
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--list":
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-loop":
+        print(json.dumps(cpu_reference_loop(images=int(sys.argv[2]) if len(sys.argv) > 2 else 2)))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--list":
         print(json.dumps(measure_list(*(sys.argv[2:3] or ["resnet101"]))))
     else:
         main()

@@ -4,6 +4,8 @@
 //         [-DMDX_GRAM_PLAIN_MAP] -I mdir_amd/csrc -I include tools/gram_ablate.hip -o tools/gram_ablate_bin_<name>
 //   MDX_GRAM_ABL=5: the loaders issue nothing inside the loop (what the operand supply costs; results wrong by construction);
 //   MDX_GRAM_LW / _LC_GK / _LC_NSTAGE: loader waves, k per stage, stages; MDX_GRAM_PLAIN_MAP: workgroup id = tile position.
+// (Round 6: MDX_GRAM_ABL / MDX_GRAM_PLAIN_MAP left mdx_gram.hip; apply tools/ablate/scores_kernel_ablate.patch to a scratch copy of
+// mdir_amd/csrc and include that copy to get them back.)
 // Only the default build's result is checked (a host sum over a few entries).  Numbers: the header of mdx_gram.hip.
 #include <cstdarg>
 #include <cstdio>

@@ -70,6 +70,14 @@ out = {"note": "HBM bytes per launch; FETCH_SIZE x2 (gfx950 correction), WRITE_S
        "scores_kernel_hbm_bytes_per_launch": traffic[sk[0]]["total_bytes"] if sk else None,
        "scores_kernel_sustained_clock_ghz": round(clock, 3) if clock else None,
        "scores_kernel_mfma_pipe_busy": round(mfma_busy, 4) if mfma_busy else None}
+# the kernel-trace averages of the same command (bench.py --profile): what `roofline.frac_rocprof` of the bench line is computed from
+_sk_rows = sorted((r for r in keep if "::scores_lc_kernel" in r["Name"]), key=lambda r: -float(r["TotalDurationNs"]))
+if _sk_rows:
+    out["scores_kernel_trace_avg_us"] = round(float(_sk_rows[0]["AverageNs"]) / 1e3, 2)
+    out["scores_kernel_trace_name"] = short(_sk_rows[0]["Name"])
+    out["scores_kernel_trace_calls"] = int(_sk_rows[0]["Calls"])
+out["ranking_trace_sum_us"] = round(sum(float(r["AverageNs"]) / 1e3 * (4 if "sort_scan_kernel" in r["Name"] else 1)
+                                        for r in keep if "::sort_" in r["Name"]), 2)
 # the split-precision kernel's own passes (tools/profile_round.sh: tools/split_bench.py under --pmc)
 f3, w3, s3 = pmc("pmc_split3_FETCH_SIZE.csv"), pmc("pmc_split3_WRITE_SIZE.csv"), pmc("pmc_split3_SQ_VALU_MFMA_BUSY_CYCLES.csv")
 for k in f3:
