@@ -277,6 +277,68 @@ def f64_arbiter(rows, qvecs, sc, rk, rk_cpu, sc_cpu, gnd, vecs_host=None):
     return out
 
 
+def requested_form():
+    """The exchange form the command line / environment asks for, in tools/preflight_ranks.py's vocabulary."""
+    comm = os.environ.get("MDIR_AMD_COMM") or ""
+    if comm in ("p2p", "mdx"):
+        return comm
+    return "allgather" if os.environ.get("MDIR_AMD_EXCHANGE") == "allgather" else "torch"
+
+
+def preflight(n):
+    """tools/preflight_ranks.py with FRESH child processes (called by a process that has not touched the GPU): the requested
+    exchange form and its fall-backs on a 10 000-row problem, every rank's rows verified on the device; then -- unless the direct-store
+    form was the one requested, or MDIR_AMD_COMM_AUTO=0 -- ONE probe of the direct-store form, whose verdict decides whether the
+    heavy run may time it against the collective (`exchange_selection`)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import preflight_ranks
+    first = requested_form()
+    pre = preflight_ranks.run(n, first)
+    if pre["form"] is not None and pre["form"] != "p2p" and first == "torch" and os.environ.get("MDIR_AMD_COMM_AUTO", "1") != "0":
+        pre["p2p_probe"] = preflight_ranks.run(n, "p2p", only=True)["tried"][0]
+    return pre
+
+
+def select_exchange(sharded, step, keep, dryrun, device, reps=3):
+    """Run time A/B of the two exchange forms on THIS node at the full size, outside the timed region: `reps` steps of the
+    collective form, then of the direct-store form (which the preflight has just verified on a small problem with fresh
+    processes).  The direct-store form is taken only if every rank's ranking is bit-identical to the collective form's, no
+    flag wait gave up, and the slowest rank's step is faster.  Any failure leaves the collective form in place."""
+    def timed():
+        step()                                              # (first step of a form: buffers, peer mappings)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device="cpu" if dryrun else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    out = {"collective_ms": round(timed(), 4)}
+    rk_a = keep["rk"].clone()
+    ok, why = 1, ""
+    try:
+        sharded.use_direct_store(True)
+        out["direct_store_ms"] = round(timed(), 4)
+        if not torch.equal(keep["rk"], rk_a):
+            ok, why = 0, "the direct-store ranking differs from the collective form's"
+        elif sharded._p2p is not None and sharded._p2p.late_peers() != 0:
+            ok, why = 0, "a peer's flag did not arrive"
+    except Exception as exc:          # noqa: BLE001 -- the collective form stays
+        ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+    flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if dryrun else device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = int(flag.item())
+    take = bool(ok and out.get("direct_store_ms", 1e9) < out["collective_ms"])
+    sharded.use_direct_store(take)
+    out.update({"direct_store_verified_equal": bool(ok), "chosen": "direct_store" if take else "collective",
+                "what": "per-step wall time of the slowest rank over %d steps of each form at the full size, before the timed region" % reps})
+    if why:
+        out["reason"] = why
+    return out
+
+
 def launch_ranks(n):
     """One child `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>`; returns its exit code.
     The children inherit stdout, so rank 0's JSON line is this command's output."""
@@ -293,6 +355,13 @@ def launch_ranks(n):
         port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", "4")
+    if "--no-preflight" not in sys.argv and "MDIR_AMD_PREFLIGHT" not in env:
+        # this process never touches the GPU: the preflight's fresh children run here, and the heavy run's ranks are told the verdict
+        pre = preflight(n)
+        if pre["form"] is None:
+            print("bench.py --gpus %d: no exchange form passed the preflight: %s" % (n, json.dumps(pre["tried"])), file=sys.stderr)
+            return 4
+        env["MDIR_AMD_PREFLIGHT"] = json.dumps(pre)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
@@ -313,9 +382,12 @@ def main():
                     help="images PER SIZE (16 sizes) of the (untimed) descriptors/sec leg: ResNet101-GeM, 3 scales + whitening; 0 = skip")
     ap.add_argument("--no-pipelined", action="store_true", help="(accepted for older command lines; no effect)")
     ap.add_argument("--profile", action="store_true", help="the headline loop only: --no-cpu-baseline --extract-images 0")
-    ap.add_argument("--comm", choices=("torch", "mdx"), default=None,
-                    help="N > 1: the exchange of partial scores through torch.distributed (default) or through the C-ABI communicator "
-                         "(mdx_comm_* / mdx_exchange_scores over RCCL; same as MDIR_AMD_COMM=mdx)")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip tools/preflight_ranks.py (fresh child processes that check the "
+                    "exchange form on a small problem before the heavy run) and the run-time choice between the exchange forms")
+    ap.add_argument("--comm", choices=("torch", "mdx", "p2p"), default=None,
+                    help="N > 1: the exchange of partial scores through torch.distributed (default), through the C-ABI communicator "
+                         "(mdx_comm_* / mdx_exchange_scores over RCCL; same as MDIR_AMD_COMM=mdx), or with no collective at all: the "
+                         "similarity kernel stores into the owners' receive buffers (mdx_scores_p2p, hipIpc + xGMI stores; MDIR_AMD_COMM=p2p)")
     args = ap.parse_args()
     if args.profile:
         args.no_cpu_baseline, args.secondary = True, False
@@ -332,6 +404,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    pre = json.loads(os.environ["MDIR_AMD_PREFLIGHT"]) if os.environ.get("MDIR_AMD_PREFLIGHT") else None
+    if world > 1 and pre is None and rank == 0 and not args.no_preflight:
+        # launched as ranks (the driver's torch.distributed.run): rank 0 runs the preflight's fresh children BEFORE it touches the
+        # GPU; the other ranks wait for it in init_process_group below and receive the verdict there
+        pre = preflight(world)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # MDIR_AMD_DRYRUN_ONE_GPU=1: every rank uses cuda:0 and gloo (host-staged collectives) --
@@ -354,6 +431,19 @@ def main():
         # the ranks that wait while rank 0 times the CPU reference do so on a gloo side group with its own generous limit: the
         # baseline must not be able to cost the measured line through the 900 s limit of the data-path group
         wait_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
+        if not args.no_preflight:
+            box = [pre]
+            dist.broadcast_object_list(box, src=0)
+            pre = box[0]
+            if pre is not None and pre["form"] is None:
+                if rank == 0:
+                    print("bench.py: no exchange form passed the preflight: %s" % json.dumps(pre["tried"]), file=sys.stderr)
+                dist.destroy_process_group()
+                sys.exit(4)
+            if pre is not None:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import preflight_ranks
+                os.environ.update(preflight_ranks.form_env(pre["form"]))       # the form that passed (the requested one or a fall-back)
         # communicator set-up (lazy peer connections) is not a step: ShardedIndex runs a small all-to-all when it is
         # built and all ranks agree there (all-reduce) on the exchange form -- see mdir_amd/sharded.py
 
@@ -404,6 +494,9 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    selection = None
+    if world > 1 and pre is not None and pre.get("p2p_probe", {}).get("ok") and not sharded._p2p_on and sharded.storage == "f32":
+        selection = select_exchange(sharded, step, keep, dryrun, device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -568,11 +661,22 @@ def main():
         step_ms = [a.elapsed_time(b) for a, b in ev]
         extra["spread_over_timed_steps"] = {"step_ms": spread(step_ms), "value": spread([NQ / (t * 1e-3) for t in step_ms], 1), "steps": args.steps,
                                             "what": "rank 0: HIP events on its compute stream around every timed step (similarity, exchange wait, sort)"}
-        extra["comm"] = "mdx (C ABI: mdx_exchange_scores over RCCL)" if getattr(sharded, "_comm", None) is not None else "torch.distributed"
+        if pre is not None:
+            extra["preflight"] = {"form_that_passed": pre["form"], "seconds": pre.get("seconds"),
+                                  "tried": [{k: v for k, v in t.items() if k in ("form", "ok", "reason", "nranks_seen", "link_types", "exchange_used", "through", "seconds_in_ranks")}
+                                            for t in pre["tried"]],
+                                  "direct_store_probe": {k: v for k, v in pre.get("p2p_probe", {}).items() if k in ("ok", "reason", "nranks_seen", "seconds_in_ranks")} or None}
+        if selection is not None:
+            extra["exchange_selection"] = selection
+        extra["comm"] = ("p2p (C ABI: mdx_scores_p2p, direct stores into the owners' buffers + one flag per peer)" if getattr(sharded, "_p2p_on", False)
+                         else "mdx (C ABI: mdx_exchange_scores over RCCL)" if getattr(sharded, "_comm", None) is not None else "torch.distributed")
+        if getattr(sharded, "_p2p", None) is not None:
+            extra["p2p_late_peers"] = sharded._p2p.late_peers()
         extra["phases_ms_per_rank"] = {"scores": [round(float(x), 4) for x in table[:, 0]],
                                        "exchange_exposed": [round(float(x), 4) for x in table[:, 1]],
                                        "sort": [round(float(x), 4) for x in table[:, 2]],
-                                       "exchange": "all_to_all" if sharded._use_a2a else "all_gather", "chunks": sharded.chunks,
+                                       "exchange": "direct_store" if getattr(sharded, "_p2p_on", False) else ("all_to_all" if sharded._use_a2a else "all_gather"),
+                                       "chunks": sharded.chunks,
                                        "what": "last timed step; exchange_exposed = compute-stream wait for transfers after the last "
                                                "similarity kernel (+ re-block copy)"}
 

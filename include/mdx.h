@@ -38,7 +38,8 @@ extern "C" {
 /* 2: round 4's additions (mdx_index_bytes, mdx_index_create_in, mdx_scores_rowmajor, mdx_scores_ex / _workspace_ex,
  * mdx_rank_positions) and the stream synchronisation inside mdx_index_create* for fp32 shards (the shard maximum is read
  * back): a host built against version 1 must not load this library unnoticed. */
-#define MDX_ABI_VERSION 2
+/* 3: round 6's additions (the direct-store exchange: mdx_p2p_* and mdx_scores_p2p); nothing of version 2 changed. */
+#define MDX_ABI_VERSION 3
 
 typedef enum mdx_status {
     MDX_OK = 0,
@@ -459,6 +460,47 @@ int mdx_allgather_scores(mdx_comm *comm, const float *local, int64_t nq, const i
  * mdx_rank_full_segments(blocks, widths, G, nq_mine, 0, ...) then yields the rankings of this rank's queries with
  * GLOBAL row ids. */
 int mdx_exchange_scores(mdx_comm *comm, const float *local, int64_t nq, const int64_t *widths, float *mine, void *stream);
+
+/* ------------------------------------------------- direct-store exchange (no collective; hipIpc + xGMI stores) */
+
+/* The third form of the same exchange (round 6): the similarity kernel itself writes query q's run of scores into row
+ * q - qlo_owner of the OWNER's receive buffer, at the columns of this shard -- over xGMI, into memory the owner has shared with
+ * hipIpcGetMemHandle.  The transfer is spread over the kernel's run time, there is no collective launch, and the owner finds a
+ * DENSE [nq_mine, n_total] matrix (mdx_rank_full; no peer blocks).  A step is closed by one flag per peer.  Shards the same
+ * statement as above, `np.dot(vecs.T, qvecs)` (cirscore.py:69), for the query-split `np.argsort(-scores, axis=0)` (cirscore.py:70).
+ *
+ *   every rank, once:  mdx_p2p_create(&p, G, r, nq, n_total, handle)   (allocates 2 receive buffers of ceil(nq/G) x n_total fp32)
+ *                      gather the G handles (MDX_P2P_HANDLE_BYTES each, rank order) by any means
+ *                      mdx_p2p_connect(p, handles)                        (maps the peers' buffers; not a collective)
+ *   every step:        mdx_scores_p2p(index, queries, nq, ..., p, ...)  once per shard (or row chunk) this rank holds
+ *                      mdx_p2p_close_step(p, &mine, stream)             mine = this rank's queries x all rows, valid until the
+ *                                                                       step after next is opened by any peer
+ * Every rank must run the same steps with the same nq.  nq <= 128; fp32 shards; the shard's first global row is the index's
+ * row_offset.  HARDWARE STATUS: exercised with several rank processes on ONE GPU (same-device IPC); it has not run over xGMI --
+ * tools/preflight_ranks.py checks it on a multi-GPU node before bench.py uses it, and mdx_exchange_scores stays the default.
+ * Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) in the environment of every rank process. */
+typedef struct mdx_p2p mdx_p2p;
+#define MDX_P2P_HANDLE_BYTES 64
+/* handle_host: MDX_P2P_HANDLE_BYTES bytes, written.  MDX_ERR_RUNTIME with *out VALID when the buffer cannot be exported
+ * (then only mdx_p2p_connect_ptrs can connect it). */
+int mdx_p2p_create(mdx_p2p **out, int nranks, int rank, int64_t nq, int64_t n_total, void *handle_host);
+/* handles_host: nranks x MDX_P2P_HANDLE_BYTES bytes in rank order (this rank's own entry is not read). */
+int mdx_p2p_connect(mdx_p2p *p2p, const void *handles_host);
+/* Ranks that live in ONE process (threads, tests): the peers' mdx_p2p_base pointers instead of handles (host array of nranks). */
+int mdx_p2p_connect_ptrs(mdx_p2p *p2p, void *const *bases);
+void *mdx_p2p_base(mdx_p2p *p2p);
+int64_t mdx_p2p_bytes(const mdx_p2p *p2p);
+/* mdx_scores with the routed epilogue: scores[q, i] goes to row q - qlo_owner(q), column row_offset(index) + i of owner(q)'s
+ * receive buffer of the open step.  Same kernels, same k order, same bits as mdx_scores.  workspace: mdx_scores_workspace(nq, d). */
+int mdx_scores_p2p(const mdx_index *index, const float *queries, int64_t nq, int qlayout, const float *center, mdx_p2p *p2p,
+                   void *workspace, int64_t workspace_bytes, void *stream);
+/* Enqueues: raise this rank's flag of the step at every peer, wait for every peer's.  *mine = device pointer to this rank's
+ * [ceil(nq/G), n_total] buffer of the step (its first nq_mine rows are the queries mdx_query_bounds gives this rank). */
+int mdx_p2p_close_step(mdx_p2p *p2p, float **mine, void *stream);
+/* Synchronises `stream` and reads the status word: bit r set = a wait for peer r gave up after 20 s (results of that step are
+ * undefined).  0 = every step so far was closed by every peer. */
+int mdx_p2p_status(mdx_p2p *p2p, uint32_t *late_peers, void *stream);
+int mdx_p2p_destroy(mdx_p2p *p2p);
 
 #ifdef __cplusplus
 }

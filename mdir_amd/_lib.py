@@ -28,7 +28,7 @@ class MdxError(RuntimeError):
 _STATUS_EXC = {-1: ValueError, -2: MdxError, -3: MemoryError, -4: ValueError}
 
 _lib = None
-ABI_VERSION = 2        # include/mdx.h MDX_ABI_VERSION this binding was written against
+ABI_VERSION = 3        # include/mdx.h MDX_ABI_VERSION this binding was written against
 
 
 def build(force=False):
@@ -110,6 +110,15 @@ def _declare(lib):
         "mdx_query_bounds": (i32, [i64, i32, i32, pi64, pi64]),
         "mdx_allgather_scores": (i32, [p, p, i64, pi64, p, p]),
         "mdx_exchange_scores": (i32, [p, p, i64, pi64, p, p]),
+        "mdx_p2p_create": (i32, [pp, i32, i32, i64, i64, p]),
+        "mdx_p2p_connect": (i32, [p, p]),
+        "mdx_p2p_connect_ptrs": (i32, [p, pp]),
+        "mdx_p2p_base": (p, [p]),
+        "mdx_p2p_bytes": (i64, [p]),
+        "mdx_scores_p2p": (i32, [p, p, i64, i32, p, p, p, i64, p]),
+        "mdx_p2p_close_step": (i32, [p, pp, p]),
+        "mdx_p2p_status": (i32, [p, ctypes.POINTER(ctypes.c_uint32), p]),
+        "mdx_p2p_destroy": (i32, [p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
@@ -122,7 +131,9 @@ EXPORTS = ("mdx_abi_version", "mdx_last_error", "mdx_capture_recover", "mdx_rmac
            "mdx_index_create", "mdx_index_create_ex", "mdx_index_bytes", "mdx_index_create_in", "mdx_index_destroy", "mdx_index_info", "mdx_scores_workspace",
            "mdx_scores", "mdx_scores_rowmajor", "mdx_scores_workspace_ex", "mdx_scores_ex", "mdx_rank_workspace", "mdx_rank_full", "mdx_rank_full_segments", "mdx_topk", "mdx_rank_of", "mdx_rank_positions",
            "mdx_gather_scores", "mdx_rank_count", "mdx_conv1x1_transpose_weights", "mdx_conv1x1_bn_act", "mdx_clahe_workspace", "mdx_clahe_u8_to_chw", "mdx_gram_f64_workspace", "mdx_gram_f64", "mdx_project_f64_workspace", "mdx_project_f64", "mdx_l2n_cols_f64", "mdx_comm_unique_id", "mdx_comm_init",
-           "mdx_comm_destroy", "mdx_comm_info", "mdx_query_bounds", "mdx_allgather_scores", "mdx_exchange_scores")
+           "mdx_comm_destroy", "mdx_comm_info", "mdx_query_bounds", "mdx_allgather_scores", "mdx_exchange_scores",
+           "mdx_p2p_create", "mdx_p2p_connect", "mdx_p2p_connect_ptrs", "mdx_p2p_base", "mdx_p2p_bytes", "mdx_scores_p2p", "mdx_p2p_close_step",
+           "mdx_p2p_status", "mdx_p2p_destroy")
 
 
 def lib():

@@ -11,6 +11,9 @@ namespace mdx {
 
 void set_error(const char *fmt, ...);
 
+// mdx_p2p.hip: the row pointers of the open step of a connected direct-store exchange (false: not connected / another nq)
+bool p2p_route(const mdx_p2p *p, int64_t nq, float *const **rows);
+
 // mdx_rank.hip: decides once per device how the sort ranks inside a wave (may synchronise `s`); 0 = not decided (capturing)
 int probe_lds_order(hipStream_t s);
 

@@ -169,7 +169,7 @@ static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_
     const int64_t blocks = ceil_div(RT, (int64_t)4 * R);
     if constexpr (MM::STEPS == 4 && !RM) {
         if (route.rows) {           // routed epilogue (the shipped schedule of each shape: PIPE for 128-row workgroups)
-            auto kr = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, MM, QR, 4, false, R == 2, 4, true>;
+            auto kr = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, MM, QR, 4, false, (R == 2 ? 1 : 0), 4, true>;
             static bool opted_r[64];
             int rcr = lds_opt_in((const void *)kr, lds, opted_r);
             if (rcr != MDX_OK) return rcr;
@@ -186,11 +186,12 @@ static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_
         // the pipelined consumer (PIPE): MDX_SCORES_PIPE=0/1 picks the form per launch (A/B in one process: tools/chain_power_probe.py)
         const char *e = getenv("MDX_SCORES_PIPE");
         if (e ? e[0] == '1' : MDX_SCORES_PIPE_DEFAULT) {
-            auto kp = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, MM, QR, 4, RM, true>;
+            auto kp = scores_lc_kernel<QT, R, LC_KC, LC_NSTAGE, 2, MM, QR, 4, RM, 1>;
             static bool opted_p[64];
             int rcp = lds_opt_in((const void *)kp, lds, opted_p);
             if (rcp != MDX_OK) return rcp;
-            hipLaunchKernelGGL(kp, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid, ld);
+            hipLaunchKernelGGL(kp, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid, ld,
+                               (float *const *)nullptr, (int64_t)0);
             return MDX_OK;
         }
     }
@@ -198,7 +199,8 @@ static int launch_scores_lc(const f32x4 *db, const f32x4 *qt, float *out, int64_
     static bool opted[64];
     int rc = lds_opt_in((const void *)kern, lds, opted);
     if (rc != MDX_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid, ld);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)passes), dim3(512), lds, s, db, qt, out, n, KB, nq_valid, ld,
+                       (float *const *)nullptr, (int64_t)0);
     return MDX_OK;
 }
 
@@ -531,11 +533,34 @@ int64_t mdx_scores_workspace(int64_t nq, int64_t d)
     return round_up(nq, TILE_ROWS) * round_up(d, 64) * 4;   // fp32 tiles; an fp16 shard uses half of it
 }
 
+static int scores_impl(const mdx_index *ix, const float *queries, int64_t nq, int qlayout, const float *center, float *scores,
+                       Route route, void *workspace, int64_t workspace_bytes, void *stream);
+
 int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayout,
                const float *center, float *scores, void *workspace, int64_t workspace_bytes,
                void *stream)
 {
     MDX_CHECK_ARG(ix && queries && scores, "mdx_scores: NULL pointer");
+    return scores_impl(ix, queries, nq, qlayout, center, scores, Route{nullptr, 0}, workspace, workspace_bytes, stream);
+}
+
+int mdx_scores_p2p(const mdx_index *ix, const float *queries, int64_t nq, int qlayout, const float *center, mdx_p2p *p2p,
+                   void *workspace, int64_t workspace_bytes, void *stream)
+{
+    MDX_CHECK_ARG(ix && queries && p2p, "mdx_scores_p2p: NULL pointer");
+    MDX_CHECK_ARG(ix->storage == MDX_F32, "mdx_scores_p2p: an fp32 shard is needed (this one is stored as fp16)");
+    MDX_CHECK_ARG(nq > 0 && nq <= MAX_QT * TILE_ROWS, "mdx_scores_p2p: nq=%lld, 1..%d supported", (long long)nq, MAX_QT * TILE_ROWS);
+    float *const *rows = nullptr;
+    if (!p2p_route(p2p, nq, &rows)) {
+        set_error("mdx_scores_p2p: the exchange is not connected or was created for another number of queries");
+        return MDX_ERR_INVALID;
+    }
+    return scores_impl(ix, queries, nq, qlayout, center, nullptr, Route{rows, ix->row_offset}, workspace, workspace_bytes, stream);
+}
+
+static int scores_impl(const mdx_index *ix, const float *queries, int64_t nq, int qlayout, const float *center, float *scores,
+                       Route route, void *workspace, int64_t workspace_bytes, void *stream)
+{
     MDX_CHECK_ARG(nq > 0, "mdx_scores: nq=%lld must be positive", (long long)nq);
     MDX_CHECK_ARG(qlayout == MDX_DIM_MAJOR || qlayout == MDX_ROW_MAJOR, "mdx_scores: qlayout %d",
                   qlayout);
@@ -556,7 +581,7 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
     const int64_t full_passes = QT_total / MAX_QT;
     static const bool no_pass_grid = getenv("MDX_NO_PASS_GRID") != nullptr, no_query_split = getenv("MDX_NO_QUERY_SPLIT") != nullptr,
                       no_leftover = getenv("MDX_NO_LEFTOVER_MFMA") != nullptr;
-    if (full_passes > 1 && full_passes < 65536 && !no_pass_grid) {
+    if (full_passes > 1 && full_passes < 65536 && !no_pass_grid && !route.rows) {
         // many queries: all full groups of MAX_QT query tiles in ONE launch (grid.y = group), so that a
         // small database still fills the chip (20 000 rows are 313 workgroups per group)
         const int mode = (small ? 0 : 1) | (ix->storage == MDX_F16 ? 2 : 0);
@@ -572,7 +597,7 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
         // ONE query tile instead (grid.y = tile): 5x the workgroups, a fifth of the chain each.
         const int64_t blocks = ceil_div(ix->RT, (int64_t)4);
         if (small && blocks * QT_total <= 1024) {
-            rc = launch_qt<1>(0, ix->tiles, qtiles, scores, ix->n, ix->RT, (int)ix->KB, (int)nq, s, (int)QT_total);
+            rc = launch_qt<1>(0, ix->tiles, qtiles, scores, ix->n, ix->RT, (int)ix->KB, (int)nq, s, (int)QT_total, route);
             if (rc != MDX_OK) return rc;
             MDX_LAUNCH_CHECK();
             return MDX_OK;
@@ -583,13 +608,13 @@ int mdx_scores(const mdx_index *ix, const float *queries, int64_t nq, int qlayou
         const int64_t q0 = qt0 * TILE_ROWS;
         const int nq_valid = (int)((nq - q0) < qt * TILE_ROWS ? (nq - q0) : qt * TILE_ROWS);
         const f32x4 *qp = qtiles + qt0 * ix->KB * 64;
-        float *op = scores + q0 * ix->n;
+        float *op = route.rows ? nullptr : scores + q0 * ix->n;
         const int mode = (small ? 0 : 1) | (ix->storage == MDX_F16 ? 2 : 0);
         const int tail = nq_valid - (qt - 1) * TILE_ROWS;      // queries in the last tile of this launch
         if (mode == 1 && qt >= 2 && tail <= 8 && !no_leftover)
-            rc = dispatch_leftover(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+            rc = dispatch_leftover(qt, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s, route);
         else
-            rc = dispatch_qt(qt, mode, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s);
+            rc = dispatch_qt(qt, mode, ix->tiles, qp, op, ix->n, ix->RT, (int)ix->KB, nq_valid, s, route);
         if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK();
     }

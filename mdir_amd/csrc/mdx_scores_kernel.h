@@ -113,7 +113,7 @@ struct MmaF16 {                 // v_mfma_f32_16x16x32_f16: lane (g,j) element e
 // into this process (hipIpc), col0 = the shard's first global row.  The stores are system-scope (write-through: sc0 sc1), so that
 // nothing of them lingers in this XCD's L2 when the kernel ends and the step's flag goes out.  Same accumulators, same bits.
 template <int QT, int R, int KC, int NSTAGE, int DB_AUX = 0, typename MM = MmaF32, int QR = 0, int CWAVES = 4, bool RM = false,
-          bool PIPE = false, int LWAVES = 4, bool ROUTED = false>
+          int PIPE = 0, int LWAVES = 4, bool ROUTED = false>
 __global__ __launch_bounds__((CWAVES + LWAVES) * 64, ((R >= 4 || CWAVES > 4) ? 1 : 2)) void scores_lc_kernel(const f32x4 *__restrict__ db,
                                                            const f32x4 *__restrict__ qtiles,
                                                            float *__restrict__ out, int64_t n, int KB,
@@ -218,7 +218,7 @@ __global__ __launch_bounds__((CWAVES + LWAVES) * 64, ((R >= 4 || CWAVES > 4) ? 1
     const int l_row = 4 * (lane >> 3) + (lane & 3);             // row inside the wave's 32 rows
     const int l_boff = (l_row >> 4) * KC * 64 + (l_row & 15);   // f32x4 offset of (tile, row) inside the wave's tiles
 
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 1) {
         static_assert(MM::STEPS == 4 && (KC == 2 || KC == 1) && !RM, "pipelined consumer: fp32 tiles, one or two k-blocks per stage");
         // Registers: a full second operand set does not fit beside the accumulators and the leftover operands (128 registers per
         // wave at two workgroups per CU), so only what a block's FIRST MFMAs need is read ahead -- its database operands bn[] and

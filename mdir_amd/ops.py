@@ -463,6 +463,25 @@ class DescriptorIndex:
                                            _vp(ws.data_ptr()), need, mode, _stream()), "mdx_scores_ex")
         return out
 
+    def scores_p2p(self, queries, p2p, qlayout="DN", center=None):
+        """The similarity of ``scores`` with the ROUTED epilogue (``mdx_scores_p2p``): query q's scores against this shard's
+        rows go straight to row ``q - qlo_owner`` of the owner rank's receive buffer, at columns ``row_offset ..`` -- the
+        direct-store exchange of a row-sharded database (:class:`P2P`).  Nothing is returned: ``p2p.close_step()`` hands
+        out this rank's ``[nq_mine, n_total]`` matrix once every rank has written its part."""
+        if self._h is None:
+            raise RuntimeError("index is closed")
+        nq, d, lay = _layout(queries, qlayout, "queries")
+        if d != self.d:
+            raise ValueError("query dimension %d != index dimension %d" % (d, self.d))
+        if self.storage != "f32":
+            raise ValueError("the direct-store exchange multiplies an fp32 shard; this one is stored as %s" % self.storage)
+        qp = _dev(queries, torch.float32, "queries")
+        cp = _dev(center, torch.float32, "center") if center is not None else None
+        need = _lib.lib().mdx_scores_workspace(nq, d)
+        ws = _workspace(need, self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mdx_scores_p2p(self._h, qp, nq, lay, cp, p2p._h, _vp(ws.data_ptr()), need, _stream()), "mdx_scores_p2p")
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             h, self._h = self._h, None
@@ -790,3 +809,104 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+class _DeviceMemory:
+    """Library-owned device memory as something ``torch.as_tensor`` accepts (the CUDA array interface)."""
+
+    def __init__(self, ptr, shape, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner             # keeps the exchange (and with it the allocation) alive as long as the view is
+
+
+class P2P:
+    """The direct-store exchange of per-shard partial scores (``mdx_p2p_*``, include/mdx.h; round 6): every rank's
+    similarity kernel writes its scores straight into the receive buffers of the ranks that own the queries, over xGMI
+    (buffers shared with hipIpc); a step is closed by one flag per peer; the owner ranks a DENSE ``[nq_mine, n_total]`` matrix.
+
+    ``P2P.from_process_group(nq, n_total, device)`` builds and connects one over an initialised ``torch.distributed`` group
+    (the 64-byte handles are gathered through it -- the only use made of it); ``P2P(nranks, rank, nq, n_total)`` +
+    ``connect(handles)`` / ``connect_local(peers)`` take handles that travelled by other means / ranks living in this
+    process.  Every rank must run the same steps: ``index.scores_p2p(queries, p2p)`` for each of its shards or chunks, then
+    ``close_step()``."""
+
+    def __init__(self, nranks, rank, nq, n_total, device=None):
+        self._h = None
+        self.nranks, self.rank, self.nq, self.n_total = int(nranks), int(rank), int(nq), int(n_total)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.qlo, self.qhi = query_bounds(self.nq, self.nranks, self.rank)
+        buf = (ctypes.c_char * 64)()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            status = _lib.lib().mdx_p2p_create(ctypes.byref(h), self.nranks, self.rank, self.nq, self.n_total, buf)
+        self._h = h if h.value else None
+        self.exportable = status == 0
+        if status != 0 and self._h is None:
+            check(status, "mdx_p2p_create")
+        self.handle = bytes(buf.raw)
+        self.connected = False
+
+    @classmethod
+    def from_process_group(cls, nq, n_total, device, group=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        me = cls(world, rank, nq, n_total, device)
+        handles = [None] * world
+        if world > 1:
+            dist.all_gather_object(handles, (me.handle, me.exportable), group=group)
+            if not all(ok for _, ok in handles):
+                me.close()
+                raise _lib.MdxError("a rank could not export its receive buffer (hipIpcGetMemHandle): is HSA_ENABLE_IPC_MODE_LEGACY=0 set?")
+            me.connect([h for h, _ in handles])
+        else:
+            me.connect([me.handle])
+        return me
+
+    def connect(self, handles):
+        if len(handles) != self.nranks or any(len(h) != 64 for h in handles):
+            raise ValueError("need one 64-byte handle per rank")
+        blob = (ctypes.c_char * (64 * self.nranks)).from_buffer_copy(b"".join(bytes(h) for h in handles))
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mdx_p2p_connect(self._h, blob), "mdx_p2p_connect")
+        self.connected = True
+
+    def connect_local(self, peers):
+        """Ranks that live in ONE process: ``peers`` = the P2P objects of all ranks, in rank order."""
+        bases = (ctypes.c_void_p * self.nranks)(*[_lib.lib().mdx_p2p_base(q._h) for q in peers])
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mdx_p2p_connect_ptrs(self._h, bases), "mdx_p2p_connect_ptrs")
+        self.connected = True
+
+    def close_step(self):
+        """Enqueue the end of a step (raise my flag at every peer, wait for theirs) on the current stream; returns the
+        ``[nq_mine, n_total]`` similarities of MY queries against ALL rows -- a view of the receive buffer, valid until the
+        step after next (clone it to keep it longer)."""
+        mine = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mdx_p2p_close_step(self._h, ctypes.byref(mine), _stream()), "mdx_p2p_close_step")
+        rows = self.qhi - self.qlo
+        if rows == 0:
+            return torch.empty((0, self.n_total), dtype=torch.float32, device=self.device)
+        return torch.as_tensor(_DeviceMemory(mine.value, (rows, self.n_total), self), device=self.device)
+
+    def late_peers(self):
+        """Synchronises the current stream; bit r set = a wait for peer r gave up (20 s): that step's result is undefined."""
+        word = ctypes.c_uint32()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mdx_p2p_status(self._h, ctypes.byref(word), _stream()), "mdx_p2p_status")
+        return int(word.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            h, self._h = self._h, None
+            torch.cuda.synchronize(self.device)
+            check(_lib.lib().mdx_p2p_destroy(h), "mdx_p2p_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

@@ -241,7 +241,14 @@ class ShardedIndex:
             from . import ops
             self._comm = ops.Comm.from_process_group(self.device, group)
             self._comm_stream = torch.cuda.Stream(device=self.device)
-        self._use_a2a = self._probe_all_to_all()
+        # MDIR_AMD_COMM=p2p (bench.py --comm p2p): no collective at all -- the similarity kernel writes every query's scores
+        # straight into the owner rank's receive buffer (hipIpc mapping, xGMI stores; ops.P2P / mdx_scores_p2p) and one flag per
+        # peer closes the step; the owner ranks a dense [Q_mine, N] matrix.  Exact fp32 shards only.  The exchange object is
+        # built at the first step (it is sized by the number of queries); the process group only carries its 64-byte handles.
+        self._p2p_on = (os.environ.get("MDIR_AMD_COMM") == "p2p" and self.device.type == "cuda" and storage == "f32"
+                        and not self._score_kw)
+        self._p2p = None
+        self._use_a2a = True if self._p2p_on else self._probe_all_to_all()
 
     def _probe_all_to_all(self):
         """Decide the exchange form ONCE, identically on every rank: a tiny UNEVEN all_to_all_single is run and
@@ -386,6 +393,8 @@ class ShardedIndex:
         """Similarities of MY queries against ALL rows, as the column blocks the exchange delivers (global row order:
         peer-major, chunk-minor; block = ``[Q_mine, rows of that chunk]``): per chunk, similarity kernel then
         all-to-all, with chunk c's transfer overlapping chunk c+1's kernel."""
+        if self._p2p_on:
+            return self._exchanged_p2p(queries, qlayout)
         if self.world == 1 and self._comm is None:
             s = self.local_scores(queries, qlayout)
             return [s], (0, s.shape[0])
@@ -406,6 +415,38 @@ class ShardedIndex:
             ev[2].record()                                # the compute stream has waited for the last transfer
         # global row order: peer-major, chunk-minor
         return [per_chunk[c][r] for r in range(self.world) for c in range(self.chunks)], (qlo, qhi)
+
+    def use_direct_store(self, on):
+        """Switch the exchange of ``rank_queries`` between the direct-store form and the collective one at run time (every rank
+        must make the same call between the same steps).  Exact fp32 shards only."""
+        if on and (self.storage != "f32" or self._score_kw or self.device.type != "cuda"):
+            raise ValueError("the direct-store exchange needs an exact fp32 shard on the GPU")
+        self._p2p_on = bool(on)
+        self.phases = None
+
+    def _exchanged_p2p(self, queries, qlayout):
+        """The direct-store form: every chunk's similarity kernel writes to the owners' buffers, one flag per peer closes the
+        step, and MY queries' rows of ALL shards are one dense matrix (a view of the receive buffer, valid for two steps;
+        cloned unless ``reuse_buffers``)."""
+        from . import ops
+        nq = queries.shape[1] if qlayout in ("DN", "dim_major") else queries.shape[0]
+        if self._p2p is None or self._p2p.nq != nq:
+            if self._p2p is not None:
+                self._p2p.close()
+            self._p2p = ops.P2P.from_process_group(nq, self.n_total, self.device, self.group)
+        ev = self._events()
+        if ev:
+            ev[0].record()
+        for _, _, ix in self.parts:
+            ix.scores_p2p(queries, self._p2p, qlayout)
+        if ev:
+            ev[1].record()
+        mine = self._p2p.close_step()
+        if ev:
+            ev[2].record()
+        if not self.reuse_buffers:
+            mine = mine.clone()
+        return [mine], query_bounds(nq, self.world, self.rank)
 
     def rank_queries(self, queries, qlayout="DN"):
         """Exact full ranking, query-partitioned: returns ``(ranks [Q_mine, N] int64 with GLOBAL ids,
@@ -428,7 +469,7 @@ class ShardedIndex:
 
     def _events(self):
         """Four events on the compute stream around the phases of ``rank_queries`` (GPU only)."""
-        if self.device.type != "cuda" or (self.world == 1 and self._comm is None):
+        if self.device.type != "cuda" or (self.world == 1 and self._comm is None and not self._p2p_on):
             self.phases = None
         elif self.phases is None:
             self.phases = [torch.cuda.Event(enable_timing=True) for _ in range(4)]

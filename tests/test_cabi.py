@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(handle, name), name
     assert set(_declared()) == set(_lib.EXPORTS)
-    assert handle.mdx_abi_version() == _lib.ABI_VERSION == 2
+    assert handle.mdx_abi_version() == _lib.ABI_VERSION == 3
     # pure host-side helpers may be called without a GPU
     assert handle.mdx_scores_workspace(70, 2048) == 80 * 2048 * 4
     assert handle.mdx_scores_workspace(0, 2048) == 0

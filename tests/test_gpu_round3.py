@@ -106,7 +106,7 @@ def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts two rank processes itself (here both on this
     one GPU over gloo: MDIR_AMD_DRYRUN_ONE_GPU, a functional dry run) and prints rank 0's one line; the sharded
     evaluation gives the single-process mAP."""
-    common = ["--rows", "200000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--extract-images", "0"]
+    common = ["--rows", "200000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-preflight", "--extract-images", "0"]
     one = _bench(common, {})
     two = _bench(["--gpus", "2"] + common, {"MDIR_AMD_DRYRUN_ONE_GPU": "1"})
     assert two["n_gpus"] == 2 and two["nranks_seen"] == 2

@@ -149,7 +149,7 @@ def one_rank_line():
     return _bench(["--rows", "200000", "--steps", "3", "--warmup", "1", "--no-secondary", "--no-pipelined", "--extract-images", "0"], {})
 
 
-@pytest.mark.parametrize("form", ["all_to_all", "all_gather", "all_to_all_chunks2"])
+@pytest.mark.parametrize("form", ["all_to_all", "all_gather", "all_to_all_chunks2", "p2p"])
 def test_bench_with_eight_ranks_on_one_gpu(form, one_rank_line):
     """`bench.py --gpus 8` as the driver will launch it, here with all eight rank processes on this GPU over gloo
     (MDIR_AMD_DRYRUN_ONE_GPU: functional, never a measurement): the real kernels on eight shards, the query-split exchange
@@ -160,14 +160,17 @@ def test_bench_with_eight_ranks_on_one_gpu(form, one_rank_line):
         env["MDIR_AMD_EXCHANGE"] = "allgather"
     if form == "all_to_all_chunks2":
         env["MDIR_AMD_EXCHANGE_CHUNKS"] = "2"
-    line = _bench(["--gpus", "8", "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-secondary", "--extract-images", "0"], env)
+    more = ["--comm", "p2p"] if form == "p2p" else []        # round 6: the direct-store exchange (same-device hipIpc here)
+    line = _bench(["--gpus", "8", "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-secondary", "--no-preflight", "--extract-images", "0"] + more, env)
     one = one_rank_line
     assert line["n_gpus"] == 8 and line["nranks_seen"] == 8 and "DRY RUN" in line["data"]
     assert line["config"]["workload"].startswith("configs[3]") and "x8" in line["config"]["workload"]
     assert one["config"]["workload"].startswith("configs[2]")
     assert line["config"]["db_rows_per_gpu"] == 25000
     assert line["map_medium"] == one["map_medium"]
-    assert line["phases_ms_per_rank"]["exchange"] == ("all_gather" if form == "all_gather" else "all_to_all")
+    assert line["phases_ms_per_rank"]["exchange"] == {"all_gather": "all_gather", "p2p": "direct_store"}.get(form, "all_to_all")
+    if form == "p2p":
+        assert line["comm"].startswith("p2p") and line["p2p_late_peers"] == 0
     assert line["phases_ms_per_rank"]["chunks"] == (2 if form == "all_to_all_chunks2" else 1)
     assert len(line["phases_ms_per_rank"]["scores"]) == 8 and "ranking_verified_on_device" in line
     for ln in (line, one):

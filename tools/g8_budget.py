@@ -1,8 +1,10 @@
 """What ONE rank does per step at G = 8 (n_local = 125 625 of 1 004 993 rows, 9 of 70 queries), measured on one GPU with the
 real kernels; the exchange cannot run here (one GPU per box) and enters as a stated model.  Writes the table of
-profiles/r05_g8_budget.md.
+profiles/r06_g8_budget.md (round 5's table: profiles/r05_g8_budget.md).  Round 6 adds the direct-store
+form: the same similarity launches with the ROUTED epilogue (stores into eight receive buffers -- all in THIS GPU's memory here,
+so what is measured is the kernel-side cost of routing, not xGMI) and the dense ranking it leads to.
 
-    python tools/g8_budget.py [--md profiles/r05_g8_budget.md]
+    python tools/g8_budget.py [--md profiles/r06_g8_budget.md]
 """
 import os
 import sys
@@ -44,8 +46,8 @@ def main():
     # --- similarity of the shard: one launch, and the shard cut into chunks (each chunk its own index and launch, as ShardedIndex does)
     cuts = {"1 launch": [(0, n_local)],
             "2 chunks, halving (4/6, 2/6)": [(0, n_local * 2 // 3), (n_local * 2 // 3, n_local)],
-            "2 chunks, equal": [(a - lo, b - lo) for a, b in chunk_bounds(lo, hi, 2)],        # what ShardedIndex does at G = 8 (round 5)
-            "2 chunks, first = one full round of 512 workgroups (65 536 rows)": [(0, 65536), (65536, n_local)],
+            "2 chunks, equal": [(0, n_local // 2), (n_local // 2, n_local)],        # what ShardedIndex did at G = 8 in round 5
+            "2 chunks, first = one full round of 512 workgroups (65 536 rows)": [(a - lo, b - lo) for a, b in chunk_bounds(lo, hi, 2)],   # round 6: what ShardedIndex does
             "3 chunks, halving (4/7, 2/7, 1/7)": [(0, n_local * 4 // 7), (n_local * 4 // 7, n_local * 6 // 7), (n_local * 6 // 7, n_local)]}
     sims = {}
     for name, pieces in cuts.items():
@@ -59,6 +61,23 @@ def main():
         sims[name] = (timed(all_chunks), per, [b - a for a, b in pieces])
         for ix in ixs:
             ix.close()
+    # --- the direct-store form: the shipped cut with the routed epilogue, eight receive buffers (ranks in one process: all local memory)
+    peers = [ops.P2P(G, r, NQ, N, dev) for r in range(G)]
+    for pp in peers:
+        pp.connect_local(peers)
+    ixs = [ops.DescriptorIndex(rows[a - lo:b - lo].contiguous(), "ND", a) for a, b in chunk_bounds(lo, hi, 2)]
+
+    def routed():
+        for ix in ixs:
+            ix.scores_p2p(q, peers[0], "ND")
+    t_routed = timed(routed)
+    one_ix = ops.DescriptorIndex(rows, "ND", lo)
+    t_routed_one = timed(lambda: one_ix.scores_p2p(q, peers[0], "ND"))
+    mine = peers[0].close_step()                    # (one rank alone here: nothing to wait for; its rows hold this shard's columns)
+    want = ixs[0].scores(q, "ND")
+    routed_equal = bool(torch.equal(mine[:, :want.shape[1]], want[:mine.shape[0]]))
+    for ix in ixs + [one_ix]:
+        ix.close()
     # --- the sort of this rank's 9 queries over all N rows, read from the peer blocks in place (8 x chunks segments)
     sorts = {}
     full = torch.randn((nq_mine, N), generator=g, device=dev) * 0.022
@@ -78,8 +97,8 @@ def main():
     model = {"optimistic (0.7 of the 7 links, 30 us)": 0.03 + sent / (7 * 153e9 * 0.7) * 1e3,
              "honest (uneven pieces, half the link rate, 80 us of RCCL launch + sync)": 0.08 + sent / (7 * 153e9 * 0.5) * 1e3,
              "pessimistic (a quarter of the link rate, 100 us)": 0.10 + sent / (7 * 153e9 * 0.25) * 1e3}
-    one = 3.44          # the single-GPU step of this round's bench line (similarity 2.62 + ranking 0.82 ms)
-    lines = ["# r05: the G = 8 budget of one rank (VERDICT round 4, item 2c)", "",
+    one = 3.44          # the single-GPU step (similarity 2.62 + ranking 0.82 ms; profiles/r05_bench_line.json, unchanged kernels)
+    lines = ["# r06: the G = 8 budget of one rank (VERDICT round 5, item 1)", "",
              "`tools/g8_budget.py` on one MI355X: rank 0's work of a step of `bench.py --gpus 8` -- the similarity of 70 queries against its "
              "%d-row shard and the exact sort of its %d queries over all %d rows -- with the real kernels; the exchange "
              "(%.1f MB sent per rank, one piece per peer link) is a MODEL, three of them.  Nothing here is a scaling measurement." % (n_local, nq_mine, N, sent / 1e6), "",
@@ -115,6 +134,18 @@ def main():
             step = t + exposed + sorts[chunks]
             cells.append("%.3f exposed, %.3f (%.2fx)" % (exposed, step, one / step) if chunks > 1 else "%.3f (%.2fx)" % (step, one / step))
         lines.append("| %s | %.3f | %s |" % (mname, t_x, " | ".join(cells)))
+    best = sims["2 chunks, first = one full round of 512 workgroups (65 536 rows)"][0]
+    lines += ["", "## Direct-store form (`--comm p2p`: `mdx_scores_p2p`, no collective)", "",
+              "The same two launches with the routed epilogue (every query's run goes to its owner's receive buffer; here all eight buffers "
+              "are in this GPU's memory, so this is the kernel-side cost of routing and of write-through stores, not xGMI): **%.3f ms** "
+              "(collective form's plain stores: %.3f); as one launch %.3f.  Routed scores bit-equal to `mdx_scores`: %s.  The owner then "
+              "ranks a DENSE [9, N] matrix: **%.3f ms**.  A step = similarity + one flag per peer (a 64-lane kernel: store, then spin on "
+              "seven lines; modelled 0.015 ms + one xGMI round trip) + dense ranking:" % (t_routed, best, t_routed_one, routed_equal, dense), "",
+              "| | per-rank compute ms | step ms | speed-up over %.2f ms |" % one, "|---|---|---|---|",
+              "| direct-store, flag closed in 0.02 ms | %.3f | %.3f | %.2fx |" % (t_routed + dense, t_routed + dense + 0.02, one / (t_routed + dense + 0.02)),
+              "| direct-store, flag closed in 0.05 ms (stores still draining over the links) | %.3f | %.3f | %.2fx |"
+              % (t_routed + dense, t_routed + dense + 0.05, one / (t_routed + dense + 0.05)),
+              "| collective (2 chunks, honest model above) | %.3f | see table | |" % (best + sorts[2])]
     text = "\n".join(lines) + "\n"
     print(text)
     if "--md" in sys.argv:
