@@ -201,9 +201,95 @@ def _alexnet_features():
     return mods[:-1]   # imageretrievalnet.py:168-169
 
 
-# imageretrievalnet.py:58-75 (densenet / squeezenet are not re-declared here)
+# ---- DenseNet / SqueezeNet (imageretrievalnet.py:73-78, 175-180; round 6).  torchvision's module names, so that a reference
+# state_dict loads unchanged: features.4.denselayer1.norm1.weight, features.5.conv.weight, features.3.squeeze.weight ...
+class _DenseLayer(nn.Module):
+    def __init__(self, cin, growth, bn_size):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(cin, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, padding=1, bias=False)
+
+    def forward(self, feats):
+        x = torch.cat(feats, 1) if isinstance(feats, (list, tuple)) else feats
+        x = self.conv1(self.relu1(self.norm1(x)))
+        return self.conv2(self.relu2(self.norm2(x)))
+
+
+class _DenseBlock(nn.ModuleDict):
+    def __init__(self, layers, cin, growth, bn_size):
+        super().__init__()
+        for i in range(layers):
+            self.add_module("denselayer%d" % (i + 1), _DenseLayer(cin + i * growth, growth, bn_size))
+
+    def forward(self, x):
+        feats = [x]
+        for layer in self.values():
+            feats.append(layer(feats))
+        return torch.cat(feats, 1)
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("norm", nn.BatchNorm2d(cin))
+        self.add_module("relu", nn.ReLU(inplace=True))
+        self.add_module("conv", nn.Conv2d(cin, cout, 1, bias=False))
+        self.add_module("pool", nn.AvgPool2d(2, 2))
+
+
+_DENSENET = {"densenet121": (32, (6, 12, 24, 16), 64), "densenet169": (32, (6, 12, 32, 32), 64),
+             "densenet201": (32, (6, 12, 48, 32), 64), "densenet161": (48, (6, 12, 36, 24), 96)}
+
+
+def _densenet_features(arch):
+    growth, blocks, c = _DENSENET[arch]
+    mods = [nn.Conv2d(3, c, 7, 2, 3, bias=False), nn.BatchNorm2d(c), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)]
+    for i, layers in enumerate(blocks):
+        mods.append(_DenseBlock(layers, c, growth, 4))
+        c += layers * growth
+        if i != len(blocks) - 1:
+            mods.append(_Transition(c, c // 2))
+            c //= 2
+    # children of torchvision's `features` (... norm5) + a ReLU: imageretrievalnet.py:175-177
+    return mods + [nn.BatchNorm2d(c), nn.ReLU(inplace=True)]
+
+
+class _Fire(nn.Module):
+    def __init__(self, cin, squeeze, e1, e3):
+        super().__init__()
+        self.squeeze = nn.Conv2d(cin, squeeze, 1)
+        self.squeeze_activation = nn.ReLU(inplace=True)
+        self.expand1x1 = nn.Conv2d(squeeze, e1, 1)
+        self.expand1x1_activation = nn.ReLU(inplace=True)
+        self.expand3x3 = nn.Conv2d(squeeze, e3, 3, padding=1)
+        self.expand3x3_activation = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        x = self.squeeze_activation(self.squeeze(x))
+        return torch.cat([self.expand1x1_activation(self.expand1x1(x)), self.expand3x3_activation(self.expand3x3(x))], 1)
+
+
+def _squeezenet_features(arch):
+    pool = lambda: nn.MaxPool2d(3, 2, ceil_mode=True)
+    if arch == "squeezenet1_0":
+        return [nn.Conv2d(3, 96, 7, 2), nn.ReLU(inplace=True), pool(), _Fire(96, 16, 64, 64), _Fire(128, 16, 64, 64), _Fire(128, 32, 128, 128),
+                pool(), _Fire(256, 32, 128, 128), _Fire(256, 48, 192, 192), _Fire(384, 48, 192, 192), _Fire(384, 64, 256, 256), pool(),
+                _Fire(512, 64, 256, 256)]
+    # all children of torchvision's `features`: imageretrievalnet.py:178-179
+    return [nn.Conv2d(3, 64, 3, 2), nn.ReLU(inplace=True), pool(), _Fire(64, 16, 64, 64), _Fire(128, 16, 64, 64), pool(),
+            _Fire(128, 32, 128, 128), _Fire(256, 32, 128, 128), pool(), _Fire(256, 48, 192, 192), _Fire(384, 48, 192, 192),
+            _Fire(384, 64, 256, 256), _Fire(512, 64, 256, 256)]
+
+
+# imageretrievalnet.py:58-78
 OUTPUT_DIM = {"alexnet": 256, "vgg11": 512, "vgg13": 512, "vgg16": 512, "vgg19": 512, "resnet18": 512,
-              "resnet34": 512, "resnet50": 2048, "resnet101": 2048, "resnet152": 2048}
+              "resnet34": 512, "resnet50": 2048, "resnet101": 2048, "resnet152": 2048,
+              "densenet121": 1024, "densenet169": 1664, "densenet201": 1920, "densenet161": 2208,
+              "squeezenet1_0": 512, "squeezenet1_1": 512}
 
 
 def build_features(architecture):
@@ -214,4 +300,8 @@ def build_features(architecture):
         return _vgg_features(architecture)
     if architecture in _RESNET:
         return _resnet_features(architecture)
+    if architecture in _DENSENET:
+        return _densenet_features(architecture)
+    if architecture in ("squeezenet1_0", "squeezenet1_1"):
+        return _squeezenet_features(architecture)
     raise ValueError("Unsupported or unknown architecture: {}!".format(architecture))

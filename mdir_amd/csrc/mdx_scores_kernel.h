@@ -1,6 +1,7 @@
 // The similarity kernel of libmdx.so: ONE form, no compile-time forks.  The timing-only variants that earlier rounds measured
-// (no LDS-DMA beside the MFMAs, no ds_read, no epilogue, the same rows from the L2, in-kernel time stamps, the blocked shard
-// order) are a patch on this file, tools/ablate/scores_kernel_ablate.patch, applied to a scratch copy by tools/scores_where.sh.
+// (no LDS-DMA beside the MFMAs, no ds_read, no epilogue, the same rows from the L2, the blocked shard order) are a patch on this
+// file -- tools/ablate/scores_kernel_ablate.patch, regenerated from these sources by tools/ablate/make_patch.py and applied to a
+// scratch copy by tools/scores_where.sh; round 6's two-loader-wave experiment is tools/ablate/scores_lw2.patch.
 #pragma once
 #include "mdx_common.h"
 

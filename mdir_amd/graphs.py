@@ -56,6 +56,14 @@ def parallel_map(fn, items):
 # (measured, torch 2.10 / ROCm 7.0: tests/test_gpu_round5.py).  So a refusal switches captures off for the rest of the process;
 # graphs captured before it keep replaying, everything else runs eagerly -- slower, never different.
 _captures_off = False
+_refusals = 0
+
+
+def capture_stats():
+    """``{"captures_off": bool, "refusals": int}`` of this process: after ONE refused capture every later shape stays eager (PyTorch
+    aborts on the next capture_begin after a failed one) -- a throughput cliff that must show in results, not only in a warning
+    (ADVICE round 5); bench.py puts it into `descriptors_per_s`."""
+    return {"captures_off": bool(_captures_off), "refusals": int(_refusals)}
 
 
 class _Entry:
@@ -131,13 +139,21 @@ class ShapeGraphs:
             # during capture"): torch.cuda.graph.__exit__ raises out of capture_end() BEFORE it restores the stream context, so
             # this thread's current stream is still the (invalidated) capture stream; that stream may still be capturing; and
             # HIP's per-thread last-error is set.  Put the stream back, end the capture, clear the error.
+            # (`stream_ctx` / `capture_stream` are private attributes of torch.cuda.graph: on a PyTorch without them the recovery
+            # falls back to the public calls -- the original capture error must never be replaced by an AttributeError here)
             from . import _lib
             if torch.cuda.current_stream() != before:
+                stream_ctx = getattr(ctx, "stream_ctx", None)
                 try:
-                    ctx.stream_ctx.__exit__(None, None, None)
+                    if stream_ctx is None:
+                        raise AttributeError("stream_ctx")
+                    stream_ctx.__exit__(None, None, None)
                 except Exception:
                     torch.cuda.set_stream(before)
-            for stream in {ctx.capture_stream, before}:
+            streams = {before}
+            if getattr(ctx, "capture_stream", None) is not None:
+                streams.add(ctx.capture_stream)
+            for stream in streams:
                 _lib.lib().mdx_capture_recover(ctypes.c_void_p(stream.cuda_stream))
             torch.cuda.synchronize()
             # ... and PyTorch's random generator of the device was told that a capture began and never that it ended (the same
@@ -149,8 +165,9 @@ class ShapeGraphs:
             except Exception:                       # older / newer PyTorch without the graph-safe state API: nothing to repair with
                 pass
             self.refused.add(key)
-            global _captures_off
+            global _captures_off, _refusals
             _captures_off = True
+            _refusals += 1
             warnings.warn("hipGraph capture refused for input shape %s (%s); this and every further shape of the process stay eager"
                           % (key[0], err))
             return None

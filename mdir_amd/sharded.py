@@ -225,6 +225,11 @@ class ShardedIndex:
             self.parts.append((a, b, self.backend.make_index(piece, layout, a, storage) if storage != "f32"
                                else self.backend.make_index(piece, layout, a)))
         self.index = self.parts[0][2] if self.chunks == 1 else None
+        # the direct-store exchange wants the shard as ONE launch (its transfer is spread over the kernel by construction, and
+        # every launch ends by draining its write-through stores: two chunks 0.370 ms, one launch 0.343, profiles/r06_g8_budget.md):
+        # a whole-shard index is built on first use from the caller's matrix (kept by reference, not copied)
+        self._whole = self.index
+        self._local = (local_vecs, layout)
         # RCCL moves device buffers directly; under gloo (CPU tests, or several ranks
         # sharing one GPU for a dry run) collectives are staged through host memory.
         self._host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and self.device.type == "cuda")
@@ -437,8 +442,9 @@ class ShardedIndex:
         ev = self._events()
         if ev:
             ev[0].record()
-        for _, _, ix in self.parts:
-            ix.scores_p2p(queries, self._p2p, qlayout)
+        if self._whole is None:
+            self._whole = self.backend.make_index(self._local[0], self._local[1], self.lo)
+        self._whole.scores_p2p(queries, self._p2p, qlayout)
         if ev:
             ev[1].record()
         mine = self._p2p.close_step()

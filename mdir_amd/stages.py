@@ -261,6 +261,7 @@ def paste_pca_normalize(params, data, device="cuda"):
     if data[0].shape == (0,):
         return {}, data[0]
     value = np.concatenate(data, axis=1)
+    in_dtype = value.dtype
     if dimensions:
         resources = ResourceUsage()
         time0 = time.time()
@@ -270,6 +271,8 @@ def paste_pca_normalize(params, data, device="cuda"):
         vecs = eigvec[:, -dimensions:].contiguous()
         proj = ops.project_f64(ops.gram_f64(vecs), vt)                   # (V V^T) value^T  -> [D, N]
         value = proj.t().contiguous().cpu().numpy()
+        if in_dtype in (np.float32, np.float64):
+            value = value.astype(in_dtype, copy=False)                   # upstream's statements run in the dtype of their input
         metadata = {"timings": {"pca_compute": round(time.time() - time0, 2)},
                     "resource_usage": resources.take_current_stats().get_resources()}
     else:

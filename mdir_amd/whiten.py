@@ -92,6 +92,15 @@ def _inverse_lower(L, device):
     return torch.linalg.solve_triangular(Ld, torch.eye(Ld.shape[0], dtype=torch.float64, device=Ld.device), upper=False)
 
 
+def _like_input(t, X):
+    """The float64 result in the dtype numpy would have given the reference: its statements run in the dtype of ``X`` (float32
+    descriptors -> float32 ``m`` / ``P``, and with them a float32 ``.lw.pkl`` and float32 whitened descriptors downstream:
+    cirtorch_format/test.py:241-268).  Computed in float64 here either way; float64 in, float64 out."""
+    a = t.cpu().numpy()
+    dt = np.asarray(X).dtype
+    return a.astype(dt, copy=False) if dt in (np.float32, np.float64) else a
+
+
 def pcawhitenlearn(X, shrink=None, device="cuda"):
     """PCA whitening without annotations (``whiten.py:14-35``): returns ``(m, P)``.  The descriptors go to the device once;
     mean, covariance (``mdx_gram_f64`` with the centring fused), eigen-decomposition and scaling happen there."""
@@ -105,7 +114,7 @@ def pcawhitenlearn(X, shrink=None, device="cuda"):
         b = eigval[shrink - 1]
         eigval = (1 - b) * eigval + b
     P = (1.0 / torch.sqrt(eigval))[:, None] * eigvec.t()       # inv(sqrt(diag(eigval))) @ eigvec.T
-    return m.cpu().numpy(), P.cpu().numpy()
+    return _like_input(m, X), _like_input(P, X)
 
 
 def whitenlearn(X, qidxs, pidxs, device="cuda"):
@@ -129,4 +138,4 @@ def whitenlearn(X, qidxs, pidxs, device="cuda"):
     del df
     _, eigvec = _eigh_descending(D)
     P = ops.project_f64(eigvec.t().contiguous(), P.contiguous())     # np.dot(eigvec.T, P)
-    return m.cpu().numpy(), P.cpu().numpy()
+    return _like_input(m, X), _like_input(P, X)

@@ -949,3 +949,34 @@ def test_dict_dataset_scores_like_the_official_branch(fops, tmp_path, monkeypatc
     assert set(rows_b[1][3]) == {"map"} and 0.0 < rows_b[1][3]["map"] <= 1.0
     assert [r[3] for r in rows_a[1:]] == [r[3] for r in rows_b[1:]]
     assert capsys.readouterr().out.count(">> oxford5k: mAP") == 2
+
+
+@pytest.mark.parametrize("arch,dim,params,keys", [
+    ("densenet121", 1024, 6953856, ["features.0.weight", "features.4.denselayer1.norm1.weight", "features.4.denselayer6.conv2.weight",
+                                    "features.5.norm.running_mean", "features.5.conv.weight", "features.10.denselayer16.conv1.weight",
+                                    "features.11.weight"]),
+    ("densenet169", 1664, 12484480, ["features.8.denselayer32.conv2.weight", "features.10.denselayer32.norm2.bias"]),
+    ("densenet201", 1920, 18092928, ["features.8.denselayer48.conv2.weight"]),
+    ("densenet161", 2208, 26472000, ["features.0.weight", "features.10.denselayer24.conv2.weight"]),
+    ("squeezenet1_0", 512, 735424, ["features.0.bias", "features.3.squeeze.weight", "features.10.expand1x1.weight", "features.12.expand3x3.bias"]),
+    ("squeezenet1_1", 512, 722496, ["features.0.weight", "features.3.squeeze.weight", "features.6.expand3x3.weight", "features.12.expand3x3.bias"])])
+def test_densenet_and_squeezenet_trunks_of_init_network(arch, dim, params, keys):
+    """`init_network` for the `densenet*` / `squeezenet*` architectures (imageretrievalnet.py:73-78, 175-180): the torch-only
+    re-declaration has torchvision's module names (a reference state_dict loads unchanged: the listed keys exist), EXACTLY the
+    parameter count torchvision publishes for the convolutional part of each model (total minus its classifier), the channel
+    count of OUTPUT_DIM, and -- DenseNet -- the ReLU the reference appends after `norm5`."""
+    import torch.nn as nn
+    from mdir_amd.backbones import OUTPUT_DIM, build_features
+    from mdir_amd.networks import init_network
+    mods = build_features(arch)
+    assert sum(p.numel() for p in nn.Sequential(*mods).parameters()) == params and OUTPUT_DIM[arch] == dim
+    assert isinstance(mods[-1], nn.ReLU) == arch.startswith("densenet")
+    net = init_network({"architecture": arch, "pooling": "mac", "whitening": False, "pretrained": False}).eval()
+    have = set(net.state_dict())
+    assert all(k in have for k in keys), [k for k in keys if k not in have]
+    assert net.meta["outputdim"] == dim and net.meta["architecture"] == arch
+    with torch.no_grad():
+        f = net.features(torch.rand(1, 3, 70, 93))
+    assert f.shape[1] == dim and bool((f >= 0).all())
+    with pytest.raises(ValueError):
+        build_features("densenet999")

@@ -291,7 +291,8 @@ def measure_list(arch="resnet101", workers=8, short=12, mid=40, long=64):
                          "algorithmic_flops_per_image": flops, "traffic": None,
                          "what": "2 x multiply-adds of every convolution of the three scales (hooks on an eager pass, mean of three of the 16 sizes) "
                                  "x images / wall time of the whole warm list (loader, graph captures, tail and whitening included in the time)"},
-            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}
+            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"),
+            "graph_captures": __import__("mdir_amd.graphs", fromlist=["capture_stats"]).capture_stats()}
 
 
 def cpu_reference_loop(arch="resnet101", images=8, size=(768, 1024), budget_s=40.0):

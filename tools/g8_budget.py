@@ -136,16 +136,19 @@ def main():
         lines.append("| %s | %.3f | %s |" % (mname, t_x, " | ".join(cells)))
     best = sims["2 chunks, first = one full round of 512 workgroups (65 536 rows)"][0]
     lines += ["", "## Direct-store form (`--comm p2p`: `mdx_scores_p2p`, no collective)", "",
-              "The same two launches with the routed epilogue (every query's run goes to its owner's receive buffer; here all eight buffers "
-              "are in this GPU's memory, so this is the kernel-side cost of routing and of write-through stores, not xGMI): **%.3f ms** "
-              "(collective form's plain stores: %.3f); as one launch %.3f.  Routed scores bit-equal to `mdx_scores`: %s.  The owner then "
-              "ranks a DENSE [9, N] matrix: **%.3f ms**.  A step = similarity + one flag per peer (a 64-lane kernel: store, then spin on "
-              "seven lines; modelled 0.015 ms + one xGMI round trip) + dense ranking:" % (t_routed, best, t_routed_one, routed_equal, dense), "",
+              "The similarity with the routed epilogue (every query's run goes to its owner's receive buffer; here all eight buffers "
+              "are in this GPU's memory, so this is the kernel-side cost of routing and of write-through stores, not xGMI): the shard as "
+              "ONE launch **%.3f ms** (what `ShardedIndex` runs in this form: the transfer is spread over the kernel by construction), as "
+              "the collective form's two chunks %.3f (every launch ends by draining its stores; plain stores: %.3f).  Routed scores "
+              "bit-equal to `mdx_scores`: %s.  The owner then ranks a DENSE [9, N] matrix: **%.3f ms**.  A step = similarity + one flag "
+              "per peer (a 64-lane kernel: store, then spin on seven lines; modelled) + dense ranking:" % (t_routed_one, t_routed, best, routed_equal, dense), "",
               "| | per-rank compute ms | step ms | speed-up over %.2f ms |" % one, "|---|---|---|---|",
-              "| direct-store, flag closed in 0.02 ms | %.3f | %.3f | %.2fx |" % (t_routed + dense, t_routed + dense + 0.02, one / (t_routed + dense + 0.02)),
+              "| direct-store, flag closed in 0.02 ms | %.3f | %.3f | %.2fx |" % (t_routed_one + dense, t_routed_one + dense + 0.02, one / (t_routed_one + dense + 0.02)),
               "| direct-store, flag closed in 0.05 ms (stores still draining over the links) | %.3f | %.3f | %.2fx |"
-              % (t_routed + dense, t_routed + dense + 0.05, one / (t_routed + dense + 0.05)),
-              "| collective (2 chunks, honest model above) | %.3f | see table | |" % (best + sorts[2])]
+              % (t_routed_one + dense, t_routed_one + dense + 0.05, one / (t_routed_one + dense + 0.05)),
+              "| direct-store, flag closed in 0.10 ms | %.3f | %.3f | %.2fx |"
+              % (t_routed_one + dense, t_routed_one + dense + 0.10, one / (t_routed_one + dense + 0.10)),
+              "| collective (2 chunks; step: the exchange models above) | %.3f | | |" % (best + sorts[2])]
     text = "\n".join(lines) + "\n"
     print(text)
     if "--md" in sys.argv:

@@ -55,7 +55,7 @@ def fallbacks(first):
     return order[first]
 
 
-def run(n, first="torch", dryrun=None, timeout_s=240, python=sys.executable, only=False):
+def run(n, first="torch", dryrun=None, timeout_s=150, python=sys.executable, only=False, budget_s=320):
     """Preflight with FRESH child processes: every form of `fallbacks(first)` in turn until one passes.  Returns
     ``{"form": <the form that passed or None>, "tried": [verdict per form], "seconds": ...}``.  The caller must not have touched the
     GPU in a way that forbids starting children (this function only starts processes; it never execs).  ``only``: just `first`,
@@ -64,6 +64,10 @@ def run(n, first="torch", dryrun=None, timeout_s=240, python=sys.executable, onl
     t0 = time.perf_counter()
     tried, chosen = [], None
     for form in ([first] if only else fallbacks(first)):
+        left = budget_s - (time.perf_counter() - t0)
+        if left < 30:                                   # the preflight must stay a preflight: what is left of its budget bounds every form
+            tried.append({"form": form, "ok": False, "reason": "not tried: the preflight's %d s were used up" % budget_s})
+            continue
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -80,7 +84,7 @@ def run(n, first="torch", dryrun=None, timeout_s=240, python=sys.executable, onl
                "--master-port", str(port), os.path.abspath(__file__), "--form", form]
         verdict = {"form": form, "ok": False}
         try:
-            proc = subprocess.run(cmd, env=env, text=True, capture_output=True, timeout=timeout_s)
+            proc = subprocess.run(cmd, env=env, text=True, capture_output=True, timeout=min(timeout_s, left))
             lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
             if lines:
                 verdict.update(json.loads(lines[-1]))
@@ -88,7 +92,7 @@ def run(n, first="torch", dryrun=None, timeout_s=240, python=sys.executable, onl
             if not verdict["ok"]:
                 verdict.setdefault("reason", "exit code %d: %s" % (proc.returncode, (proc.stderr or proc.stdout)[-600:]))
         except subprocess.TimeoutExpired:
-            verdict["reason"] = "no answer within %d s (children ended)" % timeout_s
+            verdict["reason"] = "no answer within %d s (children ended)" % min(timeout_s, left)
         tried.append(verdict)
         if verdict["ok"]:
             chosen = form
