@@ -295,15 +295,10 @@ def measure_list(arch="resnet101", workers=8, short=12, mid=40, long=64):
             "graph_captures": __import__("mdir_amd.graphs", fromlist=["capture_stats"]).capture_stats()}
 
 
-def cpu_reference_loop(arch="resnet101", images=8, size=(768, 1024), budget_s=40.0):
-    """The REFERENCE-STYLE extraction loop on the host cores, for `descriptors_per_s.cpu_baseline`: batch 1, three scales
-    (``[1, 1/sqrt(2), 1/2]``, F.interpolate bilinear), one trunk forward per scale, GeM / L2N / multi-scale aggregation /
-    whitening as stock torch ops, ``.cpu()`` per image -- the loop of cirtorch/networks/imageretrievalnet.py:284-324
-    (``extract_vectors`` -> ``extract_ms``) under mdir's wrapper chain (components/data/wrapper.py:104-119, 193-195), restated
-    here (nothing of the reference is imported); the same random-init trunk as the GPU leg, synthetic 1024x768 inputs already
-    decoded (the reference overlaps decoding in 6 loader workers).  Timed at 3 threads (what the reference asks for,
-    mdir/stages/validate.py:10-12) and at all cores; each leg stops after ``images`` images or ``budget_s`` seconds."""
+def _cpu_loop_leg(arch, images, size, threads, budget_s):
+    """One leg of ``cpu_reference_loop`` in THIS process (a CPU-only child of bench.py): ``threads`` torch threads."""
     from mdir_amd.networks import init_network
+    torch.set_num_threads(threads)
     torch.manual_seed(3)
     net = init_network({"architecture": arch, "pooling": "gem", "whitening": False, "pretrained": False})
     feats = net.features.eval()
@@ -331,32 +326,54 @@ def cpu_reference_loop(arch="resnet101", images=8, size=(768, 1024), budget_s=40
         X = P.mm(v.unsqueeze(1).sub(m))
         return X.div(torch.norm(X, p=2, dim=0, keepdim=True) + 1e-6).squeeze().cpu()
 
+    with torch.no_grad():
+        one(imgs[0])                             # warm-up: oneDNN builds its primitives for the three shapes
+        t0, done = time.perf_counter(), 0
+        while done < images and (done == 0 or time.perf_counter() - t0 < budget_s):
+            one(imgs[done % 2])
+            done += 1
+        dt = time.perf_counter() - t0
+    return {"descriptors_per_s": round(done / dt, 4), "s_per_image": round(dt / done, 3), "images": done, "threads": threads}
+
+
+def cpu_reference_loop(arch="resnet101", images=8, size=(768, 1024), budget_s=30.0, leg_timeout_s=75):
+    """The REFERENCE-STYLE extraction loop on the host cores, for `descriptors_per_s.cpu_baseline`: batch 1, three scales
+    (``[1, 1/sqrt(2), 1/2]``, F.interpolate bilinear), one trunk forward per scale, GeM / L2N / multi-scale aggregation /
+    whitening as stock torch ops, ``.cpu()`` per image -- the loop of cirtorch/networks/imageretrievalnet.py:284-324
+    (``extract_vectors`` -> ``extract_ms``) under mdir's wrapper chain (components/data/wrapper.py:104-119, 193-195), restated
+    here (nothing of the reference is imported); the same random-init trunk as the GPU leg, synthetic 1024x768 inputs already
+    decoded (the reference overlaps decoding in 6 loader workers).  Two legs, each a CPU-only CHILD process with a time limit:
+    3 threads (what the reference asks for, mdir/stages/validate.py:10-12) and 16 threads.  (Not "all cores": on the pool's
+    256-core hosts oneDNN with 256 threads took 243 s per image -- measured in round 6, the first default run of this leg --
+    against 1.2 s with 3; a leg that cannot finish is ended by its limit and reported as such.)"""
+    import subprocess
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    before = torch.get_num_threads()
     out = {}
-    try:
-        with torch.no_grad():
-            for name, threads in (("all_cores", cores), ("threads_3", min(3, cores))):
-                torch.set_num_threads(threads)
-                one(imgs[0])                             # warm-up: oneDNN builds its primitives for the three shapes
-                t0, done = time.perf_counter(), 0
-                while done < images and (done == 0 or time.perf_counter() - t0 < budget_s):
-                    one(imgs[done % 2])
-                    done += 1
-                dt = time.perf_counter() - t0
-                out[name] = {"descriptors_per_s": round(done / dt, 4), "s_per_image": round(dt / done, 3), "images": done, "threads": threads}
-    finally:
-        torch.set_num_threads(before)
-    best = max(out.values(), key=lambda r: r["descriptors_per_s"])
+    for name, threads in (("threads_3", min(3, cores)), ("threads_16", min(16, cores))):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-loop-leg", arch, str(images), str(size[0]), str(size[1]), str(threads), str(budget_s)]
+        try:
+            proc = subprocess.run(cmd, env=env, text=True, capture_output=True, timeout=leg_timeout_s)
+            lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+            out[name] = json.loads(lines[-1]) if lines and proc.returncode == 0 else {"error": (proc.stderr or "no output")[-300:], "threads": threads}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "not finished within %d s" % leg_timeout_s, "threads": threads}
+    good = [r for r in out.values() if "descriptors_per_s" in r]
+    if not good:
+        return {"value": None, "unit": "descriptors/s", "kind": "port", "legs": out, "host_cores": cores}
+    best = max(good, key=lambda r: r["descriptors_per_s"])
     return {"value": best["descriptors_per_s"], "unit": "descriptors/s", "cores": best["threads"], "kind": "port",
             "sample": "%d images of %dx%d per leg (bounded), batch 1, 3 scales, torch CPU ops (oneDNN convolutions) for the trunk and the "
-                      "tail, .cpu() per image: the loop of imageretrievalnet.py:284-324 under the wrapper chain, restated; %s-GeM random init"
-                      % (images, size[1], size[0], arch),
-            "value_3_threads": out["threads_3"]["descriptors_per_s"], "legs": out, "host_cores": cores}
+                      "tail, .cpu() per image: the loop of imageretrievalnet.py:284-324 under the wrapper chain, restated; %s-GeM random init; "
+                      "each leg a CPU-only child process" % (images, size[1], size[0], arch),
+            "value_3_threads": out["threads_3"].get("descriptors_per_s"), "legs": out, "host_cores": cores}
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-loop":
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-loop-leg":
+        a = sys.argv[2:]
+        print(json.dumps(_cpu_loop_leg(a[0], int(a[1]), (int(a[2]), int(a[3])), int(a[4]), float(a[5]))))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--cpu-loop":
         print(json.dumps(cpu_reference_loop(images=int(sys.argv[2]) if len(sys.argv) > 2 else 2)))
     elif len(sys.argv) > 1 and sys.argv[1] == "--list":
         print(json.dumps(measure_list(*(sys.argv[2:3] or ["resnet101"]))))

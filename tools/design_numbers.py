@@ -3,17 +3,27 @@
    profiles/<tag>_bench_line.json   the one JSON line of `python bench.py` on an MI355X
    profiles/<tag>_traffic.json      HBM bytes per launch from the PMC passes (tools/summarize_profile.py)
 Everything between `<!-- NUMBERS:BEGIN -->` and `<!-- NUMBERS:END -->` in DESIGN.md is replaced.
-    python tools/design_numbers.py r04"""
+    python tools/design_numbers.py r06"""
 import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 b = json.load(open(os.path.join(root, "profiles", tag + "_bench_line.json")))
 t = json.load(open(os.path.join(root, "profiles", tag + "_traffic.json")))
 r, rr, sec = b["roofline"], b.get("roofline_rank", {}), b.get("secondary_configs", {})
 cpu, ds = b.get("cpu_baseline", {}), b.get("descriptors_per_s", {})
+# round 6: the side legs are a second run (`bench.py --secondary`), committed as <tag>_secondary_line.json
+sec_path = os.path.join(root, "profiles", tag + "_secondary_line.json")
+if not sec and os.path.exists(sec_path):
+    b2 = json.load(open(sec_path))
+    sec = b2.get("secondary_configs", {})
+    b.setdefault("sort_free_map_route", b2.get("sort_free_map_route"))
+    for mode in ("split3", "split2"):          # (the second run's own exact-chain time stands beside its split times)
+        if mode in sec and not sec[mode].get("exact_chain_scores_ms"):
+            sec[mode]["exact_chain_scores_ms"] = b2["roofline"]["kernel_ms"]
+arb = (b.get("cpu_path_parity") or {}).get("f64_arbiter") or {}
 
 
 def g(d, *keys, default=None):
@@ -35,6 +45,8 @@ rows = [
      "%s ms = %s TFLOP/s = **%s of the fp32 MFMA peak** (157.3); %s of the peak at the profiled clock (%s GHz, pipe busy %s)"
      % (f(r["kernel_ms"]), f(r["achieved"], "%.1f"), f(r["frac"]), f(r.get("frac_of_peak_at_profiled_clock")),
         f(r.get("profiled_sustained_clock_ghz"), "%.2f"), f(r.get("profiled_mfma_pipe_busy"), "%.2f")), "`roofline`"),
+    ("  the same kernel in the committed rocprofv3 kernel trace (same command under the profiler)",
+     "%s us average = **%s of the peak**" % (f(r.get("rocprof_kernel_avg_us"), "%.1f"), f(r.get("frac_rocprof"))), "`roofline.frac_rocprof`"),
     ("  its HBM traffic by PMC / algorithmic bytes", "%s GB / %s GB = %sx" % (f(r["traffic"] / 1e9 if r.get("traffic") else None),
                                                                              f(r["algorithmic_bytes"] / 1e9),
                                                                              f(r["traffic"] / r["algorithmic_bytes"] if r.get("traffic") else None, "%.2f")),
@@ -46,6 +58,14 @@ rows = [
     ("step time not inside the two kernel families (launch gaps)", "%s ms" % f(b.get("step_ms_minus_kernels"), "%.4f"), "`step_ms_minus_kernels`"),
     ("mAP-medium (synthetic rOxford-shaped labels): GPU / numpy CPU path", "%s / %s" % (f(b.get("map_medium"), "%.10f"), f(b.get("map_medium_cpu"), "%.10f")),
      "`map_medium`, `map_medium_cpu`, `cpu_path_parity`"),
+    ("  float64 arbiter: ranking slots where GPU and CPU differ; of those the GPU / the CPU / neither names float64's row; mAP under the float64 order",
+     "%s of %s; %s / %s / %s; %s" % (arb.get("slots_where_gpu_and_cpu_differ"), arb.get("of_slots"), arb.get("gpu_order_agrees_with_f64"),
+                                    arb.get("cpu_order_agrees_with_f64"), arb.get("neither_agrees_with_f64"), f(arb.get("map_medium_f64_order"), "%.10f")),
+     "`cpu_path_parity.f64_arbiter`"),
+    ("  largest |score - float64 score|: GPU chain / BLAS; largest float64 gap between two rows a path orders the other way: GPU / CPU",
+     "%s / %s; %s / %s (bound 2e-6)" % (f(arb.get("gpu_max_abs_score_error_vs_f64"), "%.2e"), f(arb.get("cpu_max_abs_score_error_vs_f64"), "%.2e"),
+                                         f(arb.get("gpu_max_f64_gap_between_misordered_rows"), "%.2e"), f(arb.get("cpu_max_f64_gap_between_misordered_rows"), "%.2e")),
+     "`cpu_path_parity.f64_arbiter`"),
     ("CPU reference beside it (np.dot + np.argsort, %s host cores)" % cpu.get("cores"), "%s queries/s (%s with the BLAS pool at 3 threads)"
      % (f(cpu.get("value"), "%.1f"), f(cpu.get("value_blas_3_threads"), "%.1f")), "`cpu_baseline`"),
     ("sort-free evaluation route (similarity + rank counting, same mAP)", "%s queries/s" % f(g(b, "sort_free_map_route", "value"), "%.0f"), "`sort_free_map_route`"),
@@ -88,6 +108,13 @@ rows = [
      "%s descriptors/s (%s ms per image); steady-state estimate %s; loader alone %s images/s"
      % (f(ds.get("value"), "%.1f"), f(ds.get("ms_per_image"), "%.2f"), f(g(ds, "steady_state_estimate", "descriptors_per_s"), "%.1f"),
         f(ds.get("loader_only_images_per_s"), "%.0f")), "`descriptors_per_s`"),
+    ("  its roofline: trunk convolutions (MIOpen + own expand 1x1), whole list / steady state",
+     "%s TFLOP/s = %s of the fp32 MFMA peak / %s = %s" % (f(g(ds, "roofline", "achieved"), "%.1f"), f(g(ds, "roofline", "frac")),
+                                                         f(g(ds, "roofline", "achieved_at_steady_state"), "%.1f"), f(g(ds, "roofline", "frac_at_steady_state"))),
+     "`descriptors_per_s.roofline`"),
+    ("  CPU reference beside it (the reference-style loop: batch 1, 3 scales, torch CPU ops): 3 threads / 16 threads",
+     "%s / %s descriptors/s" % (f(g(ds, "cpu_baseline", "legs", "threads_3", "descriptors_per_s"), "%.2f"),
+                               f(g(ds, "cpu_baseline", "legs", "threads_16", "descriptors_per_s"), "%.2f")), "`descriptors_per_s.cpu_baseline`"),
     ("  resident single shape / VGG16", "%s / %s descriptors/s" % (f(ds.get("resident_single_shape_descriptors_per_s"), "%.1f"),
                                                                   f(ds.get("vgg16_resident_single_shape_descriptors_per_s"), "%.1f")), "`descriptors_per_s`"),
 ]
