@@ -287,3 +287,38 @@ def test_single_process_forms_and_argument_errors():
         ShardedIndex(torch.from_numpy(vecs), "DN", 50, backend=OracleBackend(), compute="bf16x9")
     with pytest.raises(ValueError, match="multiplies an fp32 shard"):
         ShardedIndex(torch.from_numpy(vecs), "DN", 50, backend=OracleBackend(), storage="f16", compute="split3")
+
+
+def test_preflight_vocabulary_and_the_order_forms_are_tried_in(monkeypatch):
+    """tools/preflight_ranks.py (round 6): the environment each exchange form stands for, the fall-back order from each
+    requested form, what bench.py asks for by default and under --comm / MDIR_AMD_EXCHANGE; a preflight whose children cannot
+    start reports every form with its reason instead of raising (bench.py then keeps the requested form)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    sys.path.insert(0, root)
+    import bench
+    import preflight_ranks as P
+    assert P.form_env("p2p") == {"MDIR_AMD_COMM": "p2p", "MDIR_AMD_EXCHANGE": ""}
+    assert P.form_env("mdx")["MDIR_AMD_COMM"] == "mdx" and P.form_env("allgather")["MDIR_AMD_EXCHANGE"] == "allgather"
+    assert P.form_env("torch") == {"MDIR_AMD_COMM": "", "MDIR_AMD_EXCHANGE": ""}
+    with pytest.raises(ValueError):
+        P.form_env("ring")
+    assert P.fallbacks("p2p") == ["p2p", "mdx", "torch", "allgather"] and P.fallbacks("torch") == ["torch", "allgather"]
+    assert P.fallbacks("allgather") == ["allgather"]
+    for comm, exchange, want in (("", "", "torch"), ("mdx", "", "mdx"), ("p2p", "allgather", "p2p"), ("", "allgather", "allgather")):
+        monkeypatch.setenv("MDIR_AMD_COMM", comm)
+        monkeypatch.setenv("MDIR_AMD_EXCHANGE", exchange)
+        assert bench.requested_form() == want
+    # children that cannot even start (a python that does not exist): every form tried, none passed, reasons kept, nothing raised
+    pre = None
+    try:
+        pre = P.run(2, "torch", dryrun=True, python="/nonexistent/python", budget_s=60)
+    except FileNotFoundError:
+        pass                                    # (subprocess raises before a child exists: bench.preflight turns that into a verdict)
+    if pre is not None:
+        assert pre["form"] is None and all(not t["ok"] for t in pre["tried"])
+    monkeypatch.setattr(P, "run", lambda *a, **k: (_ for _ in ()).throw(OSError("no children here")))
+    verdict = bench.preflight(2)
+    assert verdict["form"] is None and "no children here" in verdict["tried"][0]["reason"]
