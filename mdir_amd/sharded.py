@@ -182,7 +182,7 @@ def chunk_bounds(lo, hi, chunks):
         if chunks == 2 and FULL_ROUND_ROWS + FULL_ROUND_ROWS // 2 <= n <= 2 * FULL_ROUND_ROWS:
             return [(lo, lo + FULL_ROUND_ROWS), (lo + FULL_ROUND_ROWS, hi)]
         # the smallest of the halving chunks would not fill the chip once (a similarity launch has 512 workgroup slots of 128
-        # rows): equal chunks instead -- at 125 625 rows 2 x 62 812 take 0.345 ms, 83 750 + 41 875 take 0.399 (tools/g8_budget.py)
+        # rows): equal chunks instead (at 125 625 rows the halving cut 83 750 + 41 875 takes 0.40 ms against 0.34: tools/g8_budget.py)
         weights = [1] * chunks
     total, edges, acc = sum(weights), [lo], 0
     for w in weights[:-1]:
