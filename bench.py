@@ -29,6 +29,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np
 import torch
@@ -39,11 +40,8 @@ NQ, DIM = 70, 2048
 GEN_BLOCK = 4096
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
-# Two correct fp32 evaluations of one 2048-term dot product of unit vectors (BLAS order on the host, k-ordered fma
-# chain on the GPU) differ by summation order only: <~ D * 2^-24 * |s| ~ 2e-6 for the |s| <= 0.02 of near-tied
-# distractors (measured: 8e-8).  The CPU and GPU rankings may disagree only between scores closer than this -- 5x
-# tighter than the north star's 1e-5 score tolerance, so that a real regression cannot hide under it.
-SUM_ORDER_TOL = 2e-6
+from bench_parity import SUM_ORDER_TOL, cpu_path_parity, f64_arbiter          # noqa: E402,F401  (tools/: the parity half of the cpu_baseline leg)
+from bench_ranks import launch_ranks, preflight, ranks_report, requested_form, select_exchange      # noqa: E402,F401  (tools/: the N > 1 half)
 
 
 def gen_rows(lo, hi, device):
@@ -201,174 +199,6 @@ def verify_ranking(sc, rk):
         s = sc[q][rk[q]]
         ok_order = ok_order and bool((s[:-1] >= s[1:]).all()) and bool(((s[:-1] != s[1:]) | (rk[q, :-1] < rk[q, 1:])).all())
     return ok_perm, ok_order
-
-
-def f64_arbiter(rows, qvecs, sc, rk, rk_cpu, sc_cpu, gnd, vecs_host=None):
-    """WHICH of the two fp32 orders is right where they differ.  The reference's statement
-    (cirscore.py:69-70) evaluated in float64 -- every dot product of the fp32 descriptors accumulated in float64 (device dgemm,
-    cross-checked against numpy float64 on the host for the disputed rows), ranked descending with ties by ascending id -- is the
-    arbiter between the GPU's k-ordered fp32 fma chain (``sc`` [Q,N], ``rk`` [Q,N]) and the host's BLAS fp32 product + numpy
-    argsort (``sc_cpu`` [N,Q], ``rk_cpu`` [N,Q]).  ``rows`` [N,D] fp32 and ``qvecs`` [D,Q] on the device.  Returns a dict."""
-    from mdir_amd.evaluate import compute_map_and_print
-    device, (nq, n) = rows.device, sc.shape
-    q64 = qvecs.double()
-    s64 = torch.empty((nq, n), dtype=torch.float64, device=device)
-    for a in range(0, n, 131072):
-        b = min(n, a + 131072)
-        s64[:, a:b] = (rows[a:b].double() @ q64).t()
-    rk64 = torch.sort(s64, dim=1, descending=True, stable=True).indices          # ties: ascending id (the build's tie rule)
-    rkc = torch.from_numpy(np.ascontiguousarray(rk_cpu.T)).to(device)
-    out = {"what": "float64 arbiter: the same fp32 descriptors multiplied with float64 accumulation and ranked (ties by ascending id); "
-                   "counts of ranking slots / labelled rows where each fp32 path names the row the float64 order names"}
-    disputed = rk != rkc
-    g_ok, c_ok = rk == rk64, rkc == rk64
-    nd = int(disputed.sum())
-    out["slots_where_gpu_and_cpu_differ"] = nd
-    out["of_slots"] = int(rk.numel())
-    out["gpu_order_agrees_with_f64"] = int((g_ok & disputed).sum())
-    out["cpu_order_agrees_with_f64"] = int((c_ok & disputed).sum())
-    out["neither_agrees_with_f64"] = nd - int(((g_ok | c_ok) & disputed).sum())
-    out["whole_ranking_slots_equal_to_f64"] = {"gpu": int(g_ok.sum()), "cpu": int(c_ok.sum())}
-    out["top100_slots_equal_to_f64"] = {"gpu": int(g_ok[:, :100].sum()), "cpu": int(c_ok[:, :100].sum()), "of": 100 * nq}
-    # how far apart, in float64, are two rows that an fp32 path puts in the other order than float64 does
-    def worst_gap(order, ok):
-        bad = torch.nonzero(~ok)
-        if not len(bad):
-            return 0.0
-        qq, ss = bad[:, 0], bad[:, 1]
-        return float((s64[qq, order[qq, ss]] - s64[qq, rk64[qq, ss]]).abs().max())
-    out["gpu_max_f64_gap_between_misordered_rows"] = worst_gap(rk, g_ok)
-    out["cpu_max_f64_gap_between_misordered_rows"] = worst_gap(rkc, c_ok)
-    out["gpu_max_abs_score_error_vs_f64"] = float((sc.double() - s64).abs().max())
-    scc = torch.from_numpy(np.ascontiguousarray(sc_cpu.T)).to(device)
-    out["cpu_max_abs_score_error_vs_f64"] = float((scc.double() - s64).abs().max())
-    del scc, g_ok, c_ok
-    # labelled rows (all that mAP depends on): their positions under the three orders
-    ar = torch.arange(n, device=device)
-    inv = torch.empty(n, dtype=torch.int64, device=device)
-    moved = g_moved_ok = c_moved_ok = g_lab_ok = c_lab_ok = total = 0
-    for q in range(nq):
-        ids = torch.from_numpy(np.concatenate([gnd[q]["easy"], gnd[q]["hard"], gnd[q]["junk"]]).astype(np.int64)).to(device)
-        pos = []
-        for order in (rk, rkc, rk64):
-            inv[order[q]] = ar
-            pos.append(inv[ids].clone())
-        pg, pc, p6 = pos
-        mv = pg != pc
-        moved += int(mv.sum())
-        g_moved_ok += int(((pg == p6) & mv).sum())
-        c_moved_ok += int(((pc == p6) & mv).sum())
-        g_lab_ok += int((pg == p6).sum())
-        c_lab_ok += int((pc == p6).sum())
-        total += len(ids)
-    out["labelled_rows"] = {"of": total, "ranked_differently_by_gpu_and_cpu": moved, "of_those_gpu_position_equals_f64": g_moved_ok,
-                            "of_those_cpu_position_equals_f64": c_moved_ok, "gpu_position_equals_f64": g_lab_ok, "cpu_position_equals_f64": c_lab_ok}
-    with contextlib.redirect_stdout(sys.stderr):
-        avg64, _ = compute_map_and_print("roxford5k", rk64.t(), gnd)
-    out["map_medium_f64_order"] = avg64["map_medium"]
-    if vecs_host is not None and nd:
-        # the device's float64 values of (a sample of) the disputed rows against numpy float64 on the HOST: the arbiter's own check
-        where = torch.nonzero(disputed)[:4000].cpu().numpy()
-        qh = qvecs.cpu().numpy().astype(np.float64)
-        ids_g = rk[where[:, 0], where[:, 1]].cpu().numpy()
-        host = np.einsum("dk,dk->k", vecs_host[:, ids_g].astype(np.float64), qh[:, where[:, 0]])
-        dev = s64[torch.from_numpy(where[:, 0]).to(device), torch.from_numpy(ids_g).to(device)].cpu().numpy()
-        out["host_f64_crosscheck"] = {"rows": int(len(where)), "max_abs_diff_device_f64_vs_numpy_f64": float(np.abs(host - dev).max())}
-    return out
-
-
-def requested_form():
-    """The exchange form the command line / environment asks for, in tools/preflight_ranks.py's vocabulary."""
-    comm = os.environ.get("MDIR_AMD_COMM") or ""
-    if comm in ("p2p", "mdx"):
-        return comm
-    return "allgather" if os.environ.get("MDIR_AMD_EXCHANGE") == "allgather" else "torch"
-
-
-def preflight(n):
-    """tools/preflight_ranks.py with FRESH child processes (called by a process that has not touched the GPU): the requested
-    exchange form and its fall-backs on a 10 000-row problem, every rank's rows verified on the device; then -- unless the direct-store
-    form was the one requested, or MDIR_AMD_COMM_AUTO=0 -- ONE probe of the direct-store form, whose verdict decides whether the
-    heavy run may time it against the collective (`exchange_selection`)."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    first = requested_form()
-    try:
-        import preflight_ranks
-        pre = preflight_ranks.run(n, first)
-        if (pre["form"] is not None and pre["form"] != "p2p" and first == "torch" and os.environ.get("MDIR_AMD_COMM_AUTO", "1") != "0"
-                and pre["seconds"] < 200):
-            pre["p2p_probe"] = preflight_ranks.run(n, "p2p", only=True, budget_s=160)["tried"][0]
-    except Exception as exc:          # noqa: BLE001 -- a preflight that cannot run must not cost the measured line
-        pre = {"form": None, "tried": [{"form": first, "ok": False, "reason": "the preflight itself failed: %s: %s" % (type(exc).__name__, exc)}],
-               "seconds": None}
-    return pre
-
-
-def select_exchange(sharded, step, keep, dryrun, device, reps=3):
-    """Run time A/B of the two exchange forms on THIS node at the full size, outside the timed region: `reps` steps of the
-    collective form, then of the direct-store form (which the preflight has just verified on a small problem with fresh
-    processes).  The direct-store form is taken only if every rank's ranking is bit-identical to the collective form's, no
-    flag wait gave up, and the slowest rank's step is faster.  Any failure leaves the collective form in place."""
-    def timed():
-        step()                                              # (first step of a form: buffers, peer mappings)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            step()
-        torch.cuda.synchronize()
-        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device="cpu" if dryrun else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-    out = {"collective_ms": round(timed(), 4)}
-    rk_a = keep["rk"].clone()
-    ok, why = 1, ""
-    try:
-        sharded.use_direct_store(True)
-        out["direct_store_ms"] = round(timed(), 4)
-        if not torch.equal(keep["rk"], rk_a):
-            ok, why = 0, "the direct-store ranking differs from the collective form's"
-        elif sharded._p2p is not None and sharded._p2p.late_peers() != 0:
-            ok, why = 0, "a peer's flag did not arrive"
-    except Exception as exc:          # noqa: BLE001 -- the collective form stays
-        ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
-    flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if dryrun else device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    ok = int(flag.item())
-    take = bool(ok and out.get("direct_store_ms", 1e9) < out["collective_ms"])
-    sharded.use_direct_store(take)
-    out.update({"direct_store_verified_equal": bool(ok), "chosen": "direct_store" if take else "collective",
-                "what": "per-step wall time of the slowest rank over %d steps of each form at the full size, before the timed region" % reps})
-    if why:
-        out["reason"] = why
-    return out
-
-
-def launch_ranks(n):
-    """One child `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>`; returns its exit code.
-    The children inherit stdout, so rank 0's JSON line is this command's output."""
-    import socket
-    import subprocess
-    dryrun = os.environ.get("MDIR_AMD_DRYRUN_ONE_GPU") == "1"
-    have = torch.cuda.device_count()
-    if have < n and not dryrun:
-        print("bench.py --gpus %d: this node shows %d GPU(s) (MDIR_AMD_DRYRUN_ONE_GPU=1 runs all ranks on one GPU over "
-              "gloo: a functional dry run, not a measurement)" % (n, have), file=sys.stderr)
-        return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    env.setdefault("OMP_NUM_THREADS", "4")
-    if "--no-preflight" not in sys.argv and "MDIR_AMD_PREFLIGHT" not in env:
-        # this process never touches the GPU: the preflight's fresh children run here, and the heavy run's ranks are told the verdict
-        pre = preflight(n)
-        if pre["form"] is None:         # (the heavy run then keeps the requested form, as if there had been no preflight: see main)
-            print("bench.py --gpus %d: no exchange form passed the preflight: %s" % (n, json.dumps(pre["tried"])), file=sys.stderr)
-        env["MDIR_AMD_PREFLIGHT"] = json.dumps(pre)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -615,98 +445,9 @@ def main():
             "what": "12 launches per ranking; the 4-pass form moves ~4.8x the bytes of an ideal one-pass argsort and streams them at the "
                     "rate HBM gives a read+write mix (DESIGN section 4): only fewer passes would help, and the MSD / one-sweep forms measured slower"}
     else:
-        rk_mine, sc_mine, (qlo, qhi) = keep["rk"], keep["sc"], keep["q"]
-        ok = torch.tensor([1], device="cpu" if dryrun else device)
-        if qhi > qlo:
-            ok[0] = int(bool((rk_mine[:, 0].cpu() == torch.from_numpy(qid[qlo:qhi])).all()))
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        assert int(ok.item()) == 1, "sharded ranking lost a query's source row"
-        # every rank's rows of the global ranking, checked on its device against the exchanged scores: permutations of
-        # 0..N-1 (global ids), non-increasing, ascending ids inside ties -- what the single-GPU line asserts for all 70
-        if qhi > qlo:
-            perm_ok, order_ok = verify_ranking(sc_mine.dense(), rk_mine)
-            ok[0] = int(perm_ok and order_ok)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        assert int(ok.item()) == 1, "a rank's rows of the sharded ranking are not stable descending permutations"
-        extra["ranking_verified_on_device"] = "every rank's query rows: permutation of the global ids, non-increasing scores, ascending ids inside ties"
-        # mAP without any ranking: counting kernel + two tiny all-reduces
-        s_local = sharded.local_scores(qvecs, "DN")
-        from mdir_amd.evaluate import map_from_positions
-        oks = [np.concatenate([g["easy"], g["hard"]]) for g in gnd]
-        junks = [g["junk"] for g in gnd]
-        pos, off = sharded.positions(s_local, [np.concatenate([o, j]) for o, j in zip(oks, junks)])
-        pos = pos.cpu().numpy()
-        pl = [pos[off[q]:off[q] + len(oks[q])] for q in range(NQ)]
-        jl = [pos[off[q] + len(oks[q]):off[q + 1]] for q in range(NQ)]
-        extra["map_medium"] = map_from_positions(pl, jl, [len(o) for o in oks])[0]
-        # per-phase breakdown of the LAST timed step on every rank (HIP events on the compute stream) and a head count
-        ph = sharded.phase_ms() or {"scores_ms": float("nan"), "exchange_exposed_ms": float("nan"), "sort_ms": float("nan")}
-        mine = torch.tensor([ph["scores_ms"], ph["exchange_exposed_ms"], ph["sort_ms"], 1.0], dtype=torch.float64,
-                            device="cpu" if dryrun else device)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        table = torch.stack(gathered).cpu().numpy()
-        extra["nranks_seen"] = int(round(float(table[:, 3].sum())))
-        # the same roofline objects as the single-GPU line, per rank: a rank multiplies its shard (2 Q n_local D flop on the
-        # fp32 MFMA) and sorts its queries' rows of the whole database (12 B per element of [Q_mine, N]); the job's figure is
-        # the SLOWEST rank's (the step waits for it)
-        from mdir_amd.sharded import shard_bounds as _sb
-        per_rank_tf, per_rank_gbs = [], []
-        for r in range(world):
-            rl, rh = _sb(n_total, world, r)
-            qb = (NQ // world) + (1 if r < NQ % world else 0)
-            t_s, t_r = float(table[r, 0]), float(table[r, 2])
-            per_rank_tf.append(round(2.0 * NQ * (rh - rl) * DIM / (t_s * 1e-3) / 1e12, 2) if t_s > 0 else None)
-            per_rank_gbs.append(round(12.0 * qb * n_total / (t_r * 1e-3) / 1e9, 1) if t_r > 0 and qb else None)
-        tf_ok = [x for x in per_rank_tf if x]
-        # HBM traffic per rank: the committed single-GPU PMC figure scaled by the shard's share of the rows (the kernel streams
-        # its rows once, the traffic is linear in them: 1.007x algorithmic at N = 1 M) -- derived, labelled, not measured here
-        _, t1, t1_src, r1, r1_src = committed_traffic()
-        n_big = max(_sb(n_total, world, r)[1] - _sb(n_total, world, r)[0] for r in range(world))
-        q_big = -(-NQ // world)
-        n_prof = N_ROXFORD + N_DISTRACTORS
-        traffic_rank = round(t1 * n_big / n_prof, 1) if t1 else None
-        traffic_sort = round(r1 * (q_big * n_total) / (NQ * n_prof), 1) if r1 else None
-        if tf_ok:
-            extra["roofline"] = {"kernel": "mdx::scores_lc_kernel (fp32 MFMA 16x16x4 [+ 4x4x1 leftover]; 4 MFMA + 4 LDS-DMA loader waves), per rank on its shard",
-                                 "bound": "mfma", "achieved": min(tf_ok), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU (slowest rank)",
-                                 "frac": round(min(tf_ok) / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic_rank,
-                                 "traffic_source": (t1_src + "; x %d / %d rows: the largest shard's share of the single-GPU launch" % (n_big, n_prof)) if t1_src else None,
-                                 "algorithmic_flops_per_rank": 2.0 * NQ * n_big * DIM,
-                                 "algorithmic_bytes_per_rank": 4.0 * n_big * DIM + 4.0 * NQ * DIM + 4.0 * NQ * n_big,
-                                 "per_rank_achieved": per_rank_tf,
-                                 "kernel_ms_per_rank": [round(float(x), 4) for x in table[:, 0]],
-                                 "what": "HIP events on each rank's compute stream around the similarity kernels of the last timed step "
-                                         "(chunked shards: the sum of the chunks' launches)"}
-        gb_ok = [x for x in per_rank_gbs if x]
-        if gb_ok:
-            extra["roofline_rank"] = {"kernel": "mdx::sort_* x 4 passes over the peer blocks (mdx_rank_full_segments), per rank on its queries",
-                                      "bound": "hbm", "achieved": min(gb_ok), "peak": PEAK_HBM_GBS, "unit": "GB/s per GPU (slowest rank)",
-                                      "frac": round(min(gb_ok) / PEAK_HBM_GBS, 4), "traffic": traffic_sort,
-                                      "traffic_source": (r1_src + "; x (%d x %d) / (%d x %d) elements" % (q_big, n_total, NQ, n_prof)) if r1_src else None,
-                                      "per_rank_achieved": per_rank_gbs,
-                                      "algorithmic_bytes_per_rank": [12.0 * ((NQ // world) + (1 if r < NQ % world else 0)) * n_total for r in range(world)]}
-        step_ms = [a.elapsed_time(b) for a, b in ev]
-        extra["spread_over_timed_steps"] = {"step_ms": spread(step_ms), "value": spread([NQ / (t * 1e-3) for t in step_ms], 1), "steps": args.steps,
-                                            "what": "rank 0: HIP events on its compute stream around every timed step (similarity, exchange wait, sort)"}
-        if pre is not None:
-            extra["preflight"] = {"form_that_passed": pre["form"], "seconds": pre.get("seconds"),
-                                  "tried": [{k: v for k, v in t.items() if k in ("form", "ok", "reason", "nranks_seen", "link_types", "exchange_used", "through", "seconds_in_ranks")}
-                                            for t in pre["tried"]],
-                                  "direct_store_probe": {k: v for k, v in pre.get("p2p_probe", {}).items() if k in ("ok", "reason", "nranks_seen", "seconds_in_ranks")} or None}
-        if selection is not None:
-            extra["exchange_selection"] = selection
-        extra["comm"] = ("p2p (C ABI: mdx_scores_p2p, direct stores into the owners' buffers + one flag per peer)" if getattr(sharded, "_p2p_on", False)
-                         else "mdx (C ABI: mdx_exchange_scores over RCCL)" if getattr(sharded, "_comm", None) is not None else "torch.distributed")
-        if getattr(sharded, "_p2p", None) is not None:
-            extra["p2p_late_peers"] = sharded._p2p.late_peers()
-        extra["phases_ms_per_rank"] = {"scores": [round(float(x), 4) for x in table[:, 0]],
-                                       "exchange_exposed": [round(float(x), 4) for x in table[:, 1]],
-                                       "sort": [round(float(x), 4) for x in table[:, 2]],
-                                       "exchange": "direct_store" if getattr(sharded, "_p2p_on", False) else ("all_to_all" if sharded._use_a2a else "all_gather"),
-                                       "chunks": sharded.chunks,
-                                       "what": "last timed step; exchange_exposed = compute-stream wait for transfers after the last "
-                                               "similarity kernel (+ re-block copy)"}
+        import types
+        extra.update(ranks_report(types.SimpleNamespace(keep=keep, dryrun=dryrun, device=device, qid=qid, gnd=gnd, sharded=sharded, qvecs=qvecs,
+                                                         world=world, n_total=n_total, ev=ev, args=args, pre=pre, selection=selection)))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -723,63 +464,8 @@ def main():
             if t_dot3 is not None:
                 extra["cpu_baseline"]["value_blas_3_threads"] = round(NQ / (t_dot3 + t_sort), 3)
                 extra["cpu_baseline"]["sample"] += "; with the BLAS pool at 3 threads (the reference's OMP_NUM_THREADS=3) np.dot takes %.2f s" % t_dot3
-            # parity with the reference CPU path at full size: the two statements differ only in the summation order of
-            # the 2048-term dot products (BLAS vs the k-ordered chain), i.e. in the last bits of near-tied scores
-            with contextlib.redirect_stdout(sys.stderr):
-                avg_cpu, _ = compute_map_and_print("roxford5k", rk_cpu, gnd)
-            extra["map_medium_cpu"] = avg_cpu["map_medium"]
-            gpu_top = rk[:, :100].t().cpu().numpy()
-            differ = np.argwhere(rk_cpu[:100] != gpu_top)                       # (slot, query)
-            extra["cpu_top100_id_agreement"] = round(1.0 - len(differ) / gpu_top.size, 6)
-            max_gap = 0.0
-            if len(differ):
-                qs = torch.from_numpy(differ[:, 1]).to(device)
-                a = sc[qs, torch.from_numpy(gpu_top[differ[:, 0], differ[:, 1]]).to(device)]
-                b = sc[qs, torch.from_numpy(rk_cpu[:100][differ[:, 0], differ[:, 1]]).to(device)]
-                max_gap = float((a - b).abs().max())
-            extra["cpu_top100_max_score_gap_where_ids_differ"] = max_gap
-            # ids may only differ between scores closer than the summation-order bound (north-star tolerance: 1e-5)
-            assert max_gap <= SUM_ORDER_TOL, "CPU and GPU rankings differ between scores %.3g apart" % max_gap
-            # positions of the labelled rows (all that mAP depends on) under both rankings; a row may sit elsewhere only
-            # if its GPU score has a neighbour in the GPU ranking closer than the score tolerance (a near-tie)
-            labelled_pos_equal, worst, n_moved = True, 0.0, 0
-            inv_cpu = np.empty(n_total, dtype=np.int64)
-            for q in range(NQ):
-                ids = np.concatenate([gnd[q]["easy"], gnd[q]["hard"], gnd[q]["junk"]]).astype(np.int64)
-                inv_cpu[rk_cpu[:, q]] = np.arange(n_total)
-                ids_d = torch.from_numpy(ids).to(device)
-                pos_gpu = torch.nonzero(rk[q].unsqueeze(0) == ids_d.unsqueeze(1))[:, 1].cpu().numpy()     # aligned with ids
-                moved = np.nonzero(pos_gpu != inv_cpu[ids])[0]
-                if len(moved):
-                    labelled_pos_equal = False
-                    n_moved += len(moved)
-                    at = torch.from_numpy(np.clip(pos_gpu[moved], 1, n_total - 2)).to(device)
-                    s0, sm, sp = sc[q, rk[q, at]], sc[q, rk[q, at - 1]], sc[q, rk[q, at + 1]]
-                    worst = max(worst, float(torch.minimum((s0 - sm).abs(), (s0 - sp).abs()).max()))
-            assert worst <= SUM_ORDER_TOL, "a labelled row ranks differently on the CPU path without a near-tie (gap %.3g)" % worst
-            if labelled_pos_equal:
-                assert avg_cpu["map_medium"] == extra["map_medium"], (avg_cpu["map_medium"], extra["map_medium"])
-            extra["map_equals_cpu_path"] = bool(avg_cpu["map_medium"] == extra["map_medium"])
-            extra["labelled_positions_equal_cpu_path"] = labelled_pos_equal
-            extra["cpu_path_parity"] = {
-                "labelled_rows_ranked_elsewhere": n_moved, "of": 20 * NQ, "their_gap_to_a_neighbouring_score": worst,
-                "asserted_bound": SUM_ORDER_TOL, "top100_slots_with_other_ids": int(len(differ)),
-                "what": "the CPU path (np.dot in BLAS order, numpy's unstable argsort) and the GPU path (k-ordered fma chain, "
-                        "ties by ascending id) may order rows differently only inside runs of scores closer than the summation-order "
-                        "bound 2e-6 (5x tighter than the 1e-5 score tolerance); asserted above for every such row.  mAP then differs by what such swaps of labelled rows move (compare map_medium "
-                        "with map_medium_cpu); the printed 2-decimal mAP is the same"}
-            # ... and WHICH order is right where the two differ: the float64 arbiter
-            try:
-                arb = f64_arbiter(rows, qvecs, sc, rk, rk_cpu, sc_cpu, gnd, vecs_host)
-                extra["cpu_path_parity"].update({
-                    "gpu_order_agrees_with_f64": arb["gpu_order_agrees_with_f64"], "cpu_order_agrees_with_f64": arb["cpu_order_agrees_with_f64"],
-                    "map_medium_f64_order": arb["map_medium_f64_order"], "f64_arbiter": arb})
-                assert arb["gpu_max_abs_score_error_vs_f64"] <= SUM_ORDER_TOL and arb["gpu_max_f64_gap_between_misordered_rows"] <= SUM_ORDER_TOL, \
-                    "the GPU chain is further from the float64 order than the summation-order bound"
-            except AssertionError:
-                raise
-            except Exception as exc:
-                extra["cpu_path_parity"]["f64_arbiter"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            # parity with the reference CPU path at full size + the float64 arbiter (tools/bench_parity.py)
+            cpu_path_parity(rows, qvecs, sc, rk, sc_cpu, rk_cpu, gnd, vecs_host, extra, n_total, NQ)
             del vecs_host, rk_cpu, sc_cpu
         except Exception as exc:          # the reported baseline must not cost the measured line
             extra["cpu_baseline"] = {"value": None, "unit": "queries/s", "error": "%s: %s" % (type(exc).__name__, exc)}
