@@ -143,3 +143,22 @@ def test_late_round4_entry_points_check_their_arguments():
     assert h.mdx_rank_positions(None, 10, 1, 10, P(16), P(16), 1, P(16), None) == -1
     assert h.mdx_rank_positions(P(16), 10, 1, 5, P(16), P(16), 1, P(16), None) == -1                          # row stride < n
     assert h.mdx_rank_positions(P(16), 10, 1, 10, P(16), P(16), 0, P(16), None) == 0                          # nothing to look up
+
+
+def test_round6_entry_points_check_their_arguments():
+    """The direct-store exchange (mdx_p2p_* / mdx_scores_p2p) refuses bad arguments before touching a device."""
+    import ctypes
+    from mdir_amd import _lib
+    h = _lib.lib()
+    out, buf = ctypes.c_void_p(), (ctypes.c_char * 64)()
+    assert h.mdx_p2p_create(None, 2, 0, 70, 1000, buf) == -1 and b"NULL" in h.mdx_last_error()
+    assert h.mdx_p2p_create(ctypes.byref(out), 2, 2, 70, 1000, buf) == -1 and out.value is None          # rank out of range
+    assert h.mdx_p2p_create(ctypes.byref(out), 65, 0, 70, 1000, buf) == -1                               # more than 64 ranks
+    assert h.mdx_p2p_create(ctypes.byref(out), 8, 0, 129, 1000, buf) == -1 and b"nq" in h.mdx_last_error()     # at most 128 queries per step
+    assert h.mdx_p2p_create(ctypes.byref(out), 8, 0, 70, 0, buf) == -1
+    assert h.mdx_p2p_connect(None, buf) == -1 and h.mdx_p2p_connect_ptrs(None, None) == -1
+    assert h.mdx_scores_p2p(None, None, 70, 0, None, None, None, 0, None) == -1
+    mine = ctypes.c_void_p()
+    assert h.mdx_p2p_close_step(None, ctypes.byref(mine), None) == -1
+    assert h.mdx_p2p_status(None, None, None) == -1
+    assert h.mdx_p2p_destroy(None) == 0 and h.mdx_p2p_base(None) is None and h.mdx_p2p_bytes(None) == 0
