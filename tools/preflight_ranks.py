@@ -83,16 +83,25 @@ def run(n, first="torch", dryrun=None, timeout_s=150, python=sys.executable, onl
         cmd = [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__), "--form", form]
         verdict = {"form": form, "ok": False}
+        # the launcher and its rank processes are a process group of their own: a form that hangs is ended AS A WHOLE (killing only
+        # the launcher would orphan rank processes that keep their GPUs busy while the heavy run starts)
+        proc = subprocess.Popen(cmd, env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
         try:
-            proc = subprocess.run(cmd, env=env, text=True, capture_output=True, timeout=min(timeout_s, left))
-            lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+            out, err = proc.communicate(timeout=min(timeout_s, left))
+            lines = [ln for ln in out.splitlines() if ln.startswith("{")]
             if lines:
                 verdict.update(json.loads(lines[-1]))
             verdict["ok"] = bool(proc.returncode == 0 and verdict.get("ok"))
             if not verdict["ok"]:
-                verdict.setdefault("reason", "exit code %d: %s" % (proc.returncode, (proc.stderr or proc.stdout)[-600:]))
+                verdict.setdefault("reason", "exit code %d: %s" % (proc.returncode, (err or out)[-600:]))
         except subprocess.TimeoutExpired:
-            verdict["reason"] = "no answer within %d s (children ended)" % min(timeout_s, left)
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)          # exactly the group this call started
+            except (ProcessLookupError, PermissionError):
+                pass
+            proc.communicate()
+            verdict["reason"] = "no answer within %d s (launcher and rank processes ended)" % min(timeout_s, left)
         tried.append(verdict)
         if verdict["ok"]:
             chosen = form
