@@ -30,6 +30,14 @@ for it in range(iters):
     if not np.array_equal(got, want):
         bad += 1
         print("rank_full MISMATCH it=%d n=%d nq=%d kind=%d" % (it, n, nq, kind))
+    # the same scores as column blocks of random widths (the peer blocks of the multi-GPU exchange): tiles that end in the next block,
+    # blocks narrower than a tile, empty blocks -- the ranking read in place equals the dense one
+    cuts = np.sort(rng.choice(n + 1, size=int(min(n, rng.integers(1, 31))), replace=True))
+    edges = [0] + [int(c) for c in cuts] + [n]
+    blocks = [sd[:, a:b].contiguous() for a, b in zip(edges[:-1], edges[1:])]
+    if len(blocks) <= 32 and not np.array_equal(ops.rank_full_segments(blocks).cpu().numpy(), want):
+        bad += 1
+        print("rank_full_segments MISMATCH it=%d n=%d nq=%d kind=%d widths=%s" % (it, n, nq, kind, [b.shape[1] for b in blocks]))
     k = int(min(n, rng.integers(1, 300))) if it % 2 else int(max(1, min(n, n // 256)))    # every other one: sampled-threshold regime
     ids, vals = ops.topk(sd, k)
     if not np.array_equal(ids.cpu().numpy(), want[:, :k]):

@@ -44,6 +44,15 @@ for it in range(iters):
             if not np.array_equal(got_rm, want):
                 bad += 1
                 print("rowmajor MISMATCH it=%d rep=%d n=%d d=%d nq=%d: %d wrong" % (it, rep, n, d, nq, int((got_rm != want).sum())))
+        if storage == "f32" and nq <= 128 and rep == 3:      # round 6: the routed epilogue (mdx_scores_p2p, one rank: the buffer is local)
+            p2p = ops.P2P(1, 0, nq, n, "cuda")
+            p2p.connect([p2p.handle])
+            ix.scores_p2p(qd, p2p, "ND")
+            got_rt = p2p.close_step().cpu().numpy()
+            p2p.close()
+            if not np.array_equal(got_rt, want):
+                bad += 1
+                print("routed MISMATCH it=%d n=%d d=%d nq=%d: %d wrong" % (it, n, d, nq, int((got_rt != want).sum())))
         if not ok:
             bad += 1
             w = np.argwhere(got != want) if storage == "f32" else np.argwhere(np.abs(got - want) > 2e-6)
