@@ -22,7 +22,6 @@
 // invalidates what its L2s may still hold of the buffer from two steps ago.  HARDWARE STATUS: verified with several rank
 // processes on ONE GPU (same-device IPC; tests/test_gpu_round6.py) -- it has never run over xGMI; tools/preflight_ranks.py
 // checks it on the first multi-GPU node before bench.py uses it, and the all-to-all stays the default.
-#include <mutex>
 
 #include "mdx_common.h"
 
@@ -103,22 +102,24 @@ int mdx_p2p_create(mdx_p2p **out, int nranks, int rank, int64_t nq, int64_t n_to
         delete p;
         return MDX_ERR_NOMEM;
     }
-    e = hipMemset(p->base + p->flags_off, 0, (size_t)(p->total_bytes - p->flags_off));
     memset(handle_host, 0, MDX_P2P_HANDLE_BYTES);
-    if (e == hipSuccess && nranks > 1) {
+    e = hipMemset(p->base + p->flags_off, 0, (size_t)(p->total_bytes - p->flags_off));      // flags and status start at zero
+    if (e != hipSuccess || hipMalloc((void **)&p->routes, sizeof(float *) * 2 * nq) != hipSuccess ||
+        hipMalloc((void **)&p->peer_flags, sizeof(uint32_t *) * 64) != hipSuccess) {
+        set_error("mdx_p2p_create: %s", e != hipSuccess ? hipGetErrorString(e) : "hipMalloc of the route tables failed");
+        (void)hipGetLastError();
+        (void)hipFree(p->base);
+        if (p->routes) (void)hipFree(p->routes);
+        if (p->peer_flags) (void)hipFree(p->peer_flags);
+        delete p;
+        return e != hipSuccess ? MDX_ERR_RUNTIME : MDX_ERR_NOMEM;
+    }
+    e = hipSuccess;
+    if (nranks > 1) {
         hipIpcMemHandle_t h;
         e = hipIpcGetMemHandle(&h, p->base);
         if (e == hipSuccess) memcpy(handle_host, &h, sizeof h);
         else (void)hipGetLastError();           // a process that cannot export (no dmabuf IPC) can still be connected by pointers
-    }
-    if (e != hipSuccess && nranks == 1) e = hipSuccess;
-    if (hipMalloc((void **)&p->routes, sizeof(float *) * 2 * nq) != hipSuccess ||
-        hipMalloc((void **)&p->peer_flags, sizeof(uint32_t *) * 64) != hipSuccess) {
-        set_error("mdx_p2p_create: hipMalloc of the route tables failed");
-        (void)hipFree(p->base);
-        if (p->routes) (void)hipFree(p->routes);
-        delete p;
-        return MDX_ERR_NOMEM;
     }
     p->peer[rank] = p->base;
     *out = p;
