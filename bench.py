@@ -328,7 +328,7 @@ def main():
     torch.cuda.synchronize()
     selection = None
     if world > 1 and pre is not None and pre.get("p2p_probe", {}).get("ok") and not sharded._p2p_on and sharded.storage == "f32":
-        selection = select_exchange(sharded, step, keep, dryrun, device)
+        selection = select_exchange(sharded, step, keep, dryrun, device, qvecs)
     def timed_region():
         if world > 1:
             dist.barrier()

@@ -429,6 +429,54 @@ class ShardedIndex:
         self._p2p_on = bool(on)
         self.phases = None
 
+    def prepare_direct_store(self, nq):
+        """Everything the direct-store form needs BEFORE its first step, made with the ranks in lockstep: the whole-shard index,
+        the exchange object (handles gathered through the process group) and the peer mappings.  Returns True on every rank or
+        False on every rank -- a rank whose local part failed (no memory, a peer buffer it cannot map) drags the others out with
+        it through two MIN all-reduces, so nobody is left waiting in a collective the failed rank never reaches."""
+        from . import ops
+
+        def agree(ok):
+            if self.world == 1:
+                return bool(ok)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if self._host_staged else self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(int(flag.item()))
+        ok = self.storage == "f32" and not self._score_kw and self.device.type == "cuda"
+        if ok and self._whole is None:
+            try:
+                self._whole = self.backend.make_index(self._local[0], self._local[1], self.lo)
+            except Exception:               # noqa: BLE001 -- reported through the agreement below
+                ok = False
+        if not agree(ok):
+            return False
+        if self._p2p is not None and self._p2p.nq == nq and self._p2p.connected:
+            return True
+        if self._p2p is not None:
+            self._p2p.close()
+            self._p2p = None
+        me, ok = None, True
+        try:
+            me = ops.P2P(self.world, self.rank, nq, self.n_total, self.device)
+        except Exception:                   # noqa: BLE001
+            ok = False
+        handles = [(me.handle if me is not None else b"", bool(me is not None and (me.exportable or self.world == 1)))]
+        if self.world > 1:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, (me.handle if me is not None else b"", bool(me is not None and me.exportable)), group=self.group)
+        ok = all(good for _, good in handles)
+        if ok:
+            try:
+                me.connect([h for h, _ in handles])
+            except Exception:               # noqa: BLE001
+                ok = False
+        if not agree(ok):
+            if me is not None:
+                me.close()
+            return False
+        self._p2p = me
+        return True
+
     def _exchanged_p2p(self, queries, qlayout):
         """The direct-store form: every chunk's similarity kernel writes to the owners' buffers, one flag per peer closes the
         step, and MY queries' rows of ALL shards are one dense matrix (a view of the receive buffer, valid for two steps;
@@ -436,14 +484,12 @@ class ShardedIndex:
         from . import ops
         nq = queries.shape[1] if qlayout in ("DN", "dim_major") else queries.shape[0]
         if self._p2p is None or self._p2p.nq != nq:
-            if self._p2p is not None:
-                self._p2p.close()
-            self._p2p = ops.P2P.from_process_group(nq, self.n_total, self.device, self.group)
+            if not self.prepare_direct_store(nq):
+                raise RuntimeError("the direct-store exchange could not be set up on every rank (peer buffers could not be shared or "
+                                   "mapped: is HSA_ENABLE_IPC_MODE_LEGACY=0 set?); use the collective form")
         ev = self._events()
         if ev:
             ev[0].record()
-        if self._whole is None:
-            self._whole = self.backend.make_index(self._local[0], self._local[1], self.lo)
         self._whole.scores_p2p(queries, self._p2p, qlayout)
         if ev:
             ev[1].record()

@@ -40,7 +40,7 @@ def preflight(n):
     return pre
 
 
-def select_exchange(sharded, step, keep, dryrun, device, reps=3):
+def select_exchange(sharded, step, keep, dryrun, device, qvecs, reps=3):
     """Run time A/B of the two exchange forms on THIS node at the full size, outside the timed region: `reps` steps of the
     collective form, then of the direct-store form (which the preflight has just verified on a small problem with fresh
     processes).  The direct-store form is taken only if every rank's ranking is bit-identical to the collective form's, no
@@ -59,15 +59,34 @@ def select_exchange(sharded, step, keep, dryrun, device, reps=3):
     out = {"collective_ms": round(timed(), 4)}
     rk_a = keep["rk"].clone()
     ok, why = 1, ""
+    # set-up first, with the ranks in lockstep (every collective of it is reached by every rank, whatever fails locally): after it
+    # a direct-store step contains no collective, so a rank that fails INSIDE the trial cannot strand the others in one
+    nq = int(qvecs.shape[1])
+    if not sharded.prepare_direct_store(nq):
+        sharded.use_direct_store(False)
+        out.update({"direct_store_verified_equal": False, "chosen": "collective",
+                    "reason": "the direct-store exchange could not be set up on every rank"})
+        return out
+    sharded.use_direct_store(True)
+    trouble, real_step = [], step
+
+    def guarded_step():
+        if not trouble:
+            try:
+                real_step()
+            except Exception as exc:          # noqa: BLE001 -- this rank sits the rest of the trial out, the barriers below still match
+                trouble.append("%s: %s" % (type(exc).__name__, exc))
+    step = guarded_step                       # (what timed() calls)
     try:
-        sharded.use_direct_store(True)
         out["direct_store_ms"] = round(timed(), 4)
-        if not torch.equal(keep["rk"], rk_a):
-            ok, why = 0, "the direct-store ranking differs from the collective form's"
-        elif sharded._p2p is not None and sharded._p2p.late_peers() != 0:
-            ok, why = 0, "a peer's flag did not arrive"
-    except Exception as exc:          # noqa: BLE001 -- the collective form stays
-        ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+    finally:
+        step = real_step
+    if trouble:
+        ok, why = 0, trouble[0]
+    elif not torch.equal(keep["rk"], rk_a):
+        ok, why = 0, "the direct-store ranking differs from the collective form's"
+    elif sharded._p2p is not None and sharded._p2p.late_peers() != 0:
+        ok, why = 0, "a peer's flag did not arrive"
     flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if dryrun else device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     ok = int(flag.item())
